@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build libfod_hip.so (gfx950) in-tree.  hipcc cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+mkdir -p lib build
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-comment"
+pids=()
+for f in gemm_nt gemm_tn attention elementwise loss optim; do
+  hipcc $FLAGS -c csrc/$f.hip -o build/$f.o &
+  pids+=($!)
+done
+hipcc $FLAGS -c csrc/lap.cpp -o build/lap.o &
+pids+=($!)
+hipcc $FLAGS -c csrc/api.cpp -o build/api.o &
+pids+=($!)
+for p in "${pids[@]}"; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o lib/libfod_hip.so build/*.o -lpthread
+echo "built $(pwd)/lib/libfod_hip.so"

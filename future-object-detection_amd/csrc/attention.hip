@@ -1,0 +1,376 @@
+// Fused multi-head attention with per-head score = q1.k1 (+ q2.k2), head slices of 32 per part,
+// value head dim 32, online softmax, no N x N materialisation.  Forward + two backward passes.
+//
+//   one part  : encoder self-attention (torch nn.MultiheadAttention core, reference
+//               future_od/models/transformer.py:404,417) and decoder query self-attention (:61-82)
+//   two parts : conditional cross-attention, per-head [content(32) | sine(32)] queries and keys,
+//               scale 1/sqrt(64) (reference future_od/models/transformer.py:151-178; MHA core =
+//               ConditionalDETR.models.attention.MultiheadAttention, see oracle/thirdparty.py)
+//
+// Layout: q*, k*, v, o are [B, T, H*32] (token stride = H*32 by default; strides are arguments).
+// Each WAVE owns 32 query rows (fwd, dq pass) or 32 keys (dk/dv pass) and walks the other sequence
+// in tiles of 32 with everything in registers: the transposed score tile S^T = K.Q^T puts the query
+// on the lane, so the row max / row sum are lane-local plus one cross-half exchange, and the
+// exponentiated tile is directly the B operand of O^T += V^T.P^T (accumulator-as-operand, acc-order
+// kappa, common.h).  No LDS, no barriers.  Operand rows come straight from global/L2.
+//
+// lse is kept in log2 units: lse2[q] = max2 + log2(sum exp2(x - max2)), x = score*scale*log2(e).
+#include "common.h"
+
+namespace {
+
+struct AttnParams {
+  const void *q1, *k1, *q2, *k2, *v;
+  void* o;
+  float* lse2;
+  const void *dout, *out;
+  float* delta;
+  void *dq1, *dq2, *dk1, *dk2, *dv;
+  int B, H, Tq, S;
+  long q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
+  float scale;
+};
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <typename T>
+FOD_DEVINL void store4(T* p, float a, float b, float c, float d);
+template <>
+FOD_DEVINL void store4<float>(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
+}
+template <>
+FOD_DEVINL void store4<__bf16>(__bf16* p, float a, float b, float c, float d) {
+  *reinterpret_cast<bf16x4_t*>(p) = bf16x4_t{(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d};
+}
+
+// write a 32(d) x 32(token) transposed accumulator: lane = token, regs = d rows
+template <typename T>
+FOD_DEVINL void store_acc_t(T* rowptr, const f32x16& acc, int fh, float mul) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    store4<T>(rowptr + 8 * g + 4 * fh, acc[4 * g] * mul, acc[4 * g + 1] * mul, acc[4 * g + 2] * mul,
+              acc[4 * g + 3] * mul);
+}
+
+template <typename T>
+FOD_DEVINL void zero_acc(f32x16& a) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) a[r] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, int PARTS>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  if (q0 >= p.Tq) return;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q = min(q0 + fr, p.Tq - 1);
+  const T* Qp[2] = {reinterpret_cast<const T*>(p.q1), reinterpret_cast<const T*>(p.q2)};
+  const T* Kp[2] = {reinterpret_cast<const T*>(p.k1), reinterpret_cast<const T*>(p.k2)};
+  const T* Vp = reinterpret_cast<const T*>(p.v) + (long)b * p.v_bs + h * 32;
+
+  Frag<T> fq[PARTS][2];
+#pragma unroll
+  for (int pt = 0; pt < PARTS; ++pt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      frag_load_contig(fq[pt][s], Qp[pt] + (long)b * p.q_bs + (long)q * p.q_ts + h * 32 + 16 * s + 8 * fh);
+
+  const float c = p.scale * LOG2E;
+  float m = -INFINITY, l = 0.f;
+  f32x16 oacc;
+  zero_acc<T>(oacc);
+
+  for (int k0 = 0; k0 < p.S; k0 += 32) {
+    const int kr = min(k0 + fr, p.S - 1);
+    f32x16 sacc;
+    zero_acc<T>(sacc);
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        Frag<T> fk;
+        frag_load_contig(fk, Kp[pt] + (long)b * p.k_bs + (long)kr * p.k_ts + h * 32 + 16 * s + 8 * fh);
+        mma16(fk, fq[pt][s], sacc);
+      }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool ok = (k0 + acc_row(r, lane)) < p.S;
+      sacc[r] = ok ? sacc[r] * c : -INFINITY;
+      mx = fmaxf(mx, sacc[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = exp2f(m - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sacc[r] = exp2f(sacc[r] - m_new);
+      rs += sacc[r];
+    }
+    rs += __shfl_xor(rs, 32);
+    l = l * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      Frag<T> fp, fv;
+      frag_from_acc(fp, sacc, s);
+      frag_gather_accorder(fv, Vp + (long)k0 * p.v_ts + fr, p.v_ts, s, fh, p.S - k0);
+      mma16(fv, fp, oacc);
+    }
+  }
+  if (q0 + fr < p.Tq) {
+    T* op = reinterpret_cast<T*>(p.o) + (long)b * p.o_bs + (long)q * p.o_ts + h * 32;
+    store_acc_t<T>(op, oacc, fh, 1.f / l);
+    if (fh == 0) p.lse2[((long)b * p.H + h) * p.Tq + q] = m + log2f(l);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dq pass: wave owns 32 queries.  Also writes delta[q] = sum_d dO[q,d] * O[q,d].
+template <typename T, int PARTS>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  if (q0 >= p.Tq) return;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q = min(q0 + fr, p.Tq - 1);
+  const T* Qp[2] = {reinterpret_cast<const T*>(p.q1), reinterpret_cast<const T*>(p.q2)};
+  const T* Kp[2] = {reinterpret_cast<const T*>(p.k1), reinterpret_cast<const T*>(p.k2)};
+  const T* Vp = reinterpret_cast<const T*>(p.v) + (long)b * p.v_bs + h * 32;
+  const T* dOp = reinterpret_cast<const T*>(p.dout) + (long)b * p.o_bs + (long)q * p.o_ts + h * 32;
+  const T* Op = reinterpret_cast<const T*>(p.out) + (long)b * p.o_bs + (long)q * p.o_ts + h * 32;
+
+  Frag<T> fq[PARTS][2], fdo[2];
+  float dl = 0.f;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    Frag<T> fo;
+    frag_load_contig(fdo[s], dOp + 16 * s + 8 * fh);
+    frag_load_contig(fo, Op + 16 * s + 8 * fh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dl += to_f32(fdo[s].v[j]) * to_f32(fo.v[j]);
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt)
+      frag_load_contig(fq[pt][s], Qp[pt] + (long)b * p.q_bs + (long)q * p.q_ts + h * 32 + 16 * s + 8 * fh);
+  }
+  dl += __shfl_xor(dl, 32);
+  const long sidx = ((long)b * p.H + h) * p.Tq + q;
+  const float lse2 = p.lse2[sidx];
+  if (fh == 0 && q0 + fr < p.Tq) p.delta[sidx] = dl;
+
+  const float c = p.scale * LOG2E;
+  f32x16 dq[PARTS];
+#pragma unroll
+  for (int pt = 0; pt < PARTS; ++pt) zero_acc<T>(dq[pt]);
+
+  for (int k0 = 0; k0 < p.S; k0 += 32) {
+    const int kr = min(k0 + fr, p.S - 1);
+    f32x16 sacc, dpacc;
+    zero_acc<T>(sacc);
+    zero_acc<T>(dpacc);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt) {
+        Frag<T> fk;
+        frag_load_contig(fk, Kp[pt] + (long)b * p.k_bs + (long)kr * p.k_ts + h * 32 + 16 * s + 8 * fh);
+        mma16(fk, fq[pt][s], sacc);
+      }
+      Frag<T> fv;
+      frag_load_contig(fv, Vp + (long)kr * p.v_ts + 16 * s + 8 * fh);
+      mma16(fv, fdo[s], dpacc);             // dP^T[k, q] = sum_d V[k,d] dO[q,d]
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool ok = (k0 + acc_row(r, lane)) < p.S;
+      const float pr = ok ? exp2f(sacc[r] * c - lse2) : 0.f;
+      sacc[r] = pr * (dpacc[r] - dl) * p.scale;      // dS^T
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      Frag<T> fds;
+      frag_from_acc(fds, sacc, s);
+#pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt) {
+        Frag<T> fkt;   // K^T: row = d (lane), kappa = key
+        frag_gather_accorder(fkt, Kp[pt] + (long)b * p.k_bs + (long)k0 * p.k_ts + h * 32 + fr, p.k_ts, s, fh,
+                             p.S - k0);
+        mma16(fkt, fds, dq[pt]);             // dQ^T[d, q] += sum_k K[k,d] dS^T[k,q]
+      }
+    }
+  }
+  if (q0 + fr < p.Tq) {
+    T* d1 = reinterpret_cast<T*>(p.dq1) + (long)b * p.q_bs + (long)q * p.q_ts + h * 32;
+    store_acc_t<T>(d1, dq[0], fh, 1.f);
+    if (PARTS == 2) {
+      T* d2 = reinterpret_cast<T*>(p.dq2) + (long)b * p.q_bs + (long)q * p.q_ts + h * 32;
+      store_acc_t<T>(d2, dq[PARTS - 1], fh, 1.f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dk/dv pass: wave owns 32 keys (key on the lane); needs lse2 and delta from the passes above.
+template <typename T, int PARTS>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int k0 = (blockIdx.x * 4 + wave) * 32;
+  if (k0 >= p.S) return;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int key = min(k0 + fr, p.S - 1);
+  const T* Qp[2] = {reinterpret_cast<const T*>(p.q1), reinterpret_cast<const T*>(p.q2)};
+  const T* Kp[2] = {reinterpret_cast<const T*>(p.k1), reinterpret_cast<const T*>(p.k2)};
+  const T* Vp = reinterpret_cast<const T*>(p.v) + (long)b * p.v_bs + (long)key * p.v_ts + h * 32;
+  const T* dOb = reinterpret_cast<const T*>(p.dout) + (long)b * p.o_bs + h * 32;
+
+  Frag<T> fk[PARTS][2], fv[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    frag_load_contig(fv[s], Vp + 16 * s + 8 * fh);
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt)
+      frag_load_contig(fk[pt][s], Kp[pt] + (long)b * p.k_bs + (long)key * p.k_ts + h * 32 + 16 * s + 8 * fh);
+  }
+  const float c = p.scale * LOG2E;
+  f32x16 dk[PARTS], dv;
+  zero_acc<T>(dv);
+#pragma unroll
+  for (int pt = 0; pt < PARTS; ++pt) zero_acc<T>(dk[pt]);
+  const float* lse_b = p.lse2 + ((long)b * p.H + h) * p.Tq;
+  const float* del_b = p.delta + ((long)b * p.H + h) * p.Tq;
+
+  for (int q0 = 0; q0 < p.Tq; q0 += 32) {
+    const int qr = min(q0 + fr, p.Tq - 1);
+    f32x16 sacc, dpacc;
+    zero_acc<T>(sacc);
+    zero_acc<T>(dpacc);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt) {
+        Frag<T> fqq;
+        frag_load_contig(fqq, Qp[pt] + (long)b * p.q_bs + (long)qr * p.q_ts + h * 32 + 16 * s + 8 * fh);
+        mma16(fqq, fk[pt][s], sacc);          // S[q, key]
+      }
+      Frag<T> fdo;
+      frag_load_contig(fdo, dOb + (long)qr * p.o_ts + 16 * s + 8 * fh);
+      mma16(fdo, fv[s], dpacc);               // dP[q, key] = sum_d dO[q,d] V[key,d]
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qq = q0 + acc_row(r, lane);
+      const bool ok = qq < p.Tq;
+      const int qc = ok ? qq : 0;
+      const float pr = ok ? exp2f(sacc[r] * c - lse_b[qc]) : 0.f;
+      dpacc[r] = pr * (dpacc[r] - del_b[qc]) * p.scale;   // dS
+      sacc[r] = pr;                                       // P
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      Frag<T> fp, fds, fdot;
+      frag_from_acc(fp, sacc, s);
+      frag_from_acc(fds, dpacc, s);
+      frag_gather_accorder(fdot, dOb + (long)q0 * p.o_ts + fr, p.o_ts, s, fh, p.Tq - q0);
+      mma16(fdot, fp, dv);                    // dV^T[d, key] += sum_q dO[q,d] P[q,key]
+#pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt) {
+        Frag<T> fqt;
+        frag_gather_accorder(fqt, Qp[pt] + (long)b * p.q_bs + (long)q0 * p.q_ts + h * 32 + fr, p.q_ts, s, fh,
+                             p.Tq - q0);
+        mma16(fqt, fds, dk[pt]);              // dK^T[d, key] += sum_q Q[q,d] dS[q,key]
+      }
+    }
+  }
+  if (k0 + fr < p.S) {
+    T* o = reinterpret_cast<T*>(p.dv) + (long)b * p.v_bs + (long)key * p.v_ts + h * 32;
+    store_acc_t<T>(o, dv, fh, 1.f);
+    T* d1 = reinterpret_cast<T*>(p.dk1) + (long)b * p.k_bs + (long)key * p.k_ts + h * 32;
+    store_acc_t<T>(d1, dk[0], fh, 1.f);
+    if (PARTS == 2) {
+      T* d2 = reinterpret_cast<T*>(p.dk2) + (long)b * p.k_bs + (long)key * p.k_ts + h * 32;
+      store_acc_t<T>(d2, dk[PARTS - 1], fh, 1.f);
+    }
+  }
+}
+
+template <typename T, int PARTS>
+int launch_all(int which, const AttnParams& p, hipStream_t stream) {
+  const dim3 block(256);
+  if (which == 0) {
+    const dim3 grid(ceil_div(p.Tq, 128), p.H, p.B);
+    hipLaunchKernelGGL((attn_fwd_kernel<T, PARTS>), grid, block, 0, stream, p);
+  } else if (which == 1) {
+    const dim3 grid(ceil_div(p.Tq, 128), p.H, p.B);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, PARTS>), grid, block, 0, stream, p);
+  } else {
+    const dim3 grid(ceil_div(p.S, 128), p.H, p.B);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, PARTS>), grid, block, 0, stream, p);
+  }
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
+}
+
+int dispatch(int dtype, int parts, int which, const AttnParams& p, hipStream_t stream) {
+  if (dtype == FOD_BF16) return parts == 2 ? launch_all<__bf16, 2>(which, p, stream) : launch_all<__bf16, 1>(which, p, stream);
+  if (dtype == FOD_F32) return parts == 2 ? launch_all<float, 2>(which, p, stream) : launch_all<float, 1>(which, p, stream);
+  fod_set_error("attention: bad dtype %d", dtype);
+  return FOD_ERR_ARG;
+}
+
+int fill(AttnParams& p, const fod_attn_shape* s) {
+  FOD_REQUIRE(s, "attention: null shape");
+  FOD_REQUIRE(s->B > 0 && s->H > 0 && s->Tq > 0 && s->S > 0, "attention: empty shape");
+  FOD_REQUIRE(s->B <= 65535 && s->H <= 65535, "attention: grid too large");
+  p.B = s->B; p.H = s->H; p.Tq = s->Tq; p.S = s->S;
+  p.q_bs = s->q_batch_stride; p.q_ts = s->q_token_stride;
+  p.k_bs = s->k_batch_stride; p.k_ts = s->k_token_stride;
+  p.v_bs = s->v_batch_stride; p.v_ts = s->v_token_stride;
+  p.o_bs = s->o_batch_stride; p.o_ts = s->o_token_stride;
+  p.scale = s->scale;
+  FOD_REQUIRE(p.q_ts % 8 == 0 && p.k_ts % 8 == 0 && p.v_ts % 8 == 0 && p.o_ts % 8 == 0 && p.q_bs % 8 == 0 &&
+                  p.k_bs % 8 == 0 && p.v_bs % 8 == 0 && p.o_bs % 8 == 0,
+              "attention: strides must be multiples of 8 elements");
+  return FOD_OK;
+}
+
+}  // namespace
+
+extern "C" int fod_attn_fwd(int dtype, const void* q1, const void* k1, const void* q2, const void* k2,
+                            const void* v, void* o, float* lse2, const fod_attn_shape* shape,
+                            hipStream_t stream) {
+  AttnParams p{};
+  int rc = fill(p, shape);
+  if (rc) return rc;
+  FOD_REQUIRE(q1 && k1 && v && o && lse2, "attn_fwd: null operand");
+  FOD_REQUIRE((q2 == nullptr) == (k2 == nullptr), "attn_fwd: q2/k2 must come together");
+  p.q1 = q1; p.k1 = k1; p.q2 = q2; p.k2 = k2; p.v = v; p.o = o; p.lse2 = lse2;
+  return dispatch(dtype, q2 ? 2 : 1, 0, p, stream);
+}
+
+extern "C" int fod_attn_bwd(int dtype, const void* q1, const void* k1, const void* q2, const void* k2,
+                            const void* v, const void* o, const void* dout, const float* lse2, float* delta,
+                            void* dq1, void* dk1, void* dq2, void* dk2, void* dv,
+                            const fod_attn_shape* shape, hipStream_t stream) {
+  AttnParams p{};
+  int rc = fill(p, shape);
+  if (rc) return rc;
+  FOD_REQUIRE(q1 && k1 && v && o && dout && lse2 && delta && dq1 && dk1 && dv, "attn_bwd: null operand");
+  FOD_REQUIRE((q2 == nullptr) == (k2 == nullptr) && (q2 == nullptr) == (dq2 == nullptr) &&
+                  (q2 == nullptr) == (dk2 == nullptr), "attn_bwd: part-2 pointers must come together");
+  p.q1 = q1; p.k1 = k1; p.q2 = q2; p.k2 = k2; p.v = v; p.out = o; p.dout = dout;
+  p.lse2 = const_cast<float*>(lse2); p.delta = delta;
+  p.dq1 = dq1; p.dk1 = dk1; p.dq2 = dq2; p.dk2 = dk2; p.dv = dv;
+  const int parts = q2 ? 2 : 1;
+  rc = dispatch(dtype, parts, 1, p, stream);
+  if (rc) return rc;
+  return dispatch(dtype, parts, 2, p, stream);
+}

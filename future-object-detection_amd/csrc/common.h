@@ -1,0 +1,128 @@
+// Shared device helpers for the fod HIP kernels (gfx950 / CDNA4 only).
+//
+// One abstraction carries both arithmetic modes through every MFMA kernel:
+//   a "k-step" of 16 along the contraction dimension.
+//     bf16 : one v_mfma_f32_32x32x16_bf16 ; operand fragment = 8 bf16 per lane
+//     f32  : eight v_mfma_f32_32x32x2_f32 ; operand fragment = 8 f32 per lane, MFMA j uses element j
+//   Element j of lane-half h (h = lane>>5) stands for contraction index kappa(h, j); any kappa is
+//   legal as long as both operands use the same one.  Two are used:
+//     natural  : kappa = 8h + j                       (both operands come from memory)
+//     acc-order: kappa = 8(j>>2) + 4h + (j&3)         (one operand is regs 8s..8s+7 of a 32x32 result)
+//   C/D layout of every 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fod.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+
+#define FOD_DEVINL __device__ __forceinline__
+
+void fod_set_error(const char* fmt, ...);
+#define FOD_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      fod_set_error(__VA_ARGS__);       \
+      return FOD_ERR_ARG;               \
+    }                                   \
+  } while (0)
+#define FOD_LAUNCH_CHECK()                                              \
+  do {                                                                  \
+    hipError_t e__ = hipGetLastError();                                 \
+    if (e__ != hipSuccess) {                                            \
+      fod_set_error("%s:%d launch: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return FOD_ERR_LAUNCH;                                            \
+    }                                                                   \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static constexpr int VEC = 4;      // elements per 16-byte chunk
+  static constexpr int DT = FOD_F32;
+};
+template <>
+struct Elem<__bf16> {
+  static constexpr int VEC = 8;
+  static constexpr int DT = FOD_BF16;
+};
+
+FOD_DEVINL float to_f32(float x) { return x; }
+FOD_DEVINL float to_f32(__bf16 x) { return (float)x; }
+template <typename T>
+FOD_DEVINL T from_f32(float x) { return (T)x; }
+
+// 8-element operand fragment
+template <typename T>
+struct Frag;
+template <>
+struct Frag<__bf16> {
+  bf16x8_t v;
+};
+template <>
+struct Frag<float> {
+  float v[8];
+};
+
+// acc += A(32 x 16) * B(16 x 32)
+FOD_DEVINL void mma16(const Frag<__bf16>& a, const Frag<__bf16>& b, f32x16& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+FOD_DEVINL void mma16(const Frag<float>& a, const Frag<float>& b, f32x16& acc) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+
+// fragment from 8 consecutive elements (natural kappa): p points at element k0 + 8h of the lane's row
+FOD_DEVINL void frag_load_contig(Frag<__bf16>& f, const __bf16* p) {
+  f.v = *reinterpret_cast<const bf16x8_t*>(p);
+}
+FOD_DEVINL void frag_load_contig(Frag<float>& f, const float* p) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+  f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+  f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+template <typename T>
+FOD_DEVINL void frag_zero(Frag<T>& f) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = (T)0.f;
+}
+// fragment from regs 8s..8s+7 of a 32x32 accumulator (acc-order kappa)
+template <typename T>
+FOD_DEVINL void frag_from_acc(Frag<T>& f, const f32x16& acc, int s) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = (T)acc[8 * s + j];
+}
+// fragment gathered column-wise: element j <- base[row_j * stride], rows in acc-order:
+//   row_j = 16*s + 8*(j>>2) + 4*h + (j&3);  rows >= nrows read as zero
+template <typename T>
+FOD_DEVINL void frag_gather_accorder(Frag<T>& f, const T* base, long stride, int s, int h, int nrows) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int r = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+    f.v[j] = (r < nrows) ? base[(long)r * stride] : (T)0.f;
+  }
+}
+
+FOD_DEVINL int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+FOD_DEVINL float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+FOD_DEVINL float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

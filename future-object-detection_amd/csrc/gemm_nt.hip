@@ -1,0 +1,347 @@
+// NT contraction with an optional implicit-GEMM gather on the row operand:
+//
+//     C[m, n] = epilogue( sum_k A(m, k) * B[n, k] )
+//
+//   MODE_DENSE  : A(m,k) = A[(m % a_row_mod) * lda + k]            (nn.Linear forward / input-grad)
+//   MODE_CONV   : A(m,k) = x[img, ho*stride-pad+r, wo*stride-pad+s, c]   m=(img,ho,wo) k=(r,s,c)
+//                 (NHWC convolution forward; B = weight [Cout][kh][kw][Cin])
+//   MODE_DGRAD  : A(m,k) = dy[img, (hi+pad-r)/stride, (wi+pad-s)/stride, co]  m=(img,hi,wi) k=(r,s,co)
+//                 (convolution input-gradient; B = weight re-laid as [Cin][kh][kw][Cout])
+//
+// Replaces, on the reference path, every torch conv2d / linear forward and input-gradient:
+//   torchvision ResNet convs via reference future_od/models/paper.py:114-116, nn.Linear in
+//   future_od/models/transformer.py:54-58,88-91,407-411 and paper.py:302-303.
+//
+// Tile 128 x (64|128) x 128 bytes-of-k, 256 threads = 4 waves (2x2), 32x32 MFMA tiles, double-buffered
+// LDS with one barrier per k-tile, register-staged global->LDS copies, XOR-swizzled 16-byte chunks
+// (chunk ^ ((row>>1)&7): conflict-free for ds_read_b128 fragments and ds_write_b128 staging).
+#include "common.h"
+
+namespace {
+
+enum { MODE_DENSE = 0, MODE_CONV = 1, MODE_DGRAD = 2 };
+
+struct NtParams {
+  const void* A;
+  const void* B;
+  void* C;
+  long lda, ldb, ldc;
+  int M, N, K;
+  int a_row_mod;
+  const float* scale;
+  const float* shift;
+  const void* res;
+  long ldr;
+  int res_row_mod;
+  const void* mask;
+  long ldmask;
+  int relu;
+  int c_is_f32;
+  // gather geometry
+  int Hs, Ws, Cs;   // source image dims / channels
+  int Hd, Wd;       // m-domain dims
+  int kh, kw, stride, pad;
+};
+
+constexpr int BM = 128;
+constexpr int ROW_BYTES = 128;   // bytes of k per tile row
+
+FOD_DEVINL int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T, int MODE, int NT>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int BK = ROW_BYTES / (int)sizeof(T);
+  constexpr int BN = 64 * NT;
+  constexpr int KSTEPS = BK / 16;
+  constexpr int BROWS = BN / 32;   // B rows per thread (32 rows per pass)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;                       // 2 x BM x 128
+  unsigned char* sB = smem + 2 * BM * ROW_BYTES;  // 2 x BN x 128
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM;
+  const int cc = tid & 7;     // 16-byte chunk column handled by this thread
+  const int r0 = tid >> 3;    // first tile row handled by this thread (then +32, +64, +96)
+
+  // ---- per-row gather state (fixed over the k loop)
+  long a_base[4];
+  int a_h[4], a_w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + r0 + 32 * i;
+    const bool valid = m < p.M;
+    if (MODE == MODE_DENSE) {
+      const int row = p.a_row_mod > 0 ? (m % p.a_row_mod) : m;
+      a_base[i] = valid ? (long)row * p.lda : -1;
+      a_h[i] = a_w[i] = 0;
+    } else {
+      const int hw = p.Hd * p.Wd;
+      const int img = m / hw;
+      const int rem = m - img * hw;
+      const int ph = rem / p.Wd;
+      const int pw = rem - ph * p.Wd;
+      a_base[i] = (long)img * p.Hs * p.Ws * p.Cs;
+      if (MODE == MODE_CONV) {
+        a_h[i] = valid ? ph * p.stride - p.pad : -(1 << 28);
+        a_w[i] = pw * p.stride - p.pad;
+      } else {
+        a_h[i] = valid ? ph + p.pad : -(1 << 28);
+        a_w[i] = pw + p.pad;
+      }
+    }
+  }
+  long b_base[BROWS];
+#pragma unroll
+  for (int i = 0; i < BROWS; ++i) {
+    const int n = n0 + r0 + 32 * i;
+    b_base[i] = (n < p.N) ? (long)n * p.ldb : -1;
+  }
+
+  const T* __restrict__ Ap = reinterpret_cast<const T*>(p.A);
+  const T* __restrict__ Bp = reinterpret_cast<const T*>(p.B);
+
+  uint4 ra[4], rb[BROWS];
+  auto load_tile = [&](int kt) {
+    const int k = kt * BK + cc * VEC;
+    const bool kin = k < p.K;
+    int r = 0, s = 0, c = k;
+    if (MODE != MODE_DENSE) {
+      const int tap = k / p.Cs;
+      c = k - tap * p.Cs;
+      r = tap / p.kw;
+      s = tap - r * p.kw;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (MODE == MODE_DENSE) {
+        if (kin && a_base[i] >= 0) v = *reinterpret_cast<const uint4*>(Ap + a_base[i] + k);
+      } else if (MODE == MODE_CONV) {
+        const int hs = a_h[i] + r, ws = a_w[i] + s;
+        if (kin && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws)
+          v = *reinterpret_cast<const uint4*>(Ap + a_base[i] + ((long)hs * p.Ws + ws) * p.Cs + c);
+      } else {
+        const int th = a_h[i] - r, tw = a_w[i] - s;
+        const int sm = p.stride - 1;   // stride is 1 or 2
+        const int hs = th >> (p.stride >> 1), ws = tw >> (p.stride >> 1);
+        if (kin && th >= 0 && tw >= 0 && ((th | tw) & sm) == 0 && hs < p.Hs && ws < p.Ws)
+          v = *reinterpret_cast<const uint4*>(Ap + a_base[i] + ((long)hs * p.Ws + ws) * p.Cs + c);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (kin && b_base[i] >= 0) v = *reinterpret_cast<const uint4*>(Bp + b_base[i] + k);
+      rb[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<uint4*>(sA + buf * BM * ROW_BYTES + lds_off(r0 + 32 * i, cc)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i)
+      *reinterpret_cast<uint4*>(sB + buf * BN * ROW_BYTES + lds_off(r0 + 32 * i, cc)) = rb[i];
+  };
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nkt = (p.K + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int fr = lane & 31, fh = lane >> 5;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) load_tile(kt + 1);
+    const unsigned char* a_s = sA + buf * BM * ROW_BYTES;
+    const unsigned char* b_s = sB + buf * BN * ROW_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      Frag<T> fa[2], fb[NT];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = wm * 64 + i * 32 + fr;
+        if (sizeof(T) == 2) {
+          const uint4 v = *reinterpret_cast<const uint4*>(a_s + lds_off(row, 2 * ks + fh));
+          __builtin_memcpy(&fa[i], &v, 16);
+        } else {
+          const uint4 v0 = *reinterpret_cast<const uint4*>(a_s + lds_off(row, 4 * ks + 2 * fh));
+          const uint4 v1 = *reinterpret_cast<const uint4*>(a_s + lds_off(row, 4 * ks + 2 * fh + 1));
+          __builtin_memcpy(reinterpret_cast<char*>(&fa[i]), &v0, 16);
+          __builtin_memcpy(reinterpret_cast<char*>(&fa[i]) + 16, &v1, 16);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int row = wn * (32 * NT) + j * 32 + fr;
+        if (sizeof(T) == 2) {
+          const uint4 v = *reinterpret_cast<const uint4*>(b_s + lds_off(row, 2 * ks + fh));
+          __builtin_memcpy(&fb[j], &v, 16);
+        } else {
+          const uint4 v0 = *reinterpret_cast<const uint4*>(b_s + lds_off(row, 4 * ks + 2 * fh));
+          const uint4 v1 = *reinterpret_cast<const uint4*>(b_s + lds_off(row, 4 * ks + 2 * fh + 1));
+          __builtin_memcpy(reinterpret_cast<char*>(&fb[j]), &v0, 16);
+          __builtin_memcpy(reinterpret_cast<char*>(&fb[j]) + 16, &v1, 16);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) mma16(fa[i], fb[j], acc[i][j]);
+    }
+    if (kt + 1 < nkt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: scale/shift per column, residual, relu, mask, store
+  const T* __restrict__ Rp = reinterpret_cast<const T*>(p.res);
+  const T* __restrict__ Mp = reinterpret_cast<const T*>(p.mask);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wn * (32 * NT) + j * 32 + fr;
+    if (n >= p.N) continue;
+    const float sc = p.scale ? p.scale[n] : 1.f;
+    const float sh = p.shift ? p.shift[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+        if (m >= p.M) continue;
+        float v = acc[i][j][r] * sc + sh;
+        if (Rp) {
+          const int rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
+          v += to_f32(Rp[(long)rm * p.ldr + n]);
+        }
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (Mp) v = (to_f32(Mp[(long)m * p.ldmask + n]) > 0.f) ? v : 0.f;
+        if (p.c_is_f32)
+          reinterpret_cast<float*>(p.C)[(long)m * p.ldc + n] = v;
+        else
+          reinterpret_cast<T*>(p.C)[(long)m * p.ldc + n] = from_f32<T>(v);
+      }
+    }
+  }
+}
+
+template <typename T, int MODE>
+int launch_nt(const NtParams& p, hipStream_t stream) {
+  const bool narrow = p.N <= 64;
+  const dim3 block(256);
+  if (narrow) {
+    const dim3 grid(ceil_div(p.N, 64), ceil_div(p.M, BM));
+    const size_t lds = 2 * (BM + 64) * ROW_BYTES;
+    hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 1>), grid, block, lds, stream, p);
+  } else {
+    const dim3 grid(ceil_div(p.N, 128), ceil_div(p.M, BM));
+    const size_t lds = 2 * (BM + 128) * ROW_BYTES;
+    hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 2>), grid, block, lds, stream, p);
+  }
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
+}
+
+template <int MODE>
+int dispatch_nt(int dtype, const NtParams& p, hipStream_t stream) {
+  if (dtype == FOD_BF16) return launch_nt<__bf16, MODE>(p, stream);
+  if (dtype == FOD_F32) return launch_nt<float, MODE>(p, stream);
+  fod_set_error("gemm_nt: bad dtype %d", dtype);
+  return FOD_ERR_ARG;
+}
+
+int check_epilogue(const fod_epilogue* e) {
+  (void)e;
+  return FOD_OK;
+}
+
+void fill_epilogue(NtParams& p, const fod_epilogue* e) {
+  p.scale = e ? e->scale : nullptr;
+  p.shift = e ? e->shift : nullptr;
+  p.res = e ? e->residual : nullptr;
+  p.ldr = e ? e->ld_residual : 0;
+  p.res_row_mod = e ? e->residual_row_mod : 0;
+  p.mask = e ? e->relu_mask : nullptr;
+  p.ldmask = e ? e->ld_mask : 0;
+  p.relu = e ? e->relu : 0;
+  p.c_is_f32 = e ? e->out_f32 : 0;
+}
+
+}  // namespace
+
+extern "C" int fod_gemm_nt(int dtype, const void* A, long lda, int a_row_mod, const void* B, long ldb,
+                           void* C, long ldc, int M, int N, int K, const fod_epilogue* epi,
+                           hipStream_t stream) {
+  const int vec = dtype == FOD_BF16 ? 8 : 4;
+  FOD_REQUIRE(A && B && C, "gemm_nt: null operand");
+  FOD_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem %d %d %d", M, N, K);
+  FOD_REQUIRE(K % vec == 0 && lda % vec == 0 && ldb % vec == 0,
+              "gemm_nt: K=%d lda=%ld ldb=%ld must be multiples of %d", K, lda, ldb, vec);
+  FOD_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm_nt: operands must be 16-byte aligned");
+  NtParams p{};
+  p.A = A; p.B = B; p.C = C;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K;
+  p.a_row_mod = a_row_mod;
+  fill_epilogue(p, epi);
+  return dispatch_nt<MODE_DENSE>(dtype, p, stream);
+}
+
+static int conv_common(int dtype, bool dgrad, const void* src, const void* w, void* dst,
+                       const fod_conv_geom* g, const fod_epilogue* epi, hipStream_t stream) {
+  const int vec = dtype == FOD_BF16 ? 8 : 4;
+  FOD_REQUIRE(src && w && dst && g, "conv: null operand");
+  FOD_REQUIRE(g->stride == 1 || g->stride == 2, "conv: stride %d unsupported", g->stride);
+  const int Ho = (g->H + 2 * g->pad - g->kh) / g->stride + 1;
+  const int Wo = (g->W + 2 * g->pad - g->kw) / g->stride + 1;
+  FOD_REQUIRE(Ho == g->Ho && Wo == g->Wo, "conv: geometry mismatch Ho=%d/%d Wo=%d/%d", g->Ho, Ho, g->Wo, Wo);
+  FOD_REQUIRE(g->Cin % vec == 0 && g->Cout % vec == 0, "conv: channels %d/%d must be multiples of %d",
+              g->Cin, g->Cout, vec);
+  FOD_REQUIRE(((uintptr_t)src % 16) == 0 && ((uintptr_t)w % 16) == 0, "conv: operands must be 16-byte aligned");
+  NtParams p{};
+  p.A = src; p.B = w; p.C = dst;
+  p.kh = g->kh; p.kw = g->kw; p.stride = g->stride; p.pad = g->pad;
+  if (!dgrad) {
+    p.Hs = g->H; p.Ws = g->W; p.Cs = g->Cin;
+    p.Hd = g->Ho; p.Wd = g->Wo;
+    p.M = g->Nimg * g->Ho * g->Wo;
+    p.N = g->Cout;
+    p.K = g->kh * g->kw * g->Cin;
+  } else {
+    p.Hs = g->Ho; p.Ws = g->Wo; p.Cs = g->Cout;
+    p.Hd = g->H; p.Wd = g->W;
+    p.M = g->Nimg * g->H * g->W;
+    p.N = g->Cin;
+    p.K = g->kh * g->kw * g->Cout;
+  }
+  FOD_REQUIRE((long)g->Nimg * g->H * g->W < (1L << 31) && (long)g->Nimg * g->Ho * g->Wo < (1L << 31),
+              "conv: pixel count overflows int");
+  p.ldb = p.K;
+  p.ldc = p.N;
+  fill_epilogue(p, epi);
+  if (!dgrad) return dispatch_nt<MODE_CONV>(dtype, p, stream);
+  return dispatch_nt<MODE_DGRAD>(dtype, p, stream);
+}
+
+extern "C" int fod_conv2d_fwd(int dtype, const void* x, const void* w, void* y, const fod_conv_geom* g,
+                              const fod_epilogue* epi, hipStream_t stream) {
+  return conv_common(dtype, false, x, w, y, g, epi, stream);
+}
+
+extern "C" int fod_conv2d_dgrad(int dtype, const void* dy, const void* w_t, void* dx, const fod_conv_geom* g,
+                                const fod_epilogue* epi, hipStream_t stream) {
+  return conv_common(dtype, true, dy, w_t, dx, g, epi, stream);
+}

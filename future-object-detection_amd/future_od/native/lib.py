@@ -1,0 +1,110 @@
+"""ctypes binding of libfod_hip.so (include/fod.h).
+
+The HIP library IS the compute path: if it is missing or its ABI disagrees, importing this
+module raises -- there is no CPU or eager-PyTorch fallback behind these calls.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libfod_hip.so"))
+ABI_VERSION = 1
+
+F32, BF16 = 0, 1
+EW_ADD, EW_MUL, EW_RELU_MASK, EW_SCALE, EW_ADD3, EW_RELU = range(6)
+
+
+class FodError(RuntimeError):
+    pass
+
+
+class Epilogue(C.Structure):
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("residual", C.c_void_p),
+                ("ld_residual", C.c_long), ("residual_row_mod", C.c_int), ("relu_mask", C.c_void_p),
+                ("ld_mask", C.c_long), ("relu", C.c_int), ("out_f32", C.c_int)]
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [("Nimg", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Cin", C.c_int),
+                ("Ho", C.c_int), ("Wo", C.c_int), ("Cout", C.c_int),
+                ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int)]
+
+
+class AttnShape(C.Structure):
+    _fields_ = [("B", C.c_int), ("H", C.c_int), ("Tq", C.c_int), ("S", C.c_int),
+                ("q_batch_stride", C.c_long), ("q_token_stride", C.c_long),
+                ("k_batch_stride", C.c_long), ("k_token_stride", C.c_long),
+                ("v_batch_stride", C.c_long), ("v_token_stride", C.c_long),
+                ("o_batch_stride", C.c_long), ("o_token_stride", C.c_long),
+                ("scale", C.c_float)]
+
+
+_i, _l, _f, _p = C.c_int, C.c_long, C.c_float, C.c_void_p
+_EP, _CG, _AS = C.POINTER(Epilogue), C.POINTER(ConvGeom), C.POINTER(AttnShape)
+
+# name -> argtypes, exactly the prototypes of include/fod.h (stream last unless host-only)
+SIGNATURES = {
+    "fod_gemm_nt": [_i, _p, _l, _i, _p, _l, _p, _l, _i, _i, _i, _EP, _p],
+    "fod_gemm_tn_acc": [_i, _p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p],
+    "fod_colsum_acc": [_i, _p, _l, _i, _i, _i, _p, _p],
+    "fod_conv2d_fwd": [_i, _p, _p, _p, _CG, _EP, _p],
+    "fod_conv2d_dgrad": [_i, _p, _p, _p, _CG, _EP, _p],
+    "fod_conv2d_wgrad_acc": [_i, _p, _p, _p, _CG, _p, _p],
+    "fod_maxpool3x3s2": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "fod_nchw_to_nhwc": [_i, _p, _p, _i, _i, _i, _i, _i, _p],
+    "fod_permute3_cast": [_i, _i, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _i, _p],
+    "fod_attn_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _AS, _p],
+    "fod_attn_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _AS, _p],
+    "fod_layernorm_fwd": [_i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
+    "fod_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "fod_eltwise": [_i, _i, _p, _p, _p, _p, _l, _i, _i, _i, _f, _p],
+    "fod_posenc_table": [_i, _p, _i, _i, _i, _f, _p],
+    "fod_posenc_temporal": [_i, _p, _p, _i, _i, _i, _f, _f, _p],
+    "fod_refpoint_sine_fwd": [_i, _p, _p, _p, _i, _i, _p],
+    "fod_refpoint_sine_bwd": [_i, _p, _p, _p, _p, _i, _i, _p],
+    "fod_box_finish_fwd": [_i, _p, _p, _p, _i, _i, _p],
+    "fod_box_finish_bwd": [_i, _p, _p, _p, _p, _p, _i, _i, _p],
+    "fod_match_cost": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _p],
+    "fod_lap_solve_batch_host": [_p, _i, _i, _i, _p, _p, _i],
+    "fod_set_loss_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
+    "fod_set_loss_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
+    "fod_od_map": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p],
+    "fod_post_proc": [_p, _p, _p, _p, _i, _i, _f, _f, _p],
+    "fod_adamw_step": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _p, _p],
+    "fod_grad_sqnorm_acc": [_p, _l, _p, _p],
+}
+EXPORTS = sorted(list(SIGNATURES) + ["fod_last_error", "fod_abi_version"])
+
+
+def _load():
+    if not os.path.isfile(LIB_PATH):
+        raise FodError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or future-object-detection_amd/build.sh). There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    lib.fod_abi_version.restype = C.c_int
+    lib.fod_abi_version.argtypes = []
+    if lib.fod_abi_version() != ABI_VERSION:
+        raise FodError(f"libfod_hip.so ABI {lib.fod_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
+    lib.fod_last_error.restype = C.c_size_t
+    lib.fod_last_error.argtypes = [C.c_char_p, C.c_size_t]
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = args
+    return lib
+
+
+LIB = _load()
+
+
+def last_error():
+    buf = C.create_string_buffer(512)
+    LIB.fod_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def call(name, *args):
+    rc = getattr(LIB, name)(*args)
+    if rc != 0:
+        raise FodError(f"{name} failed ({rc}): {last_error()}")

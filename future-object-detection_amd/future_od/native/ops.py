@@ -1,0 +1,416 @@
+"""Tensor-level wrappers over the C ABI: shape/stride checks on the host (a wrong extent would be
+an out-of-bounds access on the GPU), output allocation through torch (which owns all device
+memory), launch on torch's current HIP stream.  No arithmetic happens in this file."""
+import ctypes as C
+import math
+
+import torch
+
+from . import lib as L
+from .lib import F32, BF16, AttnShape, ConvGeom, Epilogue, call
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise L.FodError(f"unsupported activation dtype {t.dtype}") from None
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def _chk(t, name, dtype=None):
+    if not t.is_cuda:
+        raise L.FodError(f"{name}: expected a device tensor (the HIP path has no CPU fallback)")
+    if not t.is_contiguous():
+        raise L.FodError(f"{name}: expected a contiguous tensor, got strides {t.stride()} for {tuple(t.shape)}")
+    if dtype is not None and t.dtype != dtype:
+        raise L.FodError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def _epi(scale=None, shift=None, residual=None, ld_residual=0, residual_row_mod=0, relu_mask=None,
+         ld_mask=0, relu=False, out_f32=False):
+    if scale is None and shift is None and residual is None and relu_mask is None and not relu and not out_f32:
+        return None
+    return C.byref(Epilogue(ptr(scale), ptr(shift), ptr(residual), ld_residual, residual_row_mod,
+                            ptr(relu_mask), ld_mask, int(relu), int(out_f32)))
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm_nt(a, b, *, a_row_mod=0, m_rows=None, scale=None, shift=None, residual=None,
+            residual_row_mod=0, relu=False, relu_mask=None, out_f32=False, out=None):
+    """C[M,N] = epi(A[M,K] . B[N,K]^T).  a: [*, K] (leading dims flattened), b: [N, K]."""
+    _chk(a, "a"); _chk(b, "b", a.dtype)
+    K = a.shape[-1]
+    N = b.shape[0]
+    assert b.shape[1] == K, (a.shape, b.shape)
+    a_rows = a.numel() // K
+    M = m_rows if m_rows is not None else a_rows
+    if a_row_mod:
+        assert a_row_mod <= a_rows
+    else:
+        assert M <= a_rows
+    for v, n in ((scale, "scale"), (shift, "shift")):
+        if v is not None:
+            _chk(v, n, torch.float32); assert v.numel() == N
+    if residual is not None:
+        _chk(residual, "residual", a.dtype)
+        assert residual.shape[-1] == N
+        rr = residual.numel() // N
+        assert (residual_row_mod and residual_row_mod <= rr) or (not residual_row_mod and rr >= M)
+    if relu_mask is not None:
+        _chk(relu_mask, "relu_mask", a.dtype)
+        assert relu_mask.numel() == M * N
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32 if out_f32 else a.dtype, device=a.device)
+    else:
+        _chk(out, "out"); assert out.numel() == M * N
+    call("fod_gemm_nt", dt(a), ptr(a), K, a_row_mod, ptr(b), K, ptr(out), N, M, N, K,
+         _epi(scale, shift, residual, N, residual_row_mod, relu_mask, N, relu, out_f32), stream())
+    return out
+
+
+def gemm_tn_acc(g, x, dw, row_scale=None):
+    """dw[N1,K2] (f32) += g[M,N1]^T . x[M,K2]."""
+    _chk(g, "g"); _chk(x, "x", g.dtype); _chk(dw, "dw", torch.float32)
+    N1, K2 = g.shape[-1], x.shape[-1]
+    M = g.numel() // N1
+    assert x.numel() // K2 == M and dw.numel() == N1 * K2, (g.shape, x.shape, dw.shape)
+    if row_scale is not None:
+        _chk(row_scale, "row_scale", torch.float32); assert row_scale.numel() == N1
+    call("fod_gemm_tn_acc", dt(g), ptr(g), N1, ptr(x), K2, ptr(dw), K2, M, N1, K2, ptr(row_scale), stream())
+    return dw
+
+
+def colsum_acc(g, out, group_rows=0):
+    _chk(g, "g"); _chk(out, "out", torch.float32)
+    N = g.shape[-1]
+    M = g.numel() // N
+    groups = 1 if group_rows <= 0 else (M + group_rows - 1) // group_rows
+    assert out.numel() == groups * N, (g.shape, out.shape, group_rows)
+    call("fod_colsum_acc", dt(g), ptr(g), N, M, N, group_rows, ptr(out), stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ conv
+def conv_geom(x_shape, cout, k, stride, pad):
+    n, h, w, cin = x_shape
+    ho = (h + 2 * pad - k) // stride + 1
+    wo = (w + 2 * pad - k) // stride + 1
+    return ConvGeom(n, h, w, cin, ho, wo, cout, k, k, stride, pad)
+
+
+def conv2d_fwd(x, w, geom, *, scale=None, shift=None, residual=None, relu=False):
+    """x NHWC, w [Cout, kh, kw, Cin] (same dtype) -> y NHWC."""
+    _chk(x, "x"); _chk(w, "w", x.dtype)
+    assert tuple(x.shape) == (geom.Nimg, geom.H, geom.W, geom.Cin), (x.shape, geom.H, geom.W, geom.Cin)
+    assert w.numel() == geom.Cout * geom.kh * geom.kw * geom.Cin
+    y = torch.empty((geom.Nimg, geom.Ho, geom.Wo, geom.Cout), dtype=x.dtype, device=x.device)
+    for v in (scale, shift):
+        if v is not None:
+            _chk(v, "scale/shift", torch.float32); assert v.numel() == geom.Cout
+    if residual is not None:
+        _chk(residual, "residual", x.dtype); assert residual.shape == y.shape
+    call("fod_conv2d_fwd", dt(x), ptr(x), ptr(w), ptr(y), C.byref(geom),
+         _epi(scale, shift, residual, geom.Cout, 0, None, 0, relu), stream())
+    return y
+
+
+def conv2d_dgrad(dy, w_t, geom, *, residual=None, relu_mask=None):
+    """dy NHWC [N,Ho,Wo,Cout], w_t [Cin, kh, kw, Cout] -> dx NHWC [N,H,W,Cin] (+residual, *mask>0)."""
+    _chk(dy, "dy"); _chk(w_t, "w_t", dy.dtype)
+    assert tuple(dy.shape) == (geom.Nimg, geom.Ho, geom.Wo, geom.Cout), (dy.shape,)
+    assert w_t.numel() == geom.Cout * geom.kh * geom.kw * geom.Cin
+    dx = torch.empty((geom.Nimg, geom.H, geom.W, geom.Cin), dtype=dy.dtype, device=dy.device)
+    for v in (residual, relu_mask):
+        if v is not None:
+            _chk(v, "residual/mask", dy.dtype); assert v.shape == dx.shape
+    call("fod_conv2d_dgrad", dt(dy), ptr(dy), ptr(w_t), ptr(dx), C.byref(geom),
+         _epi(None, None, residual, geom.Cin, 0, relu_mask, geom.Cin, False), stream())
+    return dx
+
+
+def conv2d_wgrad_acc(dy, x, dw, geom, row_scale=None):
+    _chk(dy, "dy"); _chk(x, "x", dy.dtype); _chk(dw, "dw", torch.float32)
+    assert tuple(dy.shape) == (geom.Nimg, geom.Ho, geom.Wo, geom.Cout)
+    assert tuple(x.shape) == (geom.Nimg, geom.H, geom.W, geom.Cin)
+    assert dw.numel() == geom.Cout * geom.kh * geom.kw * geom.Cin
+    if row_scale is not None:
+        _chk(row_scale, "row_scale", torch.float32); assert row_scale.numel() == geom.Cout
+    call("fod_conv2d_wgrad_acc", dt(dy), ptr(dy), ptr(x), ptr(dw), C.byref(geom), ptr(row_scale), stream())
+    return dw
+
+
+def maxpool3x3s2(x):
+    _chk(x, "x")
+    n, h, w, c = x.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.empty((n, ho, wo, c), dtype=x.dtype, device=x.device)
+    call("fod_maxpool3x3s2", dt(x), ptr(x), ptr(y), n, h, w, c, ho, wo, stream())
+    return y
+
+
+def nchw_to_nhwc(video, dtype, cpad):
+    """f32 [F,C,H,W] -> dtype [F,H,W,cpad]."""
+    _chk(video, "video", torch.float32)
+    f, c, h, w = video.shape
+    out = torch.empty((f, h, w, cpad), dtype=dtype, device=video.device)
+    call("fod_nchw_to_nhwc", _DT[dtype], ptr(video), ptr(out), f, c, h, w, cpad, stream())
+    return out
+
+
+def permute3_cast(src, dst_dtype, dims, strides, valid2=None, scale=None, scale_axis=-1):
+    """dst[i0,i1,i2] = src.flat[i0*s0+i1*s1+i2*s2] * scale[...]; src f32/bf16 (any strides as given)."""
+    assert src.is_cuda
+    d0, d1, d2 = dims
+    out = torch.empty(dims, dtype=dst_dtype, device=src.device)
+    v2 = d2 if valid2 is None else valid2
+    span = 1 + (d0 - 1) * strides[0] + (d1 - 1) * strides[1] + (v2 - 1) * strides[2]
+    assert span <= src.untyped_storage().nbytes() // src.element_size() - src.storage_offset(), (dims, strides)
+    if scale is not None:
+        _chk(scale, "scale", torch.float32); assert scale.numel() == dims[scale_axis]
+    call("fod_permute3_cast", _DT[src.dtype], _DT[dst_dtype], ptr(src), ptr(out), d0, d1, d2,
+         strides[0], strides[1], strides[2], v2, ptr(scale), scale_axis, stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_shape(q, k, v, scale):
+    B, Tq, E = q.shape
+    S = k.shape[1]
+    assert E % 32 == 0 and k.shape == (B, S, E) and v.shape == (B, S, E), (q.shape, k.shape, v.shape)
+    H = E // 32
+    return AttnShape(B, H, Tq, S, Tq * E, E, S * E, E, S * E, E, Tq * E, E, scale), H
+
+
+def attn_fwd(q1, k1, v, scale, q2=None, k2=None):
+    """[B,T,H*32] tensors; returns (o [B,Tq,H*32], lse2 f32 [B,H,Tq])."""
+    for t, n in ((q1, "q1"), (k1, "k1"), (v, "v")):
+        _chk(t, n, q1.dtype)
+    if q2 is not None:
+        _chk(q2, "q2", q1.dtype); _chk(k2, "k2", q1.dtype)
+        assert q2.shape == q1.shape and k2.shape == k1.shape
+    shp, H = _attn_shape(q1, k1, v, scale)
+    o = torch.empty_like(q1)
+    lse2 = torch.empty((q1.shape[0], H, q1.shape[1]), dtype=torch.float32, device=q1.device)
+    call("fod_attn_fwd", dt(q1), ptr(q1), ptr(k1), ptr(q2), ptr(k2), ptr(v), ptr(o), ptr(lse2),
+         C.byref(shp), stream())
+    return o, lse2
+
+
+def attn_bwd(q1, k1, v, o, dout, lse2, scale, q2=None, k2=None):
+    for t, n in ((q1, "q1"), (k1, "k1"), (v, "v"), (o, "o"), (dout, "dout")):
+        _chk(t, n, q1.dtype)
+    _chk(lse2, "lse2", torch.float32)
+    assert o.shape == q1.shape and dout.shape == q1.shape
+    shp, H = _attn_shape(q1, k1, v, scale)
+    assert lse2.shape == (q1.shape[0], H, q1.shape[1])
+    dq1, dk1, dv = torch.empty_like(q1), torch.empty_like(k1), torch.empty_like(v)
+    dq2 = dk2 = None
+    if q2 is not None:
+        _chk(q2, "q2", q1.dtype); _chk(k2, "k2", q1.dtype)
+        dq2, dk2 = torch.empty_like(q2), torch.empty_like(k2)
+    delta = torch.empty_like(lse2)
+    call("fod_attn_bwd", dt(q1), ptr(q1), ptr(k1), ptr(q2), ptr(k2), ptr(v), ptr(o), ptr(dout), ptr(lse2),
+         ptr(delta), ptr(dq1), ptr(dk1), ptr(dq2), ptr(dk2), ptr(dv), C.byref(shp), stream())
+    return dq1, dk1, dq2, dk2, dv
+
+
+# ------------------------------------------------------------------------------------------------ norm / eltwise
+def layernorm_fwd(x, gamma, beta, residual=None, res_row_div=0, res_row_mod=0, want_sum=None, eps=1e-5):
+    _chk(x, "x"); _chk(gamma, "gamma", torch.float32); _chk(beta, "beta", torch.float32)
+    D = x.shape[-1]
+    rows = x.numel() // D
+    assert gamma.numel() == D and beta.numel() == D
+    if residual is not None:
+        _chk(residual, "residual", x.dtype); assert residual.shape[-1] == D
+        rr = residual.numel() // D
+        need = rows
+        if res_row_div:
+            need = (rows - 1) // res_row_div + 1
+        if res_row_mod:
+            need = min(need, res_row_mod)
+        assert rr >= need, (x.shape, residual.shape, res_row_div, res_row_mod)
+    want_sum = (residual is not None) if want_sum is None else want_sum
+    y = torch.empty_like(x)
+    s = torch.empty_like(x) if want_sum else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    call("fod_layernorm_fwd", dt(x), ptr(x), ptr(residual), res_row_div, res_row_mod, ptr(gamma), ptr(beta),
+         ptr(y), ptr(s), ptr(mean), ptr(rstd), rows, D, eps, stream())
+    return y, (s if want_sum else x), mean, rstd
+
+
+def layernorm_bwd(dy, xsum, mean, rstd, gamma, dgamma, dbeta):
+    _chk(dy, "dy"); _chk(xsum, "xsum", dy.dtype)
+    D = dy.shape[-1]
+    rows = dy.numel() // D
+    assert xsum.numel() == dy.numel() and mean.numel() == rows and rstd.numel() == rows
+    for t in (gamma, dgamma, dbeta):
+        _chk(t, "gamma/dgamma/dbeta", torch.float32); assert t.numel() == D
+    dx = torch.empty_like(dy)
+    call("fod_layernorm_bwd", dt(dy), ptr(dy), ptr(xsum), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx),
+         ptr(dgamma), ptr(dbeta), rows, D, stream())
+    return dx
+
+
+def eltwise(op, a, b=None, c=None, b_row_div=0, b_row_mod=0, alpha=1.0, out=None):
+    _chk(a, "a")
+    cols = a.shape[-1]
+    rows = a.numel() // cols
+    if b is not None:
+        _chk(b, "b", a.dtype); assert b.shape[-1] == cols
+        need = rows
+        if b_row_div:
+            need = (rows - 1) // b_row_div + 1
+        if b_row_mod:
+            need = min(need, b_row_mod)
+        assert b.numel() // cols >= need, (a.shape, b.shape, b_row_div, b_row_mod)
+    if c is not None:
+        _chk(c, "c", a.dtype); assert c.numel() == a.numel()
+    out = torch.empty_like(a) if out is None else out
+    call("fod_eltwise", op, dt(a), ptr(out), ptr(a), ptr(b), ptr(c), rows, cols, b_row_div, b_row_mod,
+         float(alpha), stream())
+    return out
+
+
+def add(a, b, **kw):
+    return eltwise(L.EW_ADD, a, b, **kw)
+
+
+def posenc_table(h, w, c, dtype, device, temperature=10000.0):
+    out = torch.empty((h * w, c), dtype=dtype, device=device)
+    call("fod_posenc_table", _DT[dtype], ptr(out), h, w, c, temperature, stream())
+    return out
+
+
+def posenc_temporal(b, l, c, dtype, device, offsets=None, extra=0.0, temperature=10000.0):
+    out = torch.empty((b, l, c), dtype=dtype, device=device)
+    if offsets is not None:
+        _chk(offsets, "offsets", torch.float32); assert offsets.shape == (b, l)
+    call("fod_posenc_temporal", _DT[dtype], ptr(out), ptr(offsets), b, l, c, extra, temperature, stream())
+    return out
+
+
+def refpoint_sine_fwd(ref_logit, D):
+    _chk(ref_logit, "ref_logit")
+    R = ref_logit.numel() // 2
+    ref = torch.empty((R, 2), dtype=torch.float32, device=ref_logit.device)
+    sine = torch.empty((R, D), dtype=ref_logit.dtype, device=ref_logit.device)
+    call("fod_refpoint_sine_fwd", dt(ref_logit), ptr(ref_logit), ptr(ref), ptr(sine), R, D, stream())
+    return ref, sine
+
+
+def refpoint_sine_bwd(dsine, ref, dref_extra):
+    _chk(dsine, "dsine"); _chk(ref, "ref", torch.float32)
+    R, D = dsine.shape
+    assert ref.shape == (R, 2)
+    if dref_extra is not None:
+        _chk(dref_extra, "dref_extra", torch.float32); assert dref_extra.shape == (R, 2)
+    out = torch.empty((R, 2), dtype=dsine.dtype, device=dsine.device)
+    call("fod_refpoint_sine_bwd", dt(dsine), ptr(dsine), ptr(ref), ptr(dref_extra), ptr(out), R, D, stream())
+    return out
+
+
+def box_finish_fwd(t, ref, levels):
+    _chk(t, "t"); _chk(ref, "ref", torch.float32)
+    R = ref.shape[0]
+    assert t.numel() == levels * R * 4
+    boxes = torch.empty((levels, R, 4), dtype=torch.float32, device=t.device)
+    call("fod_box_finish_fwd", dt(t), ptr(t), ptr(ref), ptr(boxes), levels, R, stream())
+    return boxes
+
+
+def box_finish_bwd(dboxes, boxes, ref, act_dtype):
+    _chk(dboxes, "dboxes", torch.float32); _chk(boxes, "boxes", torch.float32)
+    levels, R, _ = boxes.shape
+    assert dboxes.shape == boxes.shape and ref.shape == (R, 2)
+    dt_ = torch.empty((levels, R, 4), dtype=act_dtype, device=boxes.device)
+    dref = torch.zeros((R, 2), dtype=torch.float32, device=boxes.device)
+    call("fod_box_finish_bwd", _DT[act_dtype], ptr(dboxes), ptr(boxes), ptr(ref), ptr(dt_), ptr(dref),
+         levels, R, stream())
+    return dt_, dref
+
+
+# ------------------------------------------------------------------------------------------------ criterion
+def match_cost(logits, boxes, tgt_labels, tgt_boxes, tgt_offset, ld_n, w_class, w_bbox, w_giou,
+               alpha=0.25, gamma=2.0):
+    _chk(logits, "logits", torch.float32); _chk(boxes, "boxes", torch.float32)
+    Lv, B, M, Cc = logits.shape
+    assert boxes.shape == (Lv, B, M, 4) and tgt_offset.dtype == torch.int32 and tgt_offset.numel() == B + 1
+    cost = torch.zeros((Lv, B, M, ld_n), dtype=torch.float32, device=logits.device)
+    call("fod_match_cost", ptr(logits), ptr(boxes), ptr(tgt_labels), ptr(tgt_boxes), ptr(tgt_offset),
+         ptr(cost), Lv, B, M, Cc, ld_n, w_class, w_bbox, w_giou, alpha, gamma, stream())
+    return cost
+
+
+def lap_solve_batch_host(cost_cpu, n_cols, threads=8):
+    """cost_cpu f32 [P, M, ld] on the HOST, n_cols list[int] -> int32 [P, M] (matched column or -1)."""
+    assert cost_cpu.device.type == "cpu" and cost_cpu.dtype == torch.float32 and cost_cpu.is_contiguous()
+    P, M, ld = cost_cpu.shape
+    nc = torch.tensor(n_cols, dtype=torch.int32)
+    assert nc.numel() == P
+    out = torch.empty((P, M), dtype=torch.int32)
+    call("fod_lap_solve_batch_host", C.c_void_p(cost_cpu.data_ptr()), P, M, ld, C.c_void_p(nc.data_ptr()),
+         C.c_void_p(out.data_ptr()), threads)
+    return out
+
+
+def set_loss_fwd(logits, boxes, match, tgt_labels, tgt_boxes, tgt_offset, num_boxes, alpha):
+    Lv, B, M, Cc = logits.shape
+    _chk(match, "match", torch.int32); assert match.shape == (Lv, B, M)
+    out = torch.empty((Lv, 5), dtype=torch.float32, device=logits.device)
+    call("fod_set_loss_fwd", ptr(logits), ptr(boxes), ptr(match), ptr(tgt_labels), ptr(tgt_boxes),
+         ptr(tgt_offset), ptr(out), Lv, B, M, Cc, float(num_boxes), alpha, stream())
+    return out
+
+
+def set_loss_bwd(logits, boxes, match, tgt_labels, tgt_boxes, g, num_boxes, alpha):
+    Lv, B, M, Cc = logits.shape
+    _chk(g, "g", torch.float32); assert g.shape == (Lv, 3)
+    dlogits, dboxes = torch.empty_like(logits), torch.empty_like(boxes)
+    call("fod_set_loss_bwd", ptr(logits), ptr(boxes), ptr(match), ptr(tgt_labels), ptr(tgt_boxes), ptr(g),
+         ptr(dlogits), ptr(dboxes), Lv, B, M, Cc, float(num_boxes), alpha, stream())
+    return dlogits, dboxes
+
+
+def post_proc(logits, boxes, img_h, img_w):
+    _chk(logits, "logits", torch.float32); _chk(boxes, "boxes", torch.float32)
+    Cc = logits.shape[-1]
+    R = logits.numel() // Cc
+    assert boxes.numel() == R * 4
+    scores = torch.empty(logits.shape[:-1] + (Cc + 1,), dtype=torch.float32, device=logits.device)
+    boxes_px = torch.empty_like(boxes)
+    call("fod_post_proc", ptr(logits), ptr(boxes), ptr(scores), ptr(boxes_px), R, Cc, float(img_h),
+         float(img_w), stream())
+    return scores, boxes_px
+
+
+def od_map(scores, boxes_px, anno_boxes, anno_classes, anno_active, imsize, T=10):
+    _chk(scores, "scores", torch.float32); _chk(boxes_px, "boxes", torch.float32)
+    _chk(anno_boxes, "anno_boxes", torch.float32)
+    _chk(anno_classes, "anno_classes", torch.int64); _chk(anno_active, "anno_active", torch.int64)
+    B, M, C1 = scores.shape
+    N = anno_classes.shape[1]
+    assert boxes_px.shape == (B, M, 4) and anno_boxes.shape == (B, N, 4) and anno_active.shape == (B, N)
+    K = min(50, M)
+    dev = scores.device
+    confs = torch.empty((T, C1, B * K), dtype=torch.float32, device=dev)
+    is_pos = torch.empty((T, C1, B * K), dtype=torch.bool, device=dev)
+    sizes = torch.empty((C1, 4, B * K), dtype=torch.bool, device=dev)
+    num_annos = torch.empty((C1, 4), dtype=torch.int64, device=dev)
+    call("fod_od_map", ptr(scores), ptr(boxes_px), ptr(anno_boxes), ptr(anno_classes), ptr(anno_active),
+         ptr(confs), ptr(is_pos), ptr(sizes), ptr(num_annos), B, M, C1, N, T, float(imsize[0]),
+         float(imsize[1]), stream())
+    return confs, is_pos, sizes, num_annos

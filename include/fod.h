@@ -1,0 +1,229 @@
+/* fod.h -- C ABI of libfod_hip.so: the MI355X (gfx950) kernels behind the spatiotemporal-DETR
+ * forward/backward hot path.
+ *
+ * The reference (atonderski/future-object-detection) has no native layer and no FFI: its hot path
+ * is PyTorch ops called from future_od/models/*.py.  This library sits below that Python surface;
+ * every entry point names the reference computation it replaces (paths relative to the reference
+ * root).  The host-side binding is ctypes (future-object-detection_amd/future_od/native/lib.py);
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers + extents; all pointers are DEVICE pointers unless the name says `host`;
+ *   - dtype: FOD_F32 (exact-f32 MFMA, the parity mode) or FOD_BF16 (bf16 MFMA, f32 accumulate);
+ *     activations / activation gradients are `dtype`, parameter gradients and statistics are f32;
+ *   - images are NHWC, token tensors are [batch, tokens, channels]; leading dimensions in ELEMENTS;
+ *   - every call is asynchronous on `stream`, allocates nothing, keeps no state (re-entrant: autograd
+ *     calls backward kernels from its own thread);
+ *   - return 0 on success; on failure a code below, text via fod_last_error().
+ *   - `_acc` entry points ADD into their f32 output (global atomics): zero it first or pass a
+ *     gradient buffer to accumulate into.
+ */
+#ifndef FOD_H_
+#define FOD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* fod_stream_t; /* == hipStream_t */
+
+enum { FOD_F32 = 0, FOD_BF16 = 1 };
+enum { FOD_OK = 0, FOD_ERR_ARG = 1, FOD_ERR_LAUNCH = 2, FOD_ERR_RUNTIME = 3 };
+
+/* Copies the calling thread's last error text (NUL-terminated) into buf; returns its length. */
+size_t fod_last_error(char* buf, size_t cap);
+/* ABI version of this header; the loader refuses a library that disagrees. */
+int fod_abi_version(void);
+#define FOD_ABI_VERSION 1
+
+/* Fused epilogue of the NT contraction family.  In order:
+ *   v = acc * scale[n] + shift[n];  v += residual[row(m), n];  v = relu ? max(v,0) : v;
+ *   v = relu_mask ? (relu_mask[m,n] > 0 ? v : 0) : v;  store as dtype (or f32 if out_f32).
+ * row(m) = residual_row_mod > 0 ? m % residual_row_mod : m.   NULL pointers skip their step. */
+typedef struct fod_epilogue {
+  const float* scale;       /* [N] : frozen-BN scale (FrozenBatchNorm2d, reference paper.py:28,97) */
+  const float* shift;       /* [N] : frozen-BN shift or Linear/conv bias */
+  const void* residual;     /* dtype [*, N] */
+  long ld_residual;
+  int residual_row_mod;
+  const void* relu_mask;    /* dtype [M, N]: forward output whose sign gates a gradient */
+  long ld_mask;
+  int relu;
+  int out_f32;
+} fod_epilogue;
+
+/* C[m,n] = epi( sum_k A[(m % a_row_mod) , k] * B[n, k] )      A:[*,K] lda, B:[N,K] ldb, C:[M,N] ldc
+ * Replaces nn.Linear forward (B = weight) and input-gradient (B = weight^T) on the path:
+ * future_od/models/transformer.py:54-58,76-78,88-91,110-112,145-163,228-233,407-411 and
+ * paper.py:302-303,409,415.  K, lda, ldb multiples of 16 bytes. */
+int fod_gemm_nt(int dtype, const void* A, long lda, int a_row_mod, const void* B, long ldb, void* C,
+                long ldc, int M, int N, int K, const fod_epilogue* epi, fod_stream_t stream);
+
+/* dW[i,j] += row_scale[i] * sum_m G[m,i] * X[m,j]     G:[M,N1] ldg, X:[M,K2] ldx, dW f32 [N1,K2] ldw
+ * Replaces autograd's Linear weight-gradient (loss.backward(), future_od/trainer.py:180). */
+int fod_gemm_tn_acc(int dtype, const void* G, long ldg, const void* X, long ldx, float* dW, long ldw,
+                    int M, int N1, int K2, const float* row_scale, fod_stream_t stream);
+
+/* out[g, n] += sum over rows m of group g of G[m, n];  group g = m / group_rows (group_rows <= 0:
+ * one group).  Bias gradients and sums over a broadcast dimension. */
+int fod_colsum_acc(int dtype, const void* G, long ldg, int M, int N, int group_rows, float* out,
+                   fod_stream_t stream);
+
+typedef struct fod_conv_geom {
+  int Nimg, H, W, Cin;   /* input  NHWC */
+  int Ho, Wo, Cout;      /* output NHWC */
+  int kh, kw, stride, pad;
+} fod_conv_geom;
+
+/* y = epi(conv2d(x, w)) as implicit GEMM.  x NHWC, w [Cout][kh][kw][Cin] (= OIHW in channels_last
+ * memory), y NHWC.  Replaces the torchvision ResNet conv + FrozenBatchNorm2d + ReLU (+ residual)
+ * chain and the 1x1 input_proj: future_od/models/paper.py:94-98,112-116. */
+int fod_conv2d_fwd(int dtype, const void* x, const void* w, void* y, const fod_conv_geom* g,
+                   const fod_epilogue* epi, fod_stream_t stream);
+/* dx = epi(conv2d_input_grad(dy, w)).  w_t is the weight re-laid as [Cin][kh][kw][Cout]. */
+int fod_conv2d_dgrad(int dtype, const void* dy, const void* w_t, void* dx, const fod_conv_geom* g,
+                     const fod_epilogue* epi, fod_stream_t stream);
+/* dw[co][r][s][ci] += row_scale[co] * sum_pixels dy * x   (f32, channels_last OIHW) */
+int fod_conv2d_wgrad_acc(int dtype, const void* dy, const void* x, float* dw, const fod_conv_geom* g,
+                         const float* row_scale, fod_stream_t stream);
+
+/* 3x3 stride-2 pad-1 max pooling, NHWC (torchvision ResNet stem; forward only: stem is frozen). */
+int fod_maxpool3x3s2(int dtype, const void* x, void* y, int Nimg, int H, int W, int C, int Ho, int Wo,
+                     fod_stream_t stream);
+
+/* video f32 NCHW [F,C,H,W] -> dtype NHWC [F,H,W,Cp], channels C..Cp-1 zero.  The one read of the
+ * [B,T,3,H,W] frame tensor (future_od/models/paper.py:146). */
+int fod_nchw_to_nhwc(int dtype, const float* src, void* dst, int F, int C, int H, int W, int Cp,
+                     fod_stream_t stream);
+
+/* dst[i0][i1][i2] = src[i0*s0 + i1*s1 + i2*s2] * scale[index on scale_axis]   (i2 >= valid2 -> 0)
+ * src_dtype/dst_dtype independent.  Weight preparation (cast, transpose, BN-scale fold, channel pad)
+ * and activation casts. */
+int fod_permute3_cast(int src_dtype, int dst_dtype, const void* src, void* dst, int d0, int d1, int d2,
+                      long s0, long s1, long s2, int valid2, const float* scale, int scale_axis,
+                      fod_stream_t stream);
+
+typedef struct fod_attn_shape {
+  int B, H, Tq, S;
+  long q_batch_stride, q_token_stride;   /* q1, q2, dq1, dq2 */
+  long k_batch_stride, k_token_stride;   /* k1, k2, dk1, dk2 */
+  long v_batch_stride, v_token_stride;   /* v, dv */
+  long o_batch_stride, o_token_stride;   /* o, dout */
+  float scale;                           /* applied to the raw score */
+} fod_attn_shape;
+
+/* o = softmax((q1.k1 + q2.k2) * scale) v per head; head h = channels [32h, 32h+32) of every tensor.
+ * q2/k2 NULL -> one part.  lse2 f32 [B,H,Tq] (log2 units) is saved for the backward.
+ * Replaces the core of nn.MultiheadAttention (future_od/models/transformer.py:404,417) and of
+ * ConditionalDETR's MultiheadAttention (transformer.py:64,126,172-178). */
+int fod_attn_fwd(int dtype, const void* q1, const void* k1, const void* q2, const void* k2, const void* v,
+                 void* o, float* lse2, const fod_attn_shape* shape, fod_stream_t stream);
+int fod_attn_bwd(int dtype, const void* q1, const void* k1, const void* q2, const void* k2, const void* v,
+                 const void* o, const void* dout, const float* lse2, float* delta /* scratch [B,H,Tq] */,
+                 void* dq1, void* dk1, void* dq2, void* dk2, void* dv, const fod_attn_shape* shape,
+                 fod_stream_t stream);
+
+/* y = LayerNorm(x + residual[row(m)]) * gamma + beta over the last dim D (D % 64 == 0, D <= 1024).
+ * row(m) = (res_row_div > 0 ? m / res_row_div : m), then % res_row_mod if > 0.
+ * sum_out (optional) receives x + residual; mean/rstd f32 [rows] are saved for the backward.
+ * Replaces the `x = norm(x + dropout(new))` pattern, transformer.py:117-118,271-272,285-286,
+ * 310-311,417-418,485-486 (dropout = identity in eval). */
+int fod_layernorm_fwd(int dtype, const void* x, const void* residual, int res_row_div, int res_row_mod,
+                      const float* gamma, const float* beta, void* y, void* sum_out, float* mean,
+                      float* rstd, int rows, int D, float eps, fod_stream_t stream);
+/* dx from dy; dgamma/dbeta += (f32 [D]).  xsum is the tensor that was normalised (x + residual). */
+int fod_layernorm_bwd(int dtype, const void* dy, const void* xsum, const float* mean, const float* rstd,
+                      const float* gamma, void* dx, float* dgamma, float* dbeta, int rows, int D,
+                      fod_stream_t stream);
+
+enum {
+  FOD_EW_ADD = 0,       /* out = a + b[row(m)]            */
+  FOD_EW_MUL = 1,       /* out = a * b[row(m)]            */
+  FOD_EW_RELU_MASK = 2, /* out = b[m] > 0 ? a : 0         */
+  FOD_EW_SCALE = 3,     /* out = alpha * a                */
+  FOD_EW_ADD3 = 4,      /* out = a + b[row(m)] + c        */
+  FOD_EW_RELU = 5       /* out = max(a, 0)                */
+};
+/* [rows, cols] contiguous element-wise helpers; row(m) as in fod_layernorm_fwd. */
+int fod_eltwise(int op, int dtype, void* out, const void* a, const void* b, const void* c, long rows,
+                int cols, int b_row_div, int b_row_mod, float alpha, fod_stream_t stream);
+
+/* DETR sine table for an h x w map as a token-major [h*w, C] tensor: first C/2 channels encode y,
+ * last C/2 encode x (future_od/models/paper.py:57-64,75-80). */
+int fod_posenc_table(int dtype, void* out, int h, int w, int C, float temperature, fod_stream_t stream);
+/* Temporal table [B, L, C] added per frame (paper.py:66-73); offsets f32 [B,L] or NULL (frame index). */
+int fod_posenc_temporal(int dtype, void* out, const float* offsets, int B, int L, int C, float extra_offset,
+                        float temperature, fod_stream_t stream);
+
+/* ref = sigmoid(ref_logit) (f32 [R,2], x then y) and its D-channel sine embedding ordered (y | x):
+ * future_od/models/transformer.py:35-48,355-360. */
+int fod_refpoint_sine_fwd(int dtype, const void* ref_logit, float* ref, void* sine, int R, int D,
+                          fod_stream_t stream);
+/* dref_logit = (d sine/d ref . dsine + dref_extra) * ref (1 - ref)    (dref_extra f32 [R,2] or NULL) */
+int fod_refpoint_sine_bwd(int dtype, const void* dsine, const float* ref, const float* dref_extra,
+                          void* dref_logit, int R, int D, fod_stream_t stream);
+
+/* boxes[l, r, :] = sigmoid(t[l, r, :] + [inverse_sigmoid(ref[r]), 0, 0])  f32 out  (paper.py:406-413) */
+int fod_box_finish_fwd(int dtype, const void* t, const float* ref, float* boxes, int levels, int R,
+                       fod_stream_t stream);
+/* dt (dtype) from dboxes (f32); dref f32 [R,2] += sum over levels */
+int fod_box_finish_bwd(int dtype, const float* dboxes, const float* boxes, const float* ref, void* dt,
+                       float* dref, int levels, int R, fod_stream_t stream);
+
+/* Matching cost (ConditionalDETR HungarianMatcher, called at set_criterion.py:182,204):
+ *   cost[l, b, m, j] = w_bbox*L1 + w_class*focal_cost + w_giou*(-GIoU), target j of sample b.
+ * logits f32 [L,B,M,C], boxes f32 [L,B,M,4] cxcywh, tgt_labels i64 [sum Nb], tgt_boxes f32 [sum Nb,4],
+ * tgt_offset i32 [B+1]; cost f32 [L,B,M,ld_n] (columns >= Nb_b untouched). */
+int fod_match_cost(const float* logits, const float* boxes, const int64_t* tgt_labels,
+                   const float* tgt_boxes, const int32_t* tgt_offset, float* cost, int L, int B, int M,
+                   int C, int ld_n, float w_class, float w_bbox, float w_giou, float alpha, float gamma,
+                   fod_stream_t stream);
+
+/* HOST.  Rectangular linear sum assignment (shortest augmenting path; same algorithm family as
+ * scipy.optimize.linear_sum_assignment, which the reference's matcher calls).  For each of nprob
+ * problems p: cost_host + p*M*ld_n is an [M, ld_n] f32 matrix whose first n_cols[p] columns are
+ * valid.  match_out[p*M + m] = assigned column or -1.  Problems are solved on `threads` host threads. */
+int fod_lap_solve_batch_host(const float* cost_host, int nprob, int M, int ld_n, const int32_t* n_cols,
+                             int32_t* match_out, int threads);
+
+/* Set losses (future_od/models/set_criterion.py:36-115) for all L levels at once.
+ * match i32 [L,B,M]: matched GLOBAL target index or -1.  out f32 [L,5]:
+ *   loss_ce, loss_bbox, loss_giou, cardinality_error, class_error.   (overwritten, not accumulated) */
+int fod_set_loss_fwd(const float* logits, const float* boxes, const int32_t* match,
+                     const int64_t* tgt_labels, const float* tgt_boxes, const int32_t* tgt_offset,
+                     float* out, int L, int B, int M, int C, float num_boxes, float alpha,
+                     fod_stream_t stream);
+/* dlogits/dboxes (f32, same shapes) = sum_k g[l][k] * d loss_k ;  g f32 [L,3] = upstream weights of
+ * (loss_ce, loss_bbox, loss_giou) per level. */
+int fod_set_loss_bwd(const float* logits, const float* boxes, const int32_t* match,
+                     const int64_t* tgt_labels, const float* tgt_boxes, const float* g, float* dlogits,
+                     float* dboxes, int L, int B, int M, int C, float num_boxes, float alpha,
+                     fod_stream_t stream);
+
+/* Detection post-processing + AP bookkeeping (st_detr.py:190-234, utils/od_map.py:214-287):
+ * scores f32 [B,M,C1] (sigmoid, last class = max), boxes f32 [B,M,4] xyxy pixels, annotations dense
+ * [B,N,*].  K = min(50, M).  Outputs: confs f32 [T,C1,B*K], is_positive u8 [T,C1,B*K],
+ * size_categories u8 [C1,4,B*K], num_annos i64 [C1,4] (zeroed by the call). */
+int fod_od_map(const float* scores, const float* boxes, const float* anno_boxes, const int64_t* anno_classes,
+               const int64_t* anno_active, float* confs, uint8_t* is_positive, uint8_t* size_categories,
+               int64_t* num_annos, int B, int M, int C1, int N, int T, float img_h, float img_w,
+               fod_stream_t stream);
+/* class_scores = sigmoid(logits) with appended max; boxes cxcywh(0..1) -> xyxy pixels (st_detr.py:198-210) */
+int fod_post_proc(const float* logits, const float* boxes, float* class_scores, float* boxes_px, int R,
+                  int C, float img_h, float img_w, fod_stream_t stream);
+
+/* Fused AdamW step over one flat f32 parameter span (torch.optim.AdamW semantics, runs/_helper.py:105)
+ * with the gradient pre-scaled by *clip_coef (device scalar from fod_grad_sqnorm_acc / clip). */
+int fod_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, float bias_c1, float bias_c2,
+                   const float* clip_coef, fod_stream_t stream);
+/* out[0] += sum(g^2) */
+int fod_grad_sqnorm_acc(const float* grad, long n, float* out, fod_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOD_H_ */

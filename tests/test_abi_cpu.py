@@ -1,0 +1,68 @@
+"""CPU-side checks of the native boundary: the library loads, exports exactly what include/fod.h
+declares, the ctypes table covers it, and the host LAP solver agrees with scipy bit-for-bit."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+from scipy.optimize import linear_sum_assignment
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build_if_needed():
+    so = os.path.join(ROOT, "future-object-detection_amd", "lib", "libfod_hip.so")
+    if not os.path.isfile(so):
+        import subprocess
+        subprocess.check_call([os.path.join(ROOT, "future-object-detection_amd", "build.sh")])
+    return so
+
+
+def test_library_exports_match_header():
+    so = _build_if_needed()
+    hdr = open(os.path.join(ROOT, "include", "fod.h")).read()
+    declared = set(re.findall(r"^(?:int|size_t)\s+(fod_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 30
+    lib = ctypes.CDLL(so)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in fod.h but not exported"
+    from future_od.native import lib as L
+    assert set(L.EXPORTS) == declared, sorted(set(L.EXPORTS) ^ declared)
+    assert L.LIB.fod_abi_version() == L.ABI_VERSION
+
+
+def test_error_path_is_loud():
+    from future_od.native import lib as L
+    from future_od.native import ops
+    with pytest.raises(L.FodError):
+        ops.gemm_nt(torch.zeros(4, 8), torch.zeros(4, 8))          # CPU tensors: no fallback
+    rc = L.LIB.fod_gemm_nt(0, None, 8, 0, None, 8, None, 8, 4, 4, 8, None, None)
+    assert rc != 0 and "null" in L.last_error()
+
+
+@pytest.mark.parametrize("shape", [(128, 23), (16, 40), (8, 8), (1, 5), (37, 1), (128, 128), (5, 0)])
+def test_lap_matches_scipy(shape):
+    from future_od.native import ops
+    M, n = shape
+    rng = np.random.default_rng(M * 1000 + n)
+    P, ld = 6, max(n, 1) + 3
+    cost = torch.from_numpy(rng.standard_normal((P, M, ld)).astype(np.float32) * 3)
+    # add a few exact ties
+    if n > 2:
+        cost[0, :, 1] = cost[0, :, 0]
+        cost[1] = torch.round(cost[1])
+    out = ops.lap_solve_batch_host(cost, [n] * P, threads=3)
+    for p in range(P):
+        if n == 0:
+            assert (out[p] == -1).all()
+            continue
+        i, j = linear_sum_assignment(cost[p, :, :n].numpy())
+        mine_i = torch.nonzero(out[p] >= 0).flatten().numpy()
+        mine_j = out[p][out[p] >= 0].numpy()
+        assert len(mine_i) == min(M, n)
+        c = cost[p, :, :n].double().numpy()
+        assert abs(c[mine_i, mine_j].sum() - c[i, j].sum()) < 1e-9          # same optimum always
+        if p >= 2:                                                          # untied problems: same assignment
+            assert np.array_equal(mine_i, i) and np.array_equal(mine_j, j)

@@ -1,0 +1,143 @@
+"""Positional tables, reference-point / box-head kernels, matcher cost, LAP, set losses and the AP
+bookkeeping kernel against the CPU oracle (oracle/) and the committed golden fixtures."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import criterion as ocrit
+from oracle import stdetr as O
+from oracle import thirdparty as tp
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from future_od.native import ops
+
+DEV = "cuda:0"
+
+
+def close(a, b, atol=1e-5, rtol=1e-5):
+    a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().float().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a, b, atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("hw", [(7, 7), (25, 42), (29, 50)])
+def test_posenc_table(golden, hw):
+    h, w = hw
+    t = ops.posenc_table(h, w, 256, torch.float32, DEV)            # [h*w, C]
+    ref = O.spatial_pos_table(h, w, 256).flatten(1).t()
+    close(t, ref, atol=2e-6, rtol=0)
+    g = golden("g1_posenc")
+    flat = t.t().reshape(256, h, w).reshape(-1).cpu()               # golden is (C,h,w) order
+    close(flat[torch.from_numpy(g[f"idx_{h}x{w}"])], g[f"val_{h}x{w}"], atol=2e-6, rtol=0)
+
+
+def test_posenc_temporal(golden):
+    g = golden("g1_posenc")
+    offs = torch.from_numpy(g["st_offsets"])
+    sp = O.spatial_pos_table(5, 6, 64)[None, None]
+    t = ops.posenc_temporal(2, 3, 64, torch.float32, DEV, offsets=offs.to(DEV))
+    close(sp + t.cpu()[:, :, :, None, None], g["st_full"], atol=2e-6, rtol=0)
+    t = ops.posenc_temporal(2, 3, 64, torch.float32, DEV)
+    close(sp + t.cpu()[:, :, :, None, None], g["st_noffs"], atol=2e-6, rtol=0)
+
+
+def test_refpoint_sine_and_box_finish():
+    g = torch.Generator().manual_seed(3)
+    R, D, Lv = 40, 256, 3
+    logit = torch.randn(R, 2, generator=g).requires_grad_(True)
+    t = (torch.randn(Lv, R, 4, generator=g)).requires_grad_(True)
+    ref = logit.sigmoid()
+    sine = O.query_sine_embed(ref[:, None, :], D)[:, 0]
+    rl = tp.inverse_sigmoid(ref)
+    boxes = torch.cat([t[..., :2] + rl, t[..., 2:]], -1).sigmoid()
+    dsine, dboxes = torch.randn(R, D, generator=g), torch.randn(Lv, R, 4, generator=g)
+    ((sine * dsine).sum() + (boxes * dboxes).sum()).backward()
+    ref_d, sine_d = ops.refpoint_sine_fwd(logit.detach().to(DEV), D)
+    close(ref_d, ref); close(sine_d, sine, atol=2e-5)
+    boxes_d = ops.box_finish_fwd(t.detach().to(DEV), ref_d, Lv)
+    close(boxes_d, boxes, atol=1e-6)
+    dt_d, dref_d = ops.box_finish_bwd(dboxes.to(DEV), boxes_d, ref_d, torch.float32)
+    close(dt_d, t.grad, atol=1e-6, rtol=1e-4)
+    dlogit = ops.refpoint_sine_bwd(dsine.to(DEV), ref_d, dref_d)
+    close(dlogit, logit.grad, atol=2e-4, rtol=1e-4)
+
+
+def _targets(nbs, seed):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for nb in nbs:
+        cxcy = torch.rand(nb, 2, generator=g) * 0.6 + 0.2
+        wh = torch.rand(nb, 2, generator=g) * 0.3 + 0.02
+        out.append({"labels": torch.randint(0, 8, (nb,), generator=g), "boxes": torch.cat([cxcy, wh], 1)})
+    return out
+
+
+@pytest.mark.parametrize("case", [(2, 128, [7, 23]), (3, 16, [0, 1, 40]), (1, 8, [0]), (2, 32, [32, 5])])
+def test_matcher_and_losses(case):
+    B, M, nbs = case
+    cfg = O.Config(dec_layers=3)
+    Lv = 3
+    g = torch.Generator().manual_seed(5)
+    logits = (torch.randn(Lv, B, M, 8, generator=g) * 2 - 2).requires_grad_(True)
+    boxes = (torch.rand(Lv, B, M, 4, generator=g) * 0.5 + 0.1).requires_grad_(True)
+    targets = _targets(nbs, 6)
+    tl = torch.cat([t["labels"] for t in targets])
+    tb = torch.cat([t["boxes"] for t in targets])
+    toff = torch.tensor([0] + list(np.cumsum(nbs)), dtype=torch.int32)
+    ld = max(max(nbs), 1)
+    cost = ops.match_cost(logits.detach().to(DEV), boxes.detach().to(DEV), tl.to(DEV), tb.to(DEV), toff.to(DEV),
+                          ld, 2.0, 5.0, 2.0).cpu()
+    matches = ops.lap_solve_batch_host(cost.view(Lv * B, M, ld), [nbs[b] for _ in range(Lv) for b in range(B)])
+    matches = matches.view(Lv, B, M)
+    gmatch = torch.full((Lv, B, M), -1, dtype=torch.int32)
+    for lv in range(Lv):
+        idx, Cref = ocrit.hungarian_match(cfg, logits[lv].detach(), boxes[lv].detach(), targets, return_cost=True)
+        for b, (i, j) in enumerate(idx):
+            if nbs[b]:
+                close(cost[lv, b, :, :nbs[b]], Cref.split(nbs, -1)[b][b], atol=2e-5, rtol=1e-5)
+            mine = matches[lv, b]
+            qi = torch.nonzero(mine >= 0).flatten()
+            assert torch.equal(qi, i), (lv, b)                          # bit-exact assignment, rows ascending
+            assert torch.equal(mine[qi].long(), j), (lv, b)
+            gmatch[lv, b, i] = (j + int(toff[b])).int()
+    nb_total = max(float(sum(nbs)), 1.0)
+    out = ops.set_loss_fwd(logits.detach().to(DEV), boxes.detach().to(DEV), gmatch.to(DEV), tl.to(DEV), tb.to(DEV),
+                           toff.to(DEV), nb_total, 0.25).cpu()
+    total = 0
+    w = torch.rand(Lv, 3, generator=g) + 0.5
+    for lv in range(Lv):
+        outputs = {"pred_logits": logits[lv], "pred_boxes": boxes[lv]}
+        ld_ = ocrit.set_criterion(cfg, outputs, targets)
+        close(out[lv, 0], ld_["loss_ce"], atol=1e-5, rtol=2e-5)
+        close(out[lv, 1], ld_["loss_bbox"], atol=1e-5, rtol=2e-5)
+        close(out[lv, 2], ld_["loss_giou"], atol=1e-5, rtol=2e-5)
+        close(out[lv, 3], ld_["cardinality_error"])
+        close(out[lv, 4], ld_["class_error"], atol=1e-4)
+        total = total + w[lv, 0] * ld_["loss_ce"] + w[lv, 1] * ld_["loss_bbox"] + w[lv, 2] * ld_["loss_giou"]
+    total.backward()
+    dl, db = ops.set_loss_bwd(logits.detach().to(DEV), boxes.detach().to(DEV), gmatch.to(DEV), tl.to(DEV),
+                              tb.to(DEV), w.to(DEV), nb_total, 0.25)
+    close(dl, logits.grad, atol=1e-6, rtol=1e-4)
+    close(db, boxes.grad, atol=1e-5, rtol=1e-4)
+
+
+def test_post_proc_and_od_map(golden):
+    g = golden("g9_odmap")
+    for ci in range(3):
+        scores = torch.from_numpy(g[f"c{ci}_scores"]).to(DEV)
+        out = ops.od_map(scores, torch.from_numpy(g[f"c{ci}_pboxes"]).to(DEV),
+                         torch.from_numpy(g[f"c{ci}_aboxes"]).to(DEV), torch.from_numpy(g[f"c{ci}_aclasses"]).to(DEV),
+                         torch.from_numpy(g[f"c{ci}_active"]).to(DEV), (448, 800))
+        np.testing.assert_array_equal(out[0].cpu().numpy(), g[f"c{ci}_confs"])
+        np.testing.assert_array_equal(out[1].cpu().numpy(), g[f"c{ci}_is_positive"])
+        np.testing.assert_array_equal(out[2].cpu().numpy(), g[f"c{ci}_size_categories"])
+        np.testing.assert_array_equal(out[3].cpu().numpy(), g[f"c{ci}_num_annos"])
+    gg = torch.Generator().manual_seed(9)
+    logits, boxes = torch.randn(2, 1, 16, 8, generator=gg), torch.rand(2, 1, 16, 4, generator=gg)
+    s, bp = ops.post_proc(logits.to(DEV), boxes.to(DEV), 448, 800)
+    sr = logits.sigmoid()
+    close(s, torch.cat([sr, sr.max(3, keepdim=True)[0]], 3), atol=1e-6)
+    bb = boxes * torch.tensor([800.0, 448.0, 800.0, 448.0])
+    close(bp, torch.cat([bb[..., :2] - 0.5 * bb[..., 2:], bb[..., :2] + 0.5 * bb[..., 2:]], -1), atol=1e-4)

@@ -1,0 +1,238 @@
+"""Kernel-level parity: every C-ABI entry point against a plain PyTorch fp32 computation of the
+same op on the same seeded inputs (the reference's path is made of exactly these torch ops).
+
+Tolerances (stated per dtype, checked as max|a-b| <= atol + rtol*|b| ):
+  f32  mode: exact-f32 MFMA, differs from torch only by summation order  -> rtol 2e-5 / atol scaled
+  bf16 mode: inputs rounded to bf16 (the reference is computed from the SAME rounded inputs in
+             fp32), output rounded to bf16                               -> rtol 1.6e-2 (2 bf16 ulp)
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from future_od.native import lib as L
+    from future_od.native import ops
+
+DEV = "cuda:0"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype, scale=1.0):
+    if dtype == torch.float32:
+        return dict(rtol=2e-5, atol=2e-5 * scale)
+    return dict(rtol=1.6e-2, atol=1.6e-2 * scale)
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    t = (torch.randn(shape, generator=g) * scale).to(dtype)
+    return t
+
+
+def check(got, want, dtype, scale=1.0, what=""):
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    t = tol(dtype, scale)
+    err = (got - want).abs()
+    bound = t["atol"] + t["rtol"] * want.abs()
+    bad = err > bound
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.3e} "
+                           f"at {np.unravel_index(int(err.argmax()), err.shape)}, ref scale {float(want.abs().max()):.3e}")
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mnk", [(128, 128, 64), (200, 72, 256), (1, 8, 16), (300, 256, 32), (257, 2, 256),
+                                 (64, 2048, 256), (513, 64, 96)])
+def test_gemm_nt(dtype, mnk):
+    M, N, K = mnk
+    a, b = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2)
+    ref = a.float() @ b.float().t()
+    out = ops.gemm_nt(a.to(DEV), b.to(DEV))
+    check(out, ref, dtype, math.sqrt(K), f"gemm_nt {mnk}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_nt_epilogue(dtype):
+    M, N, K = 150, 200, 64
+    a, b = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2)
+    scale, shift = torch.rand(N) + 0.5, torch.randn(N)
+    res = rnd((50, N), dtype, 3)
+    mask = rnd((M, N), dtype, 4)
+    acc = (a.float() @ b.float().t()) * scale + shift + res.float().repeat(3, 1)
+    ref = torch.where(mask.float() > 0, acc.clamp(min=0), torch.zeros(()))
+    out = ops.gemm_nt(a.to(DEV), b.to(DEV), scale=scale.to(DEV), shift=shift.to(DEV), residual=res.to(DEV),
+                      residual_row_mod=50, relu=True, relu_mask=mask.to(DEV))
+    check(out, ref, dtype, 8, "epilogue")
+    out32 = ops.gemm_nt(a.to(DEV), b.to(DEV), shift=shift.to(DEV), out_f32=True)
+    assert out32.dtype == torch.float32
+    check(out32, a.float() @ b.float().t() + shift, torch.float32 if dtype == torch.float32 else dtype, 8, "out_f32")
+    # row-broadcast A (a_row_mod): rows repeat with period 50
+    out = ops.gemm_nt(a[:50].contiguous().to(DEV), b.to(DEV), a_row_mod=50, m_rows=M)
+    check(out, (a[:50].float() @ b.float().t()).repeat(3, 1), dtype, 8, "a_row_mod")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mnk", [(300, 128, 128), (1000, 40, 72), (64, 256, 2048), (4097, 8, 8)])
+def test_gemm_tn_and_colsum(dtype, mnk):
+    M, N1, K2 = mnk
+    g, x = rnd((M, N1), dtype, 1), rnd((M, K2), dtype, 2)
+    rs = torch.rand(N1) + 0.5
+    dw0 = torch.randn(N1, K2)
+    ref = dw0 + (g.float().t() @ x.float()) * rs[:, None]
+    dw = dw0.clone().to(DEV)
+    ops.gemm_tn_acc(g.to(DEV), x.to(DEV), dw, row_scale=rs.to(DEV))
+    check(dw, ref, torch.float32 if dtype == torch.float32 else dtype, math.sqrt(M), f"gemm_tn {mnk}")
+    out = torch.zeros(N1, device=DEV)
+    ops.colsum_acc(g.to(DEV), out)
+    check(out, g.float().sum(0), torch.float32, math.sqrt(M), "colsum")
+    if M % 4 == 0:
+        out = torch.zeros(4, N1, device=DEV)
+        ops.colsum_acc(g.to(DEV), out, group_rows=M // 4)
+        check(out, g.float().view(4, M // 4, N1).sum(1), torch.float32, math.sqrt(M), "grouped colsum")
+
+
+CONV_CASES = [  # (Nimg, H, W, Cin, Cout, k, stride, pad)
+    (2, 17, 23, 8, 64, 7, 2, 3),      # stem shape (Cin padded 3->8)
+    (2, 15, 20, 64, 64, 3, 1, 1),
+    (1, 15, 21, 64, 128, 3, 2, 1),
+    (3, 9, 11, 128, 72, 1, 1, 0),
+    (2, 9, 12, 256, 512, 1, 2, 0),
+    (1, 29, 50, 32, 40, 3, 1, 1),
+]
+
+
+def _conv_ref(x, w, stride, pad):
+    return F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), None, stride, pad)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_dgrad_wgrad(dtype, case):
+    n, h, w_, cin, cout, k, stride, pad = case
+    x = rnd((n, h, w_, cin), dtype, 1)
+    w = rnd((cout, k, k, cin), dtype, 2, scale=1.0 / math.sqrt(k * k * cin))
+    scale, shift = torch.rand(cout) + 0.5, torch.randn(cout) * 0.1
+    geom = ops.conv_geom(x.shape, cout, k, stride, pad)
+    x32 = x.float().requires_grad_(True)
+    w32 = w.float().requires_grad_(True)
+    y_lin = _conv_ref(x32, w32, stride, pad)                       # NCHW
+    res = rnd((n, geom.Ho, geom.Wo, cout), dtype, 3)
+    y_ref = (y_lin * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res.float().permute(0, 3, 1, 2)).clamp(min=0)
+    y = ops.conv2d_fwd(x.to(DEV), w.to(DEV), geom, scale=scale.to(DEV), shift=shift.to(DEV),
+                       residual=res.to(DEV), relu=True)
+    check(y, y_ref.permute(0, 2, 3, 1), dtype, 2, f"conv fwd {case}")
+    # backward of the linear part: dgrad and wgrad against autograd
+    dy = rnd((n, geom.Ho, geom.Wo, cout), dtype, 4)
+    y_lin.backward(dy.float().permute(0, 3, 1, 2))
+    w_t = w.permute(3, 1, 2, 0).contiguous()                        # [Cin, kh, kw, Cout]
+    if stride == 1 or True:
+        dres = rnd((n, h, w_, cin), dtype, 5)
+        mask = rnd((n, h, w_, cin), dtype, 6)
+        dx = ops.conv2d_dgrad(dy.to(DEV), w_t.to(DEV), geom, residual=dres.to(DEV), relu_mask=mask.to(DEV))
+        dx_ref = torch.where(mask.float() > 0, x32.grad + dres.float(), torch.zeros(()))
+        check(dx, dx_ref, dtype, 4, f"conv dgrad {case}")
+    dw = torch.zeros((cout, k, k, cin), device=DEV)
+    rs = torch.rand(cout) + 0.5
+    ops.conv2d_wgrad_acc(dy.to(DEV), x.to(DEV), dw, geom, row_scale=rs.to(DEV))
+    check(dw, w32.grad * rs.view(-1, 1, 1, 1), torch.float32 if dtype == torch.float32 else dtype,
+          math.sqrt(n * geom.Ho * geom.Wo), f"conv wgrad {case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layout_helpers(dtype):
+    v = torch.randn(3, 3, 10, 13)
+    out = ops.nchw_to_nhwc(v.to(DEV), dtype, 8)
+    ref = torch.zeros(3, 10, 13, 8)
+    ref[..., :3] = v.permute(0, 2, 3, 1)
+    check(out, ref.to(dtype), dtype, 1, "nchw_to_nhwc")
+    x = rnd((2, 11, 14, 16), dtype, 1)
+    check(ops.maxpool3x3s2(x.to(DEV)), F.max_pool2d(x.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1),
+          dtype, 1, "maxpool")
+    w = torch.randn(6, 5, 3)                                        # [co, tap, ci]
+    sc = torch.rand(6) + 0.5
+    o = ops.permute3_cast(w.to(DEV), dtype, (6, 5, 8), (15, 3, 1), valid2=3, scale=sc.to(DEV), scale_axis=0)
+    ref = torch.zeros(6, 5, 8)
+    ref[..., :3] = w * sc[:, None, None]
+    check(o, ref.to(dtype), dtype, 1, "permute3 pad")
+    o = ops.permute3_cast(w.to(DEV), dtype, (3, 5, 6), (1, 3, 15), scale=sc.to(DEV), scale_axis=2)
+    check(o, (w * sc[:, None, None]).permute(2, 1, 0).to(dtype), dtype, 1, "permute3 transpose")
+    a, b = rnd((12, 64), dtype, 2), rnd((4, 64), dtype, 3)
+    check(ops.eltwise(L.EW_ADD, a.to(DEV), b.to(DEV), b_row_mod=4), a.float() + b.float().repeat(3, 1), dtype, 1, "add mod")
+    check(ops.eltwise(L.EW_ADD, a.to(DEV), b.to(DEV), b_row_div=3), a.float() + b.float().repeat_interleave(3, 0), dtype, 1, "add div")
+    check(ops.eltwise(L.EW_MUL, a.to(DEV), a.to(DEV)), a.float() ** 2, dtype, 1, "mul")
+    check(ops.eltwise(L.EW_RELU_MASK, a.to(DEV), (-a).to(DEV)), torch.where(a.float() < 0, a.float(), torch.zeros(())), dtype, 1, "relu mask")
+    check(ops.eltwise(L.EW_ADD3, a.to(DEV), a.to(DEV), a.to(DEV)), 3 * a.float(), dtype, 1, "add3")
+
+
+# ------------------------------------------------------------------------------------------------
+def _attn_ref(q1, k1, v, scale, q2=None, k2=None):
+    B, T, E = q1.shape
+    H = E // 32
+    def heads(t):
+        return t.view(t.shape[0], t.shape[1], H, 32).transpose(1, 2)
+    s = heads(q1) @ heads(k1).transpose(-1, -2)
+    if q2 is not None:
+        s = s + heads(q2) @ heads(k2).transpose(-1, -2)
+    p = torch.softmax(s * scale, dim=-1)
+    return (p @ heads(v)).transpose(1, 2).reshape(B, T, E)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 4, 77, 150, 1), (1, 8, 128, 49, 2), (2, 2, 33, 1, 2), (1, 8, 200, 200, 1)])
+def test_attention_fwd_bwd(dtype, shape):
+    B, H, Tq, S, parts = shape
+    E = H * 32
+    q1, k1, v = rnd((B, Tq, E), dtype, 1), rnd((B, S, E), dtype, 2), rnd((B, S, E), dtype, 3)
+    q2 = rnd((B, Tq, E), dtype, 4) if parts == 2 else None
+    k2 = rnd((B, S, E), dtype, 5) if parts == 2 else None
+    scale = 1.0 / math.sqrt(32 * parts)
+    leaves = [t.float().requires_grad_(True) if t is not None else None for t in (q1, k1, v, q2, k2)]
+    o_ref = _attn_ref(leaves[0], leaves[1], leaves[2], scale, leaves[3], leaves[4])
+    dout = rnd((B, Tq, E), dtype, 6)
+    o_ref.backward(dout.float())
+    g = lambda t: None if t is None else t.to(DEV)
+    o, lse2 = ops.attn_fwd(g(q1), g(k1), g(v), scale, g(q2), g(k2))
+    check(o, o_ref, dtype, 1, f"attn fwd {shape}")
+    # the backward consumes the forward's own (rounded) output, as it does in the model
+    dq1, dk1, dq2, dk2, dv = ops.attn_bwd(g(q1), g(k1), g(v), o, g(dout), lse2, scale, g(q2), g(k2))
+    sc = math.sqrt(max(Tq, S)) * 0.5
+    check(dq1, leaves[0].grad, dtype, sc, "dq1")
+    check(dk1, leaves[1].grad, dtype, sc, "dk1")
+    check(dv, leaves[2].grad, dtype, sc, "dv")
+    if parts == 2:
+        check(dq2, leaves[3].grad, dtype, sc, "dq2")
+        check(dk2, leaves[4].grad, dtype, sc, "dk2")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("D", [64, 256])
+def test_layernorm(dtype, D):
+    rows = 37
+    x, r = rnd((rows, D), dtype, 1), rnd((rows, D), dtype, 2)
+    gamma, beta = torch.rand(D) + 0.5, torch.randn(D) * 0.1
+    s_ref = (x.float() + r.float()).to(dtype).float().requires_grad_(True)
+    gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_ref = F.layer_norm(s_ref, (D,), gm, bt, 1e-5)
+    dy = rnd((rows, D), dtype, 3)
+    y_ref.backward(dy.float())
+    y, s, mean, rstd = ops.layernorm_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), residual=r.to(DEV))
+    check(y, y_ref, dtype, 2, "ln fwd")
+    check(s, s_ref, dtype, 1, "ln sum")
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    dx = ops.layernorm_bwd(dy.to(DEV), s, mean, rstd, gamma.to(DEV), dg, db)
+    check(dx, s_ref.grad, dtype, 4, "ln dx")
+    check(dg, gm.grad, torch.float32 if dtype == torch.float32 else dtype, 8, "ln dgamma")
+    check(db, bt.grad, torch.float32 if dtype == torch.float32 else dtype, 8, "ln dbeta")
+    # broadcast residual: row m uses residual row m // 5
+    rb = rnd((8, D), dtype, 4)
+    y, s, _, _ = ops.layernorm_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), residual=rb.to(DEV), res_row_div=5)
+    ref = F.layer_norm((x.float() + rb.float().repeat_interleave(5, 0)[:rows]).to(dtype).float(), (D,), gamma, beta, 1e-5)
+    check(y, ref, dtype, 2, "ln bcast")
