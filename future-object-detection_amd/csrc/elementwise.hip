@@ -121,6 +121,7 @@ __global__ void eltwise_kernel(int op, T* __restrict__ out, const T* __restrict_
       case FOD_EW_RELU_MASK: r = bv > 0.f ? av : 0.f; break;
       case FOD_EW_SCALE: r = alpha * av; break;
       case FOD_EW_ADD3: r = av + bv + to_f32(c[i]); break;
+      case FOD_EW_COPY_B: r = bv; break;
       default: r = fmaxf(av, 0.f); break;
     }
     out[i] = from_f32<T>(r);
@@ -148,14 +149,15 @@ __global__ void permute3_kernel(const TS* __restrict__ src, TD* __restrict__ dst
 
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int F, int C, int H, int W,
-                                    int Cp) {
+                                    int Cp, int inner, long stride_outer, long stride_inner) {
   const long hw = (long)H * W;
   const long n = (long)F * hw;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const long f = i / hw;
     const long px = i - f * hw;
+    const float* s = src + (f / inner) * stride_outer + (f % inner) * stride_inner;
     T* o = dst + i * Cp;
-    for (int c = 0; c < Cp; ++c) o[c] = from_f32<T>(c < C ? src[(f * C + c) * hw + px] : 0.f);
+    for (int c = 0; c < Cp; ++c) o[c] = from_f32<T>(c < C ? s[c * hw + px] : 0.f);
   }
 }
 
@@ -283,34 +285,36 @@ FOD_DEVINL float inv_sigmoid_grad(float x) {
 
 template <typename T>
 __global__ void box_finish_fwd_kernel(const T* __restrict__ t, const float* __restrict__ ref, float* __restrict__ boxes,
-                                      int levels, int R) {
+                                      int levels, int R, int ref_rows) {
   const long n = (long)levels * R * 4;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int k = (int)(i & 3);
     const int r = (int)((i >> 2) % R);
     float v = to_f32(t[i]);
-    if (k < 2) v += inv_sigmoid(ref[r * 2 + k]);
+    if (k < 2) v += inv_sigmoid(ref[(r % ref_rows) * 2 + k]);
     boxes[i] = 1.f / (1.f + expf(-v));
   }
 }
 
-// one thread per (r, k): loops levels so the dref sum needs no atomics
+// one thread per (ref row, k): loops levels and the rows sharing that reference point, so the dref
+// sum needs no atomics
 template <typename T>
 __global__ void box_finish_bwd_kernel(const float* __restrict__ dboxes, const float* __restrict__ boxes,
                                       const float* __restrict__ ref, T* __restrict__ dt, float* __restrict__ dref,
-                                      int levels, int R) {
-  const int n = R * 4;
+                                      int levels, int R, int ref_rows) {
+  const int n = ref_rows * 4;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int k = i & 3, r = i >> 2;
+    const int k = i & 3, rr = i >> 2;
     float acc = 0.f;
-    for (int l = 0; l < levels; ++l) {
-      const long idx = (long)l * n + i;
-      const float b = boxes[idx];
-      const float g = dboxes[idx] * b * (1.f - b);
-      dt[idx] = from_f32<T>(g);
-      acc += g;
-    }
-    if (k < 2) dref[r * 2 + k] += acc * inv_sigmoid_grad(ref[r * 2 + k]);
+    for (int l = 0; l < levels; ++l)
+      for (int r = rr; r < R; r += ref_rows) {
+        const long idx = ((long)l * R + r) * 4 + k;
+        const float b = boxes[idx];
+        const float g = dboxes[idx] * b * (1.f - b);
+        dt[idx] = from_f32<T>(g);
+        acc += g;
+      }
+    if (k < 2) dref[rr * 2 + k] += acc * inv_sigmoid_grad(ref[rr * 2 + k]);
   }
 }
 
@@ -366,7 +370,7 @@ extern "C" int fod_layernorm_bwd(int dtype, const void* dy, const void* xsum, co
 extern "C" int fod_eltwise(int op, int dtype, void* out, const void* a, const void* b, const void* c, long rows,
                            int cols, int b_row_div, int b_row_mod, float alpha, hipStream_t stream) {
   FOD_REQUIRE(out && a && rows > 0 && cols > 0, "eltwise: bad args");
-  FOD_REQUIRE(op >= FOD_EW_ADD && op <= FOD_EW_RELU, "eltwise: bad op %d", op);
+  FOD_REQUIRE(op >= FOD_EW_ADD && op <= FOD_EW_COPY_B, "eltwise: bad op %d", op);
   FOD_REQUIRE(b || op == FOD_EW_SCALE || op == FOD_EW_RELU, "eltwise: op %d needs b", op);
   FOD_REQUIRE(c || op != FOD_EW_ADD3, "eltwise: ADD3 needs c");
   const long n = rows * cols;
@@ -396,12 +400,12 @@ extern "C" int fod_permute3_cast(int src_dtype, int dst_dtype, const void* src, 
 }
 
 extern "C" int fod_nchw_to_nhwc(int dtype, const float* src, void* dst, int F, int C, int H, int W, int Cp,
-                                hipStream_t stream) {
-  FOD_REQUIRE(src && dst && F > 0 && C > 0 && Cp >= C, "nchw_to_nhwc: bad args");
+                                int inner, long stride_outer, long stride_inner, hipStream_t stream) {
+  FOD_REQUIRE(src && dst && F > 0 && C > 0 && Cp >= C && inner > 0 && F % inner == 0, "nchw_to_nhwc: bad args");
   const long n = (long)F * H * W;
   FOD_DISPATCH_T(dtype, "nchw_to_nhwc",
                  hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(n)), dim3(256), 0, stream, src, (T*)dst, F,
-                                    C, H, W, Cp))
+                                    C, H, W, Cp, inner, stride_outer, stride_inner))
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }
@@ -461,22 +465,23 @@ extern "C" int fod_refpoint_sine_bwd(int dtype, const void* dsine, const float* 
 }
 
 extern "C" int fod_box_finish_fwd(int dtype, const void* t, const float* ref, float* boxes, int levels, int R,
-                                  hipStream_t stream) {
-  FOD_REQUIRE(t && ref && boxes && levels > 0 && R > 0, "box_finish_fwd: bad args");
+                                  int ref_rows, hipStream_t stream) {
+  FOD_REQUIRE(t && ref && boxes && levels > 0 && R > 0 && ref_rows > 0 && R % ref_rows == 0, "box_finish_fwd: bad args");
   const long n = (long)levels * R * 4;
   FOD_DISPATCH_T(dtype, "box_finish_fwd",
                  hipLaunchKernelGGL((box_finish_fwd_kernel<T>), dim3(grid_for(n)), dim3(256), 0, stream, (const T*)t,
-                                    ref, boxes, levels, R))
+                                    ref, boxes, levels, R, ref_rows))
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }
 
 extern "C" int fod_box_finish_bwd(int dtype, const float* dboxes, const float* boxes, const float* ref, void* dt,
-                                  float* dref, int levels, int R, hipStream_t stream) {
-  FOD_REQUIRE(dboxes && boxes && ref && dt && dref && levels > 0 && R > 0, "box_finish_bwd: bad args");
+                                  float* dref, int levels, int R, int ref_rows, hipStream_t stream) {
+  FOD_REQUIRE(dboxes && boxes && ref && dt && dref && levels > 0 && R > 0 && ref_rows > 0 && R % ref_rows == 0,
+              "box_finish_bwd: bad args");
   FOD_DISPATCH_T(dtype, "box_finish_bwd",
-                 hipLaunchKernelGGL((box_finish_bwd_kernel<T>), dim3(grid_for((long)R * 4)), dim3(256), 0, stream,
-                                    dboxes, boxes, ref, (T*)dt, dref, levels, R))
+                 hipLaunchKernelGGL((box_finish_bwd_kernel<T>), dim3(grid_for((long)ref_rows * 4)), dim3(256), 0, stream,
+                                    dboxes, boxes, ref, (T*)dt, dref, levels, R, ref_rows))
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }

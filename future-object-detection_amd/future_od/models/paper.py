@@ -1,0 +1,252 @@
+"""Model cores of the paper architecture on the HIP kernels.
+
+Drop-in for reference future_od/models/paper.py: PositionalEncoder, CDetrBackbone,
+SeparateEncoder, CDetrDetectorSpatioTemporal, FuturePredCore with the reference's constructor
+arguments and parameter names.  What differs is how a clip flows through them:
+
+  [B,L,3,H,W] f32  --one strided read-->  frame-major NHWC [(l b),H,W,8]  (compute dtype)
+     --ResNet + input_proj (future_od.native.backbone, one autograd node)-->  tokens [(l b), N, D]
+     --encoder layers (batch-first, positional TABLE [N,D])-->  per-frame memories [B,N,D]
+     --decoder over the last `num_images` frames-->  hs [layers,B,M,D] --> logits / boxes (f32)
+
+Frames that cannot influence the output are not computed: with the shipped "attend one at a time"
+detector and no slot states only the last `num_images` past frames reach the prediction (reference
+paper.py:347-350,399-402), and the reference's decoder passes for earlier frames are
+overwritten.  `skip_dead_frames=False` restores the reference's full sweep (same outputs).
+"""
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from future_od.models.transformer import MLP, TransformerEncoder
+from future_od.native import functional as Fn
+from future_od.native import ops
+from future_od.native.backbone import ConvWeight, ResNetBody, run_backbone
+
+
+def is_main_process():
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
+class PositionalEncoder(nn.Module):
+    """DETR sine encodings.  The kernels consume token-major tables (`spatial_table`,
+    `temporal_table`); the reference-shaped getters remain for API compatibility."""
+
+    def __init__(self, no_temporal: bool = False, temperature=10000, extra_temporal_offset: float = 0.0):
+        super().__init__()
+        self._no_temporal = no_temporal
+        self._temperature = temperature
+        self._extra_temporal_offset = extra_temporal_offset
+        self.scale = 2 * math.pi
+        self._tables = {}
+
+    def spatial_table(self, h, w, c, dtype, device):
+        """[h*w, c]; input independent, so computed once per (shape, dtype, device)."""
+        key = (h, w, c, dtype, str(device))
+        if key not in self._tables:
+            self._tables[key] = ops.posenc_table(h, w, c, dtype, device, float(self._temperature))
+        return self._tables[key]
+
+    def temporal_table(self, b, l, c, dtype, device, temporal_offsets=None):
+        """[b, l, c] per-frame encoding (reference paper.py:66-73)."""
+        offs = None if temporal_offsets is None else temporal_offsets.float().contiguous()
+        return ops.posenc_temporal(b, l, c, dtype, device, offs, float(self._extra_temporal_offset),
+                                   float(self._temperature))
+
+    def get_spatial_encoding(self, b, c, h, w, device):
+        t = self.spatial_table(h, w, c, torch.float32, device)
+        return t.t().reshape(1, c, h, w).expand(b, -1, -1, -1)
+
+    def get_spatio_temporal_encoding(self, b, l, c, h, w, device, temporal_offsets):
+        enc = self.get_spatial_encoding(1, c, h, w, device)[:, None].expand(b, l, -1, -1, -1)
+        if not self._no_temporal:
+            enc = enc + self.temporal_table(b, l, c, torch.float32, device, temporal_offsets)[..., None, None]
+        return enc
+
+
+class CDetrBackbone(nn.Module):
+    """ResNet with frozen BatchNorm + 1x1 projection to hidden_dim (reference paper.py:83-116)."""
+
+    def __init__(self, name: str, train_backbone: bool, dilation: bool, hidden_dim: int, pretrained=True):
+        super().__init__()
+        if dilation:
+            raise NotImplementedError("dilated layer4 is never used by the reference's runs/ (runs/_model.py:22)")
+        if pretrained and is_main_process():
+            print("[future_od] pretrained torchvision weights cannot be fetched here (no torchvision / network): "
+                  "the backbone keeps its random init until a checkpoint is loaded.")
+        self.body = ResNetBody(name)
+        self.num_channels = 512 if name in ("resnet18", "resnet34") else 2048
+        for pname, p in self.body.named_parameters():
+            if not train_backbone or ("layer2" not in pname and "layer3" not in pname and "layer4" not in pname):
+                p.requires_grad_(False)
+        self.input_proj = ConvWeight(self.num_channels, hidden_dim, 1, 1, 0, bias=True)
+        nn.init.kaiming_uniform_(self.input_proj.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(self.num_channels)
+        nn.init.uniform_(self.input_proj.bias, -bound, bound)
+
+    def forward_clip(self, clip, dtype):
+        """clip f32 [B,L,3,H,W] (view) -> NHWC features [(l b), h, w, hidden]."""
+        return run_backbone(clip, self.body, self.input_proj, dtype)
+
+
+class SeparateEncoder(nn.Module):
+    """Per-frame backbone + transformer encoder (reference paper.py:119-170)."""
+
+    def __init__(self, backbone: CDetrBackbone, transformer: TransformerEncoder = None,
+                 imu_layers: nn.Module = None, concat_imu: bool = False):
+        super().__init__()
+        if concat_imu:
+            raise NotImplementedError("concat_imu is never used by the reference's runs/")
+        self.backbone = backbone
+        self.imu_layers = imu_layers
+        self.transformer = transformer
+        self.concat_imu = concat_imu
+
+    def forward(self, clip, pos_encoder: PositionalEncoder, imu: Tensor = None, dtype=torch.bfloat16):
+        """clip [B,L,3,H,W] f32, imu [B,L,I] f32 -> (tokens [(l b), N, D], (h, w), ego [(l b), D] | None)."""
+        B, L = clip.shape[:2]
+        feat = self.backbone.forward_clip(clip, dtype)                       # [(l b), h, w, D]
+        F_, h, w, D = feat.shape
+        tokens = feat.view(F_, h * w, D)
+        ego = None
+        if imu is not None and self.imu_layers is not None:
+            I = imu.shape[-1]
+            # (l b)-ordered, zero-padded to the 16-byte vector width, in the compute dtype
+            pad = Fn._pad_to(I, Fn._VEC[dtype])
+            sb, sl, si = imu.stride()
+            assert si == 1
+            x = ops.permute3_cast(imu, dtype, (L, B, pad), (sl, sb, 1), valid2=I).view(L * B, pad)
+            lin0, lin2 = self.imu_layers[0], self.imu_layers[2]
+            h0 = _linear_padded_in(x, lin0, I, relu=True)
+            ego = Fn.linear(h0, lin2.weight, lin2.bias)
+        if self.transformer:
+            pos = pos_encoder.spatial_table(h, w, D, dtype, feat.device)
+            tokens = self.transformer(tokens, pos, ego)
+        return tokens, (h, w), ego
+
+
+class _PaddedInLinear(torch.autograd.Function):
+    """Linear whose in_features (I) is not a multiple of the vector width: the input arrives already
+    zero-padded to Ip columns and the weight is padded on the fly; dW is cut back to [N, I]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, I, relu):
+        N = weight.shape[0]
+        Ip = x.shape[-1]
+        wp = Fn.PREP.get(weight, f"lin_pad{Ip}", x.dtype, lambda: ops.permute3_cast(
+            weight.detach(), x.dtype, (1, N, Ip), (0, I, 1), valid2=I).view(N, Ip))
+        y = ops.gemm_nt(x, wp, shift=bias, relu=relu)
+        ctx.save_for_backward(x, y)
+        ctx.meta = (I, relu, N, Ip)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        I, relu, N, Ip = ctx.meta
+        g = dy.contiguous()
+        if relu:
+            g = ops.eltwise(Fn.L.EW_RELU_MASK, g, y)
+        dw = torch.zeros((N, Ip), dtype=torch.float32, device=x.device)
+        ops.gemm_tn_acc(g, x, dw)
+        db = torch.zeros(N, dtype=torch.float32, device=x.device)
+        ops.colsum_acc(g, db)
+        return None, dw[:, :I], db, None, None
+
+
+def _linear_padded_in(x, lin, I, relu):
+    return _PaddedInLinear.apply(x, lin.weight, lin.bias, I, relu)
+
+
+class CDetrDetectorSpatioTemporal(nn.Module):
+    """Query decoder over the current and previous frames' memories (reference paper.py:280-429)."""
+
+    def __init__(self, decoder, num_classes: int, hidden_dim: int, first_layer_special_when, num_queries=300,
+                 aux_loss=True, image_memory_mode="attend one at a time"):
+        super().__init__()
+        self.decoder = decoder
+        self.aux_loss = aux_loss
+        self.class_embed = nn.Linear(hidden_dim, num_classes)
+        self.bbox_embed = MLP(hidden_dim, hidden_dim, 4, 3)
+        self.query_embed = nn.Embedding(num_queries, hidden_dim)
+        prior_prob = 0.01
+        self.class_embed.bias.data = torch.ones(num_classes) * (-math.log((1 - prior_prob) / prior_prob))
+        nn.init.constant_(self.bbox_embed.layers[-1].weight.data, 0)
+        nn.init.constant_(self.bbox_embed.layers[-1].bias.data, 0)
+        assert first_layer_special_when in ("first frame", "always", "never")
+        self._first_layer_special_when = first_layer_special_when
+        assert image_memory_mode in ("attend one at a time", "attend all at once")
+        if image_memory_mode != "attend one at a time":
+            raise NotImplementedError("'attend all at once' is not used by the reference's runs/ (SURVEY.md 8f-2)")
+        self.image_memory_mode = image_memory_mode
+        self.num_images = len(self.decoder.layers[0].image_attend)
+        assert all(self.num_images == len(layer.image_attend) for layer in self.decoder.layers)
+        self.use_slotstates = False
+
+    def frames_needed(self, L):
+        return min(self.num_images, L)
+
+    def forward(self, frame_tokens: List[Tensor], pos_table: Tensor, num_frames_total: int):
+        """frame_tokens: the LAST frames of the clip, oldest first, each [B,N,D]; pos_table [N,D].
+        Equivalent to the reference's sweep over all frames keeping the last result (paper.py:347-350)."""
+        K = len(frame_tokens)
+        first_frame = num_frames_total == 1
+        mems = [frame_tokens[K - 1 - j] for j in range(min(K, self.num_images))]   # current, then previous
+        return self.detect(mems, pos_table, first_frame)
+
+    def detect(self, mems, pos_table, first_frame=True):
+        B, N, D = mems[0].shape
+        dtype = mems[0].dtype
+        M = self.query_embed.weight.shape[0]
+        qpos = Fn.cast_ad(self.query_embed.weight, dtype)                         # [M, D]
+        x0 = torch.zeros((B, M, D), dtype=dtype, device=qpos.device)
+        special = (first_frame and self._first_layer_special_when == "first frame") or \
+            self._first_layer_special_when == "always"
+        hs, ref = self.decoder(x0, qpos, mems, [pos_table] * len(mems), first_layer_special=special)
+        Lv = hs.shape[0]
+        logits = Fn.linear(hs, self.class_embed.weight, self.class_embed.bias, out_f32=True)      # [Lv,B,M,C] f32
+        t = self.bbox_embed(hs)                                                                    # [Lv,B,M,4]
+        boxes = Fn.BoxFinishFn.apply(t.view(Lv, B * M, 4), ref, Lv).view(Lv, B, M, 4)             # f32
+        out = {"pred_logits": logits[-1], "pred_boxes": boxes[-1]}
+        if self.aux_loss:
+            out["aux_outputs"] = [{"pred_logits": a, "pred_boxes": b} for a, b in zip(logits[:-1], boxes[:-1])]
+        out["_stacked"] = (logits, boxes)          # all levels, final level last (private fast path)
+        return out
+
+
+class FuturePredCore(nn.Module):
+    """Drop the future frame, encode the past frames, decode the future detections (reference :432-485)."""
+
+    def __init__(self, separate_encoder: SeparateEncoder, joint_encoder, detector: CDetrDetectorSpatioTemporal,
+                 pos_encoder: PositionalEncoder):
+        super().__init__()
+        if joint_encoder is not None:
+            raise NotImplementedError("joint encoders are not instantiated by the reference's runs/ (SURVEY.md 8f-2)")
+        self.separate_encoder = separate_encoder
+        self.joint_encoder = None
+        self.detector = detector
+        self.pos_encoder = pos_encoder
+        self.compute_dtype = torch.bfloat16
+        self.skip_dead_frames = True
+
+    def forward(self, images: Tensor, imu: Tensor = None, temporal_offsets: Tensor = None):
+        B, L = images.shape[:2]
+        if not self.pos_encoder._no_temporal:
+            raise NotImplementedError("temporal positional encoding is disabled in the shipped model "
+                                      "(runs/_model.py:70-72); kernel exists (fod_posenc_temporal), wiring is next")
+        past = L - 1
+        assert past > 0
+        keep = self.detector.frames_needed(past) if self.skip_dead_frames else past
+        clip = images[:, past - keep:past]
+        imu_k = imu[:, past - keep:past] if imu is not None else None
+        tokens, (h, w), _ego = self.separate_encoder(clip, self.pos_encoder, imu_k, dtype=self.compute_dtype)
+        F_, N, D = tokens.shape
+        frames = list(tokens.view(keep, B, N, D).unbind(0))
+        pos = self.pos_encoder.spatial_table(h, w, D, self.compute_dtype, tokens.device)
+        out = self.detector(frames, pos, num_frames_total=past)
+        moods = [["model happy" for _ in range(L)] for _ in range(B)]
+        return out, moods

@@ -1,0 +1,160 @@
+"""Hungarian-matched set loss on the HIP kernels.
+
+Drop-in for reference future_od/models/set_criterion.py (`SetCriterion`) plus the matcher the
+reference pulls from the absent ConditionalDETR submodule (`HungarianMatcher` / `build_matcher`,
+called at reference set_criterion.py:182,204).  One pass over ALL decoder levels:
+
+    cost matrices (one kernel, all levels)  ->  ONE device-to-host copy  ->  host LAP on worker
+    threads (libfod_hip.so, same algorithm as scipy's)  ->  matches to device  ->  one loss kernel
+    (focal + L1 + GIoU + cardinality + class error per level)  ->  one gradient kernel in backward.
+
+The reference does this six times with six host syncs.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+from torch.autograd import Function
+
+from future_od.native import ops
+
+
+class HungarianMatcher(nn.Module):
+    """Optimal bipartite matching between queries and targets; focal-style class cost + L1 + GIoU."""
+
+    def __init__(self, cost_class: float = 1, cost_bbox: float = 1, cost_giou: float = 1):
+        super().__init__()
+        self.cost_class, self.cost_bbox, self.cost_giou = cost_class, cost_bbox, cost_giou
+        assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
+
+    @torch.no_grad()
+    def match_levels(self, logits, boxes, packed, threads=8):
+        """logits f32 [L,B,M,C], boxes f32 [L,B,M,4] -> match int32 [L,B,M] on device: GLOBAL target
+        index (into the concatenated target list) or -1."""
+        Lv, B, M, _ = logits.shape
+        sizes = packed["sizes"]
+        ld = max(max(sizes), 1)
+        cost = ops.match_cost(logits, boxes, packed["labels"], packed["boxes"], packed["offset"], ld,
+                              self.cost_class, self.cost_bbox, self.cost_giou)
+        local = ops.lap_solve_batch_host(cost.cpu().view(Lv * B, M, ld), sizes * Lv, threads).view(Lv, B, M)
+        off = packed["offset_cpu"][:B].view(1, B, 1)
+        glob = torch.where(local >= 0, local + off, local)
+        return glob.to(logits.device, non_blocking=True), local
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        """Reference-shaped API: list of (idx_pred int64 ascending, idx_tgt int64) per sample."""
+        packed = pack_targets(targets, outputs["pred_logits"].device)
+        _, local = self.match_levels(outputs["pred_logits"].detach().float()[None].contiguous(),
+                                     outputs["pred_boxes"].detach().float()[None].contiguous(), packed)
+        out = []
+        for b in range(local.shape[1]):
+            m = local[0, b]
+            i = torch.nonzero(m >= 0).flatten()
+            out.append((i.to(torch.int64), m[i].to(torch.int64)))
+        return out
+
+
+def build_matcher(args):
+    return HungarianMatcher(cost_class=args.set_cost_class, cost_bbox=args.set_cost_bbox,
+                            cost_giou=args.set_cost_giou)
+
+
+def pack_targets(targets, device):
+    """list of {"labels","boxes"} -> concatenated device tensors + per-sample offsets (one host sync,
+    meant to run BEFORE the model forward is queued so it does not stall the stream)."""
+    sizes = [int(t["labels"].shape[0]) for t in targets]
+    labels = torch.cat([t["labels"] for t in targets]).to(device=device, dtype=torch.int64).contiguous()
+    boxes = torch.cat([t["boxes"] for t in targets]).to(device=device, dtype=torch.float32).contiguous()
+    off = [0]
+    for s in sizes:
+        off.append(off[-1] + s)
+    off_cpu = torch.tensor(off, dtype=torch.int32)
+    if labels.numel() == 0:          # keep pointers valid for the kernels
+        labels = torch.zeros(1, dtype=torch.int64, device=device)
+        boxes = torch.zeros((1, 4), dtype=torch.float32, device=device)
+    return {"sizes": sizes, "labels": labels, "boxes": boxes, "offset": off_cpu.to(device), "offset_cpu": off_cpu}
+
+
+class _SetLossFn(Function):
+    """(logits, boxes) [L,B,M,*] f32 -> table f32 [L,5] = ce, bbox, giou, cardinality_error, class_error."""
+
+    @staticmethod
+    def forward(ctx, logits, boxes, match, packed, num_boxes, alpha):
+        table = ops.set_loss_fwd(logits, boxes, match, packed["labels"], packed["boxes"], packed["offset"],
+                                 num_boxes, alpha)
+        ctx.save_for_backward(logits, boxes, match)
+        ctx.packed, ctx.num_boxes, ctx.alpha = packed, num_boxes, alpha
+        return table
+
+    @staticmethod
+    def backward(ctx, dtable):
+        logits, boxes, match = ctx.saved_tensors
+        g = dtable[:, :3].contiguous()
+        dl, db = ops.set_loss_bwd(logits, boxes, match, ctx.packed["labels"], ctx.packed["boxes"], g,
+                                  ctx.num_boxes, ctx.alpha)
+        return dl, db, None, None, None, None
+
+
+class LossDict(dict):
+    """The reference's dict of named losses, plus the [levels, 5] table they are views of."""
+    table = None
+    level_of = None
+
+
+class SetCriterion(nn.Module):
+    """Reference set_criterion.py:11-217 (labels, boxes, cardinality; masks are not on the path)."""
+
+    def __init__(self, num_classes, matcher, weight_dict, focal_alpha, losses, matching_mode):
+        super().__init__()
+        self.num_classes = num_classes
+        self.matcher = matcher
+        self.weight_dict = weight_dict
+        self.losses = losses
+        self.focal_alpha = focal_alpha
+        assert matching_mode in ("per level", "last level")
+        self._matching_mode = matching_mode
+        for name in losses:
+            assert name in ("labels", "boxes", "cardinality"), f"do you really want to compute {name} loss?"
+
+    def global_num_boxes(self, targets, device, distributed):
+        """set_criterion.py:185-193: mean number of boxes per rank, clamped to >= 1."""
+        n = float(sum(int(t["labels"].shape[0]) for t in targets))
+        if distributed:
+            t = torch.tensor([n], dtype=torch.float, device=device)
+            dist.all_reduce(t)
+            n = float(t.item()) / dist.get_world_size()
+        return max(n, 1.0)
+
+    def forward(self, outputs, targets, distributed, packed=None, num_boxes=None):
+        if "_stacked" in outputs:
+            logits, boxes = outputs["_stacked"]
+        else:
+            levels = list(outputs.get("aux_outputs", [])) + [outputs]
+            logits = torch.stack([o["pred_logits"].float() for o in levels])
+            boxes = torch.stack([o["pred_boxes"].float() for o in levels])
+        logits, boxes = logits.contiguous(), boxes.contiguous()
+        Lv = logits.shape[0]
+        if packed is None:
+            packed = pack_targets(targets, logits.device)
+        if num_boxes is None:
+            num_boxes = self.global_num_boxes(targets, logits.device, distributed)
+        if self._matching_mode == "per level":
+            match, _ = self.matcher.match_levels(logits.detach(), boxes.detach(), packed)
+        else:
+            match, _ = self.matcher.match_levels(logits.detach()[-1:], boxes.detach()[-1:], packed)
+            match = match.expand(Lv, -1, -1).contiguous()
+        table = _SetLossFn.apply(logits, boxes, match, packed, num_boxes, self.focal_alpha)
+        out = LossDict()
+        out.table = table
+        for lv in range(Lv):
+            sfx = "" if lv == Lv - 1 else f"_{lv}"
+            if "labels" in self.losses:
+                out["loss_ce" + sfx] = table[lv, 0]
+                if lv == Lv - 1:
+                    out["class_error"] = table[lv, 4].detach()
+            if "cardinality" in self.losses:
+                out["cardinality_error" + sfx] = table[lv, 3].detach()
+            if "boxes" in self.losses:
+                out["loss_bbox" + sfx] = table[lv, 1]
+                out["loss_giou" + sfx] = table[lv, 2]
+        return out

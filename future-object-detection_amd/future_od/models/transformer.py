@@ -1,0 +1,312 @@
+"""Transformer encoder / conditional-cross-attention decoder on the HIP kernels.
+
+Drop-in for the reference module of the same name (reference future_od/models/transformer.py):
+same class names, constructor arguments and parameter names (so state_dicts interchange,
+SURVEY.md 8b), different internals:
+
+  * token tensors are BATCH-FIRST [batch, tokens, D] (= the NHWC backbone output, no transposes);
+    positional inputs are batch-independent TABLES [tokens, D] and are broadcast inside kernels;
+  * every Linear / attention / LayerNorm / element-wise step is a call into libfod_hip.so through
+    future_od.native.functional (forward and backward);
+  * the conditional cross-attention never concatenates [content | sine]: the attention kernel
+    takes the two 32-wide parts of each head as separate operands (score = q1.k1 + q2.k2);
+  * the single-key IMU attention is evaluated in its exact collapsed form (softmax over one key
+    is 1, reference transformer.py:108-119 / SURVEY F7): one row per frame instead of N rows.
+
+Dropout: the reference applies dropout(0.1) in training mode.  These modules implement the
+eval-mode graph (dropout = identity) in both modes for now -- see DESIGN.md "Gaps".
+"""
+import math
+from typing import List, Optional
+
+import torch
+from torch import Tensor, nn
+
+from future_od.native import functional as Fn
+
+
+def _reset_parameters(parameters):
+    for p in parameters:
+        if p.dim() > 1:
+            nn.init.xavier_uniform_(p)
+
+
+def _lin(x, m: nn.Linear, relu=False, out_f32=False):
+    return Fn.linear(x, m.weight, m.bias, relu=relu, out_f32=out_f32)
+
+
+class MLP(nn.Module):
+    """Linear -> ReLU -> ... -> Linear (reference transformer.py:18-32)."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        dims = [input_dim] + [hidden_dim] * (num_layers - 1) + [output_dim]
+        self.layers = nn.ModuleList(nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x, out_f32=False):
+        for i, layer in enumerate(self.layers):
+            last = i == self.num_layers - 1
+            x = _lin(x, layer, relu=not last, out_f32=out_f32 and last)
+        return x
+
+
+class OutProj(nn.Module):
+    """Parameter holder named like ConditionalDETR's MultiheadAttention (`fun.out_proj.*`)."""
+
+    def __init__(self, vdim):
+        super().__init__()
+        self.out_proj = nn.Linear(vdim, vdim)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+
+class Attention(nn.Module):
+    def __init__(self, D):
+        super().__init__()
+        self.query_content = nn.Linear(D, D)
+        self.query_pos = nn.Linear(D, D)
+        self.key_content = nn.Linear(D, D)
+        self.key_pos = nn.Linear(D, D)
+        self.value = nn.Linear(D, D)
+
+
+class SlotToSlotAttention(Attention):
+    """Query self-attention (reference transformer.py:61-82).  x [B,M,D], qpos table [M,D]."""
+
+    def __init__(self, D, Nhead, dropout):
+        super().__init__(D)
+        self.fun = OutProj(D)
+        self.Nhead, self.D = Nhead, D
+
+    def forward(self, x, qpos):
+        M = qpos.shape[0]
+        q = Fn.add(_lin(x, self.query_content), _lin(qpos, self.query_pos), b_row_mod=M)
+        k = Fn.add(_lin(x, self.key_content), _lin(qpos, self.key_pos), b_row_mod=M)
+        v = _lin(x, self.value)
+        a = Fn.attention(q, k, v, 1.0 / math.sqrt(self.D // self.Nhead))
+        return _lin(a, self.fun.out_proj)
+
+
+class EgodeepAttention(nn.Module):
+    """Attention to the per-frame IMU token(s) (reference transformer.py:85-119).
+
+    With ONE key per frame the softmax weight is exactly 1, so the output is
+    out_proj(value(ego)) for every query row, and the following LayerNorm/MLP act on identical
+    rows: computed once per frame as [frames, D]; the caller broadcasts.  query_content /
+    query_pos / key only feed the (constant) softmax: their gradient is exactly zero."""
+
+    def __init__(self, D, Nhead, droprate, Dff=None):
+        super().__init__()
+        self.query_content = nn.Linear(D, D)
+        self.query_pos = nn.Linear(D, D)
+        self.key = nn.Linear(D, D)
+        self.value = nn.Linear(D, D)
+        self.fun = OutProj(D)
+        self.use_mlp = Dff is not None
+        if self.use_mlp:
+            self.norm1 = nn.LayerNorm(D)
+            self.mlp = nn.Sequential(nn.Linear(D, Dff), nn.ReLU(inplace=True), nn.Dropout(droprate),
+                                     nn.Linear(Dff, D), nn.Dropout(droprate))
+            self.norm2 = nn.LayerNorm(D)
+
+    def dead_parameters(self):
+        return [p for m in (self.query_content, self.query_pos, self.key) for p in m.parameters()]
+
+    def forward_single_key(self, ego):
+        """ego [frames, D] -> [frames, D]."""
+        out = _lin(_lin(ego, self.value), self.fun.out_proj)
+        if self.use_mlp:
+            out = Fn.layer_norm(out, self.norm1.weight, self.norm1.bias, residual=out)   # norm1(out + out)
+            h = _lin(out, self.mlp[0], relu=True)
+            out = Fn.layer_norm(out, self.norm2.weight, self.norm2.bias, residual=_lin(h, self.mlp[3]))
+        return out
+
+
+class SlotToImageAttention(Attention):
+    """Conditional cross-attention (reference transformer.py:122-181).
+
+    x [B,M,D]; qpos table [M,D]; query_sine [B,M,D] or table [M,D]; mem [B,N,D]; mem_pos table [N,D]."""
+
+    def __init__(self, D, Nhead, dropout):
+        super().__init__(D)
+        self.query_sine = nn.Linear(D, D)
+        self.fun = OutProj(D)
+        self.D, self.Nhead = D, Nhead
+        self.store_attention = False
+
+    def forward(self, x, qpos, query_sine, mem, mem_pos, is_first):
+        B, M, D = x.shape
+        N = mem.shape[1]
+        v = _lin(mem, self.value)
+        qc = _lin(x, self.query_content)
+        if is_first:
+            qc = Fn.add(qc, _lin(qpos, self.query_pos), b_row_mod=M)
+        qs = _lin(query_sine, self.query_sine)
+        if qs.dim() == 2:
+            qs = Fn.expand_rows(qs, B).view(B, M, D)
+        ks_tab = _lin(mem_pos, self.key_pos)                       # [N, D], batch independent
+        kc = _lin(mem, self.key_content)
+        if is_first:
+            kc = Fn.add(kc, ks_tab, b_row_mod=N)
+        ks = Fn.expand_rows(ks_tab, B).view(B, N, D)
+        # per head: q = [qc | qs], k = [kc | ks] (64 wide), scale (2D/heads)^-0.5
+        a = Fn.attention(qc, kc, v, 1.0 / math.sqrt(2 * D // self.Nhead), q2=qs, k2=ks)
+        if self.store_attention:
+            self.stored_attention = _head_mean_weights(qc, kc, qs, ks, self.Nhead)
+        return _lin(a, self.fun.out_proj)
+
+
+@torch.no_grad()
+def _head_mean_weights(qc, kc, qs, ks, H):
+    """Visualisation only (demo.ipynb): head-averaged attention map [B,M,N]; off the hot path."""
+    B, M, D = qc.shape
+    N = kc.shape[1]
+    hd = D // H
+    q = torch.cat([qc.float().view(B, M, H, hd), qs.float().view(B, M, H, hd)], 3).transpose(1, 2)
+    k = torch.cat([kc.float().view(B, N, H, hd), ks.float().view(B, N, H, hd)], 3).transpose(1, 2)
+    w = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(2 * hd), dim=-1)
+    return w.mean(1)
+
+
+class TransformerDecoderLayer(nn.Module):
+    """self-attention -> one cross-attention per image -> FFN, post-norm (reference :184-312)."""
+
+    def __init__(self, D, Nhead, Dff=2048, dropout=0.1, num_images=1, use_slotstates=False, use_egodeep=False):
+        super().__init__()
+        if use_slotstates or use_egodeep:
+            raise NotImplementedError("slot-state recurrence / decoder-side IMU attention are never "
+                                      "instantiated by the reference's runs/ (SURVEY.md 8a a24)")
+        self.self_attend = SlotToSlotAttention(D, Nhead, dropout)
+        self.norm_sa = nn.LayerNorm(D)
+        self.image_attend = nn.ModuleList([SlotToImageAttention(D, Nhead, dropout) for _ in range(num_images)])
+        self.norm_ia = nn.ModuleList([nn.LayerNorm(D) for _ in range(num_images)])
+        self.slotstates_attend = None
+        self.egodeep_attend = None
+        self.feedforward = nn.Sequential(nn.Linear(D, Dff), nn.ReLU(inplace=True), nn.Dropout(dropout),
+                                         nn.Linear(Dff, D))
+        self.norm_out = nn.LayerNorm(D)
+        self.Nhead, self.D = Nhead, D
+
+    def forward(self, x, qpos, query_sine, mems, mem_poss, is_first=False):
+        o = self.self_attend(x, qpos)
+        x = Fn.layer_norm(x, self.norm_sa.weight, self.norm_sa.bias, residual=o)
+        for i, (mem, mpos) in enumerate(zip(mems, mem_poss)):
+            o = self.image_attend[i](x, qpos, query_sine, mem, mpos, is_first)
+            x = Fn.layer_norm(x, self.norm_ia[i].weight, self.norm_ia[i].bias, residual=o)
+        h = _lin(x, self.feedforward[0], relu=True)
+        return Fn.layer_norm(x, self.norm_out.weight, self.norm_out.bias, residual=_lin(h, self.feedforward[3]))
+
+
+class TransformerDecoder(nn.Module):
+    """Reference transformer.py:315-398.  Returns (hs [layers,B,M,D], ref f32 [M,2])."""
+
+    def __init__(self, layers, norm=None, return_intermediate=False, D=256):
+        super().__init__()
+        self.layers = layers
+        for module in self.layers[1:]:          # only layer 0 adds the projected query positions
+            for att in module.image_attend:
+                att.query_pos.weight = None
+                att.query_pos.bias = None
+        self.norm = norm
+        self.return_intermediate = return_intermediate
+        self.D = D
+        self.query_scale = MLP(D, D, D, 2)
+        self.ref_point_head = MLP(D, D, 2, 2)
+        _reset_parameters(self.parameters())
+
+    def forward(self, x, qpos, mems, mem_poss, first_layer_special=True):
+        """x [B,M,D] query content; qpos [M,D] learned query positions (shared by the batch)."""
+        B, M, D = x.shape
+        ref, sine0 = Fn.RefPointSineFn.apply(self.ref_point_head(qpos), D)     # [M,2] f32, [M,D]
+        inter = []
+        for lid, layer in enumerate(self.layers):
+            special = lid == 0 and first_layer_special
+            if special:
+                q_sine = sine0
+            else:
+                q_sine = Fn.mul(self.query_scale(x).view(B * M, D), sine0, b_row_mod=M).view(B, M, D)
+            x = layer(x, qpos, q_sine, mems, mem_poss, is_first=special)
+            if self.return_intermediate:
+                inter.append(Fn.layer_norm(x, self.norm.weight, self.norm.bias))
+        if not self.return_intermediate:
+            y = Fn.layer_norm(x, self.norm.weight, self.norm.bias) if self.norm is not None else x
+            return y.unsqueeze(0), ref
+        return torch.stack(inter), ref
+
+
+class PackedMHA(nn.Module):
+    """Parameter holder with torch.nn.MultiheadAttention's names (in_proj_weight, in_proj_bias, out_proj)."""
+
+    def __init__(self, D):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * D, D))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * D))
+        self.out_proj = nn.Linear(D, D)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+
+class EncoderAttention(nn.Module):
+    """Post-norm self-attention + FFN block (reference transformer.py:401-419)."""
+
+    def __init__(self, Dsrc, num_heads, Dff, droprate=0.1):
+        super().__init__()
+        self.attn = PackedMHA(Dsrc)
+        self.norm1 = nn.LayerNorm(Dsrc)
+        self.mlp = nn.Sequential(nn.Linear(Dsrc, Dff), nn.ReLU(inplace=True), nn.Dropout(droprate),
+                                 nn.Linear(Dff, Dsrc), nn.Dropout(droprate))
+        self.norm2 = nn.LayerNorm(Dsrc)
+        self.D, self.H = Dsrc, num_heads
+
+    def forward(self, src, pos):
+        """src [F,N,D]; pos table [N,D].  q = k = src + pos, v = src."""
+        D = self.D
+        N = pos.shape[0]
+        w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
+        xp = Fn.add(src, pos, b_row_mod=N)
+        q = Fn.linear(xp, w[:D], b[:D])
+        k = Fn.linear(xp, w[D:2 * D], b[D:2 * D])
+        v = Fn.linear(src, w[2 * D:], b[2 * D:])
+        a = Fn.attention(q, k, v, 1.0 / math.sqrt(D // self.H))
+        src = Fn.layer_norm(src, self.norm1.weight, self.norm1.bias, residual=_lin(a, self.attn.out_proj))
+        h = _lin(src, self.mlp[0], relu=True)
+        return Fn.layer_norm(src, self.norm2.weight, self.norm2.bias, residual=_lin(h, self.mlp[3]))
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, D, Nhead, Dff=2048, droprate=0.1, num_previmages=0, use_prevout=False, use_egodeep=False):
+        super().__init__()
+        if num_previmages or use_prevout:
+            raise NotImplementedError("prevout / previmage encoder attention is only used by "
+                                      "JointEncoderSequential, which runs/ never builds (SURVEY.md 8a a24)")
+        self.self_attn = EncoderAttention(D, Nhead, Dff, droprate=droprate)
+        self.prevout_attn = None
+        self.previmage_attn = nn.ModuleList()
+        if use_egodeep:
+            self.egodeep_attend = EgodeepAttention(D, Nhead, droprate=droprate, Dff=Dff)
+            self.norm_eda = nn.LayerNorm(D)
+        else:
+            self.egodeep_attend = None
+
+    def forward(self, x, pos, egodeep: Optional[Tensor] = None):
+        """x [F,N,D]; pos table [N,D]; egodeep [F,D] (one IMU token per frame) or None."""
+        x = self.self_attn(x, pos)
+        if egodeep is not None and self.egodeep_attend is not None:
+            N = x.shape[1]
+            e = self.egodeep_attend.forward_single_key(egodeep)
+            x = Fn.layer_norm(x, self.norm_eda.weight, self.norm_eda.bias, residual=e, res_row_div=N)
+            if torch.is_grad_enabled():
+                x = Fn.ZeroGradAnchor.apply(x, *self.egodeep_attend.dead_parameters())
+        return x
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, layers):
+        super().__init__()
+        self.layers = layers
+        _reset_parameters(self.parameters())
+
+    def forward(self, x, pos, egodeep: Optional[Tensor] = None):
+        for layer in self.layers:
+            x = layer(x, pos, egodeep)
+        return x

@@ -1,0 +1,222 @@
+"""ResNet backbone (frozen-BN) + 1x1 input projection as ONE autograd node over the HIP conv kernels.
+
+Forward: f32 NCHW frames -> NHWC compute dtype -> implicit-GEMM convs with the frozen-BN scale
+folded into the prepared weights and shift/ReLU/residual fused in the epilogue -> [F, h, w, hidden].
+Backward: a hand-written reverse sweep (dgrad with the ReLU mask and the residual-branch gradient
+fused in its epilogue, wgrad into fp32 with atomics), stopping at the first trainable block
+because stem and layer1 are frozen (reference future_od/models/paper.py:102-109).
+
+Module/parameter names follow torchvision's ResNet so checkpoints load unchanged
+(SURVEY.md 8b): body.conv1, body.bn1, body.layer{1..4}.{i}.{conv,bn}{1,2,3}, downsample.{0,1}.
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import functional as Fn
+from . import ops
+
+RESNET_SPECS = {"resnet18": ("basic", (2, 2, 2, 2), 1),
+                "resnet34": ("basic", (3, 4, 6, 3), 1),
+                "resnet50": ("bottleneck", (3, 4, 6, 3), 4)}
+STAGE_WIDTH = (64, 128, 256, 512)
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """Constant affine y = x*scale + shift from buffers (never updated, never trained)."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+        self.eps = 1e-5
+
+    def _load_from_state_dict(self, state_dict, prefix, *a, **k):
+        state_dict.pop(prefix + "num_batches_tracked", None)
+        super()._load_from_state_dict(state_dict, prefix, *a, **k)
+
+    def scale_shift(self):
+        def make():
+            scale = self.weight * (self.running_var + self.eps).rsqrt()
+            return scale.contiguous(), (self.bias - self.running_mean * scale).contiguous()
+        key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version,
+               self.weight.data_ptr())
+        hit = getattr(self, "_ss", None)
+        if hit is None or hit[0] != key:
+            self._ss = (key, make())
+        return self._ss[1]
+
+
+class ConvWeight(nn.Module):
+    """Holds an OIHW conv weight (channels_last storage = the kernels' [Cout][kh][kw][Cin] order)."""
+
+    def __init__(self, cin, cout, k, stride, pad, bias=False):
+        super().__init__()
+        w = torch.empty(cout, cin, k, k)
+        nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")
+        self.weight = nn.Parameter(w.contiguous(memory_format=torch.channels_last))
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        self.k, self.stride, self.pad = k, stride, pad
+
+
+class _Block(nn.Module):
+    def __init__(self, kind, cin, width, stride, exp):
+        super().__init__()
+        self.kind = kind
+        if kind == "basic":
+            self.conv1, self.bn1 = ConvWeight(cin, width, 3, stride, 1), FrozenBatchNorm2d(width)
+            self.conv2, self.bn2 = ConvWeight(width, width, 3, 1, 1), FrozenBatchNorm2d(width)
+        else:
+            self.conv1, self.bn1 = ConvWeight(cin, width, 1, 1, 0), FrozenBatchNorm2d(width)
+            self.conv2, self.bn2 = ConvWeight(width, width, 3, stride, 1), FrozenBatchNorm2d(width)
+            self.conv3, self.bn3 = ConvWeight(width, width * 4, 1, 1, 0), FrozenBatchNorm2d(width * 4)
+        self.downsample = None
+        if stride != 1 or cin != width * exp:
+            self.downsample = nn.Sequential(ConvWeight(cin, width * exp, 1, stride, 0),
+                                            FrozenBatchNorm2d(width * exp))
+
+    def convs(self):
+        """[(ConvWeight, FrozenBN)] main path, then the downsample pair or None."""
+        main = [(self.conv1, self.bn1), (self.conv2, self.bn2)]
+        if self.kind != "basic":
+            main.append((self.conv3, self.bn3))
+        ds = (self.downsample[0], self.downsample[1]) if self.downsample is not None else None
+        return main, ds
+
+
+class ResNetBody(nn.Module):
+    """conv1/bn1/layer1..4 containers with torchvision's names (what IntermediateLayerGetter keeps)."""
+
+    def __init__(self, name):
+        super().__init__()
+        kind, depths, exp = RESNET_SPECS[name]
+        self.conv1, self.bn1 = ConvWeight(3, 64, 7, 2, 3), FrozenBatchNorm2d(64)
+        cin = 64
+        for s, (width, depth) in enumerate(zip(STAGE_WIDTH, depths)):
+            blocks = []
+            for i in range(depth):
+                blocks.append(_Block(kind, cin, width, 2 if (i == 0 and s > 0) else 1, exp))
+                cin = width * exp
+            setattr(self, f"layer{s + 1}", nn.Sequential(*blocks))
+        self.out_channels = cin
+
+    def blocks(self):
+        for s in range(4):
+            for blk in getattr(self, f"layer{s + 1}"):
+                yield s + 1, blk
+
+
+STEM_CIN_PAD = 8   # 3 input channels padded to one 16-byte bf16 chunk
+
+
+def _conv_fwd(x, cw, bn, dtype, relu, residual=None, cin_pad=None):
+    scale, shift = bn.scale_shift()
+    w = Fn.prep_conv(cw.weight, dtype, scale, False, cin_pad=cin_pad)
+    geom = ops.conv_geom(x.shape, cw.weight.shape[0], cw.k, cw.stride, cw.pad)
+    return ops.conv2d_fwd(x, w, geom, shift=shift, residual=residual, relu=relu), geom
+
+
+class BackboneFn(Function):
+    @staticmethod
+    def forward(ctx, video, body, proj, dtype, *train_weights):
+        """video f32 [B,L,3,H,W] (a strided view is fine) -> features NHWC [(l b), h, w, hidden];
+        train_weights = trainable conv weights in body.blocks() order, then proj.weight, proj.bias
+        (listed only so autograd routes their gradients)."""
+        x = ops.clip_to_nhwc_frame_major(video, dtype, STEM_CIN_PAD)
+        x, _ = _conv_fwd(x, body.conv1, body.bn1, dtype, relu=True, cin_pad=STEM_CIN_PAD)
+        x = ops.maxpool3x3s2(x)
+        tape = []
+        for stage, blk in body.blocks():
+            main, ds = blk.convs()
+            trainable = main[0][0].weight.requires_grad
+            idt = x
+            ds_geom = None
+            if ds is not None:
+                idt, ds_geom = _conv_fwd(x, ds[0], ds[1], dtype, relu=False)
+            acts, geoms = [x], []
+            h = x
+            for j, (cw, bn) in enumerate(main):
+                last = j == len(main) - 1
+                h, g = _conv_fwd(h, cw, bn, dtype, relu=True, residual=idt if last else None)
+                acts.append(h)
+                geoms.append(g)
+            if trainable:
+                tape.append((blk, acts, geoms, ds_geom))
+            x = h
+        geom_p = ops.conv_geom(x.shape, proj.weight.shape[0], 1, 1, 0)
+        wp = Fn.prep_conv(proj.weight, dtype, None, False)
+        feat = ops.conv2d_fwd(x, wp, geom_p, shift=proj.bias.detach())
+        ctx.body, ctx.proj, ctx.dtype = body, proj, dtype
+        ctx.tape, ctx.x_last, ctx.geom_p = tape, x, geom_p
+        ctx.train_weights = train_weights
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        dtype, proj = ctx.dtype, ctx.proj
+        dev = dfeat.device
+        g = dfeat.contiguous()
+        grads = {}
+
+        def wgrad(gy, xin, cw, geom, scale):
+            co, ci, kh, kw = cw.weight.shape
+            dw = torch.zeros((co, kh, kw, ci), dtype=torch.float32, device=dev)
+            ops.conv2d_wgrad_acc(gy, xin, dw, geom, row_scale=scale)
+            grads[id(cw.weight)] = dw.permute(0, 3, 1, 2)       # OIHW view, channels_last strides
+
+        if proj.weight.requires_grad:
+            wgrad(g, ctx.x_last, proj, ctx.geom_p, None)
+            db = torch.zeros(proj.weight.shape[0], dtype=torch.float32, device=dev)
+            ops.colsum_acc(g.view(-1, g.shape[-1]), db)
+            grads[id(proj.bias)] = db
+        tape = ctx.tape
+        if tape:
+            # gradient wrt the last block's output, gated by that ReLU (x_last = relu(...))
+            g = ops.conv2d_dgrad(g, Fn.prep_conv(proj.weight, dtype, None, True), ctx.geom_p, relu_mask=ctx.x_last)
+        for bi in range(len(tape) - 1, -1, -1):
+            blk, acts, geoms, ds_geom = tape[bi]
+            main, ds = blk.convs()
+            need_dx = bi > 0
+            g_out = g                                   # already masked by (block output > 0)
+            gcur = g_out
+            for j in range(len(main) - 1, -1, -1):
+                cw, bn = main[j]
+                scale, _ = bn.scale_shift()
+                wgrad(gcur, acts[j], cw, geoms[j], scale)
+                if j > 0:
+                    gcur = ops.conv2d_dgrad(gcur, Fn.prep_conv(cw.weight, dtype, scale, True), geoms[j],
+                                            relu_mask=acts[j])
+            if ds is not None:
+                wgrad(g_out, acts[0], ds[0], ds_geom, ds[1].scale_shift()[0])
+            if need_dx:
+                if ds is not None:
+                    sc = ds[1].scale_shift()[0]
+                    d_idt = ops.conv2d_dgrad(g_out, Fn.prep_conv(ds[0].weight, dtype, sc, True), ds_geom)
+                else:
+                    d_idt = g_out
+                cw, bn = main[0]
+                sc = bn.scale_shift()[0]
+                g = ops.conv2d_dgrad(gcur, Fn.prep_conv(cw.weight, dtype, sc, True), geoms[0],
+                                     residual=d_idt, relu_mask=acts[0])
+        ctx.tape = None
+        out = [None, None, None, None]
+        for w in ctx.train_weights:
+            out.append(grads.get(id(w)))
+        return tuple(out)
+
+
+def backbone_trainable(body, proj):
+    ws = []
+    for _stage, blk in body.blocks():
+        main, ds = blk.convs()
+        for cw, _bn in main + ([ds] if ds is not None else []):
+            if cw.weight.requires_grad:
+                ws.append(cw.weight)
+    ws += [proj.weight, proj.bias]
+    return ws
+
+
+def run_backbone(video, body, proj, dtype):
+    return BackboneFn.apply(video, body, proj, dtype, *backbone_trainable(body, proj))

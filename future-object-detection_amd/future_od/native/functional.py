@@ -1,0 +1,361 @@
+"""Autograd glue: each Function's forward and backward are calls into libfod_hip.so.
+
+Parameters stay fp32 `nn.Parameter`s with the reference's names and shapes; kernels consume
+prepared copies (cast to the compute dtype, transposed for input-gradients, BN scale folded for
+convs) that are cached per parameter version, so a copy is rebuilt only after an optimizer step.
+Activations and their gradients are in the compute dtype (torch.float32 = parity mode,
+torch.bfloat16 = performance mode); parameter gradients are fp32.
+"""
+import torch
+from torch.autograd import Function
+
+from . import lib as L
+from . import ops
+
+_VEC = {torch.float32: 4, torch.bfloat16: 8}
+
+
+# ------------------------------------------------------------------------------------------------
+# prepared-weight cache
+# ------------------------------------------------------------------------------------------------
+class _Prepared:
+    def __init__(self):
+        self._store = {}
+
+    def get(self, p, kind, dtype, make):
+        key = (p.data_ptr(), tuple(p.shape), tuple(p.stride()), kind, dtype)
+        ver = p._version
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        val = make()
+        self._store[key] = (ver, val)
+        return val
+
+    def clear(self):
+        self._store.clear()
+
+
+PREP = _Prepared()
+
+
+def _pad_to(n, v):
+    return (n + v - 1) // v * v
+
+
+def prep_linear(weight, dtype, transposed):
+    """weight [N,K] f32 -> [Np,K] (rows zero-padded to the vector width) or its transpose [K,Np]."""
+    N, K = weight.shape
+    v = _VEC[dtype]
+    assert K % v == 0, f"Linear in_features {K} must be a multiple of {v} (pad the input)"
+    Np = _pad_to(N, v)
+    w = weight.detach()
+
+    def make():
+        if not transposed:   # dst[1][n][k]
+            if Np == N:
+                return ops.permute3_cast(w, dtype, (1, N, K), (0, K, 1)).view(N, K)
+            out = torch.zeros((Np, K), dtype=dtype, device=w.device)
+            out[:N] = ops.permute3_cast(w, dtype, (1, N, K), (0, K, 1)).view(N, K)
+            return out
+        # dst[1][k][n] = w[n][k], columns n >= N zero
+        return ops.permute3_cast(w, dtype, (1, K, Np), (0, 1, K), valid2=N).view(K, Np)
+
+    return PREP.get(weight, "lin_t" if transposed else "lin", dtype, make)
+
+
+def prep_conv(weight, dtype, scale, transposed, cin_pad=None):
+    """OIHW f32 (any strides) -> [Cout][kh*kw][Cin_p] * scale[co]  or  [Cin][kh*kw][Cout] * scale[co]."""
+    co, ci, kh, kw = weight.shape
+    s_co, s_ci, s_kh, s_kw = weight.stride()
+    assert s_kh == kw * s_kw, "conv weight must have a contiguous tap plane"
+    cp = ci if cin_pad is None else cin_pad
+    w = weight.detach()
+
+    def make():
+        if not transposed:
+            return ops.permute3_cast(w, dtype, (co, kh * kw, cp), (s_co, s_kw, s_ci), valid2=ci,
+                                     scale=scale, scale_axis=0 if scale is not None else -1)
+        return ops.permute3_cast(w, dtype, (ci, kh * kw, co), (s_ci, s_kw, s_co),
+                                 scale=scale, scale_axis=2 if scale is not None else -1)
+
+    tag = ("conv_t" if transposed else "conv") + ("_s" if scale is not None else "")
+    return PREP.get(weight, tag, dtype, make)
+
+
+def cast(t, dtype, pad_cols=None):
+    """[rows, cols] tensor -> dtype, optionally zero-padding the last dim."""
+    cols = t.shape[-1]
+    rows = t.numel() // cols
+    t = t.contiguous()
+    pc = cols if pad_cols is None else pad_cols
+    return ops.permute3_cast(t, dtype, (1, rows, pc), (0, cols, 1), valid2=cols).view(*t.shape[:-1], pc)
+
+
+# ------------------------------------------------------------------------------------------------
+class LinearFn(Function):
+    """y = act(x W^T + b) (+ residual)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, out_f32):
+        dtype = x.dtype
+        w = prep_linear(weight, dtype, False)
+        N = weight.shape[0]
+        y = ops.gemm_nt(x, w[:N] if w.shape[0] != N else w, shift=bias, relu=relu, out_f32=out_f32)
+        y = y.view(*x.shape[:-1], N)
+        ctx.relu, ctx.out_f32 = relu, out_f32
+        ctx.weight = weight
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        weight = ctx.weight
+        dtype = x.dtype
+        N, K = weight.shape
+        v = _VEC[dtype]
+        Np = _pad_to(N, v)
+        dy = dy.contiguous()
+        if dy.dtype != dtype or Np != N:
+            g = cast(dy.view(-1, N), dtype, pad_cols=Np)
+        else:
+            g = dy.view(-1, N)
+        if ctx.relu:
+            assert Np == N
+            g = ops.eltwise(L.EW_RELU_MASK, g, y.view(-1, N))
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm_nt(g, prep_linear(weight, dtype, True)).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros((Np, K), dtype=torch.float32, device=x.device)
+            ops.gemm_tn_acc(g, x.view(-1, K), dwp)
+            dw = dwp[:N] if Np != N else dwp
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dbp = torch.zeros(Np, dtype=torch.float32, device=x.device)
+            ops.colsum_acc(g, dbp)
+            db = dbp[:N] if Np != N else dbp
+        return dx, dw, db, None, None
+
+
+def linear(x, weight, bias=None, relu=False, out_f32=False):
+    return LinearFn.apply(x.contiguous(), weight, bias, relu, out_f32)
+
+
+class AddFn(Function):
+    """a + b[row(m)], b broadcast over row groups (div) or periodically (mod)."""
+
+    @staticmethod
+    def forward(ctx, a, b, b_row_div, b_row_mod):
+        ctx.cfg = (b_row_div, b_row_mod, b.shape, a.shape)
+        return ops.eltwise(L.EW_ADD, a, b, b_row_div=b_row_div, b_row_mod=b_row_mod)
+
+    @staticmethod
+    def backward(ctx, g):
+        div, mod, bshape, ashape = ctx.cfg
+        g = g.contiguous()
+        db = None
+        if ctx.needs_input_grad[1]:
+            cols = ashape[-1]
+            rows = g.numel() // cols
+            if not div and not mod:
+                db = g.view(bshape)
+            elif mod and not div:
+                db = _sum_periodic(g.view(rows, cols), mod).view(bshape)
+            else:
+                assert not mod
+                out = torch.zeros((rows // div, cols), dtype=torch.float32, device=g.device)
+                ops.colsum_acc(g.view(rows, cols), out, group_rows=div)
+                db = cast(out, g.dtype).view(bshape)
+        return (g.view(ashape) if ctx.needs_input_grad[0] else None), db, None, None
+
+
+def add(a, b, b_row_div=0, b_row_mod=0):
+    return AddFn.apply(a.contiguous(), b.contiguous(), b_row_div, b_row_mod)
+
+
+class MulFn(Function):
+    """a * b[m % b_row_mod] (b broadcast periodically over the rows of a when b_row_mod > 0)."""
+
+    @staticmethod
+    def forward(ctx, a, b, b_row_mod):
+        ctx.save_for_backward(a, b)
+        ctx.mod = b_row_mod
+        return ops.eltwise(L.EW_MUL, a, b, b_row_mod=b_row_mod)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        da = ops.eltwise(L.EW_MUL, g, b, b_row_mod=ctx.mod)
+        db = ops.eltwise(L.EW_MUL, g, a)
+        if ctx.mod:
+            db = _sum_periodic(db, ctx.mod).view(b.shape)
+        return da, db, None
+
+
+def _sum_periodic(g, mod):
+    """[rows, cols] -> [mod, cols]: sum of the rows congruent modulo `mod` (rows/mod is tiny)."""
+    cols = g.shape[-1]
+    parts = g.view(-1, mod, cols)
+    acc = parts[0]
+    for i in range(1, parts.shape[0]):
+        acc = ops.eltwise(L.EW_ADD, acc.contiguous(), parts[i].contiguous())
+    return acc.contiguous()
+
+
+def mul(a, b, b_row_mod=0):
+    return MulFn.apply(a.contiguous(), b.contiguous(), b_row_mod)
+
+
+class ExpandRowsFn(Function):
+    """[rows, cols] -> [reps*rows, cols] (periodic copy); backward sums the copies."""
+
+    @staticmethod
+    def forward(ctx, x, reps):
+        rows, cols = x.shape
+        ctx.rows = rows
+        out = torch.empty((reps * rows, cols), dtype=x.dtype, device=x.device)
+        return ops.eltwise(L.EW_COPY_B, out, x, b_row_mod=rows, out=out)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _sum_periodic(g.contiguous(), ctx.rows), None
+
+
+def expand_rows(x, reps):
+    return ExpandRowsFn.apply(x.contiguous(), reps)
+
+
+class LayerNormFn(Function):
+    """LayerNorm(x + residual[row(m)]) over the last dim."""
+
+    @staticmethod
+    def forward(ctx, x, residual, gamma, beta, res_row_div):
+        y, s, mean, rstd = ops.layernorm_fwd(x, gamma, beta, residual=residual, res_row_div=res_row_div)
+        ctx.save_for_backward(s, mean, rstd, gamma)
+        ctx.res_row_div = res_row_div
+        ctx.res_shape = None if residual is None else residual.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        s, mean, rstd, gamma = ctx.saved_tensors
+        D = gamma.numel()
+        dg = torch.zeros(D, dtype=torch.float32, device=dy.device)
+        db = torch.zeros(D, dtype=torch.float32, device=dy.device)
+        dx = ops.layernorm_bwd(dy.contiguous(), s, mean, rstd, gamma, dg, db)
+        dres = None
+        if ctx.res_shape is not None and ctx.needs_input_grad[1]:
+            if ctx.res_row_div:
+                rows = dx.numel() // D
+                out = torch.zeros((rows // ctx.res_row_div, D), dtype=torch.float32, device=dy.device)
+                ops.colsum_acc(dx.view(rows, D), out, group_rows=ctx.res_row_div)
+                dres = cast(out, dx.dtype).view(ctx.res_shape)
+            else:
+                dres = dx.view(ctx.res_shape)
+        return dx, dres, dg, db, None
+
+
+def layer_norm(x, gamma, beta, residual=None, res_row_div=0):
+    return LayerNormFn.apply(x.contiguous(), None if residual is None else residual.contiguous(), gamma, beta,
+                             res_row_div)
+
+
+class AttentionFn(Function):
+    @staticmethod
+    def forward(ctx, q1, k1, v, q2, k2, scale):
+        o, lse2 = ops.attn_fwd(q1, k1, v, scale, q2, k2)
+        ctx.scale = scale
+        ctx.two = q2 is not None
+        ctx.save_for_backward(q1, k1, v, q2, k2, o, lse2)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q1, k1, v, q2, k2, o, lse2 = ctx.saved_tensors
+        dq1, dk1, dq2, dk2, dv = ops.attn_bwd(q1, k1, v, o, do.contiguous(), lse2, ctx.scale, q2, k2)
+        return dq1, dk1, dv, dq2, dk2, None
+
+
+def attention(q1, k1, v, scale, q2=None, k2=None):
+    c = lambda t: None if t is None else t.contiguous()
+    return AttentionFn.apply(c(q1), c(k1), c(v), c(q2), c(k2), scale)
+
+
+class RefPointSineFn(Function):
+    """ref_logit [R,2] -> (ref f32 [R,2] = sigmoid, sine [R,D] ordered (y | x))."""
+
+    @staticmethod
+    def forward(ctx, ref_logit, D):
+        ref, sine = ops.refpoint_sine_fwd(ref_logit, D)
+        ctx.save_for_backward(ref)
+        ctx.D, ctx.act_dtype = D, ref_logit.dtype
+        return ref, sine
+
+    @staticmethod
+    def backward(ctx, dref, dsine):
+        (ref,) = ctx.saved_tensors
+        if dsine is None:
+            dsine = torch.zeros((ref.shape[0], ctx.D), dtype=ctx.act_dtype, device=ref.device)
+        return ops.refpoint_sine_bwd(dsine.contiguous(), ref, None if dref is None else dref.contiguous()), None
+
+
+class BoxFinishFn(Function):
+    """boxes f32 [L,R,4] = sigmoid(t + [inverse_sigmoid(ref[r % ref_rows]), 0, 0])."""
+
+    @staticmethod
+    def forward(ctx, t, ref, levels):
+        boxes = ops.box_finish_fwd(t, ref, levels)
+        ctx.save_for_backward(boxes, ref)
+        ctx.act_dtype = t.dtype
+        ctx.t_shape = t.shape
+        return boxes
+
+    @staticmethod
+    def backward(ctx, dboxes):
+        boxes, ref = ctx.saved_tensors
+        dt_, dref = ops.box_finish_bwd(dboxes.contiguous(), boxes, ref, ctx.act_dtype)
+        return dt_.view(ctx.t_shape), dref, None
+
+
+class ZeroGradAnchor(Function):
+    """Identity on `x`; gives the listed parameters an explicit all-zero gradient.
+
+    Used for parameters whose gradient is identically zero by construction (projections that only
+    feed the logits of a softmax over ONE key): the reference materialises zeros for them, and an
+    optimizer with decoupled weight decay treats zero and None differently."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        ctx.shapes = [(p.shape, p.device) for p in params]
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g,) + tuple(torch.zeros(s, dtype=torch.float32, device=d) for s, d in ctx.shapes)
+
+
+class CastFn(Function):
+    """dtype conversion of a [*, cols] tensor with optional zero padding of the last dim; the gradient
+    is converted back (and un-padded)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype, pad_cols):
+        ctx.src_dtype, ctx.cols = x.dtype, x.shape[-1]
+        return cast(x, dtype, pad_cols)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        cols = g.shape[-1]
+        rows = g.numel() // cols
+        out = ops.permute3_cast(g, ctx.src_dtype, (1, rows, ctx.cols), (0, cols, 1))
+        return out.view(*g.shape[:-1], ctx.cols), None, None
+
+
+def cast_ad(x, dtype, pad_cols=None):
+    if x.dtype == dtype and pad_cols in (None, x.shape[-1]):
+        return x
+    return CastFn.apply(x.contiguous(), dtype, pad_cols)

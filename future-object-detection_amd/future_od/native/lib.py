@@ -11,7 +11,7 @@ LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libfod_hip.s
 ABI_VERSION = 1
 
 F32, BF16 = 0, 1
-EW_ADD, EW_MUL, EW_RELU_MASK, EW_SCALE, EW_ADD3, EW_RELU = range(6)
+EW_ADD, EW_MUL, EW_RELU_MASK, EW_SCALE, EW_ADD3, EW_RELU, EW_COPY_B = range(7)
 
 
 class FodError(RuntimeError):
@@ -51,7 +51,7 @@ SIGNATURES = {
     "fod_conv2d_dgrad": [_i, _p, _p, _p, _CG, _EP, _p],
     "fod_conv2d_wgrad_acc": [_i, _p, _p, _p, _CG, _p, _p],
     "fod_maxpool3x3s2": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _p],
-    "fod_nchw_to_nhwc": [_i, _p, _p, _i, _i, _i, _i, _i, _p],
+    "fod_nchw_to_nhwc": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _p],
     "fod_permute3_cast": [_i, _i, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _i, _p],
     "fod_attn_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _AS, _p],
     "fod_attn_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _AS, _p],
@@ -62,8 +62,8 @@ SIGNATURES = {
     "fod_posenc_temporal": [_i, _p, _p, _i, _i, _i, _f, _f, _p],
     "fod_refpoint_sine_fwd": [_i, _p, _p, _p, _i, _i, _p],
     "fod_refpoint_sine_bwd": [_i, _p, _p, _p, _p, _i, _i, _p],
-    "fod_box_finish_fwd": [_i, _p, _p, _p, _i, _i, _p],
-    "fod_box_finish_bwd": [_i, _p, _p, _p, _p, _p, _i, _i, _p],
+    "fod_box_finish_fwd": [_i, _p, _p, _p, _i, _i, _i, _p],
+    "fod_box_finish_bwd": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "fod_match_cost": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _p],
     "fod_lap_solve_batch_host": [_p, _i, _i, _i, _p, _p, _i],
     "fod_set_loss_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],

@@ -166,7 +166,19 @@ def nchw_to_nhwc(video, dtype, cpad):
     _chk(video, "video", torch.float32)
     f, c, h, w = video.shape
     out = torch.empty((f, h, w, cpad), dtype=dtype, device=video.device)
-    call("fod_nchw_to_nhwc", _DT[dtype], ptr(video), ptr(out), f, c, h, w, cpad, stream())
+    call("fod_nchw_to_nhwc", _DT[dtype], ptr(video), ptr(out), f, c, h, w, cpad, 1, c * h * w, 0, stream())
+    return out
+
+
+def clip_to_nhwc_frame_major(video, dtype, cpad):
+    """f32 [B,L,C,H,W] (a view whose frame planes are contiguous) -> dtype [L*B,H,W,cpad] ordered (l, b)."""
+    if not video.is_cuda or video.dtype != torch.float32:
+        raise L.FodError("video must be a float32 device tensor")
+    b, l, c, h, w = video.shape
+    sb, sl, sc, sh, sw = video.stride()
+    assert (sc, sh, sw) == (h * w, w, 1), f"frame planes must be contiguous, got strides {video.stride()}"
+    out = torch.empty((l * b, h, w, cpad), dtype=dtype, device=video.device)
+    call("fod_nchw_to_nhwc", _DT[dtype], ptr(video), ptr(out), l * b, c, h, w, cpad, b, sl, sb, stream())
     return out
 
 
@@ -324,22 +336,26 @@ def refpoint_sine_bwd(dsine, ref, dref_extra):
 
 
 def box_finish_fwd(t, ref, levels):
+    """t [levels, R, 4]; ref f32 [ref_rows, 2] with R % ref_rows == 0 (row r uses ref[r % ref_rows])."""
     _chk(t, "t"); _chk(ref, "ref", torch.float32)
-    R = ref.shape[0]
-    assert t.numel() == levels * R * 4
+    ref_rows = ref.shape[0]
+    assert t.numel() % (levels * 4) == 0
+    R = t.numel() // (levels * 4)
+    assert R % ref_rows == 0 and ref.shape == (ref_rows, 2)
     boxes = torch.empty((levels, R, 4), dtype=torch.float32, device=t.device)
-    call("fod_box_finish_fwd", dt(t), ptr(t), ptr(ref), ptr(boxes), levels, R, stream())
+    call("fod_box_finish_fwd", dt(t), ptr(t), ptr(ref), ptr(boxes), levels, R, ref_rows, stream())
     return boxes
 
 
 def box_finish_bwd(dboxes, boxes, ref, act_dtype):
     _chk(dboxes, "dboxes", torch.float32); _chk(boxes, "boxes", torch.float32)
     levels, R, _ = boxes.shape
-    assert dboxes.shape == boxes.shape and ref.shape == (R, 2)
+    ref_rows = ref.shape[0]
+    assert dboxes.shape == boxes.shape and ref.shape == (ref_rows, 2) and R % ref_rows == 0
     dt_ = torch.empty((levels, R, 4), dtype=act_dtype, device=boxes.device)
-    dref = torch.zeros((R, 2), dtype=torch.float32, device=boxes.device)
+    dref = torch.zeros((ref_rows, 2), dtype=torch.float32, device=boxes.device)
     call("fod_box_finish_bwd", _DT[act_dtype], ptr(dboxes), ptr(boxes), ptr(ref), ptr(dt_), ptr(dref),
-         levels, R, stream())
+         levels, R, ref_rows, stream())
     return dt_, dref
 
 

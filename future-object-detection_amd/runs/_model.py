@@ -1,0 +1,58 @@
+"""`build_model(args, detr_args)`: the architecture the reference ships (reference runs/_model.py:14-83:
+ResNet-50, IMU-token encoder, 2-image conditional decoder, spatial-only positional encoding), built
+from the HIP-backed modules.  Extra knobs are read from `args` if present and default to the
+reference's literals, so the reference's run scripts work unchanged:
+
+    args.compute_dtype : "bf16" (default) | "fp32"      -- arithmetic mode of the kernels
+    args.num_images    : decoder cross-attention blocks (reference literal: 2)
+    args.backbone      : "resnet50" (reference literal) | "resnet18" | "resnet34"
+    args.skip_dead_frames : True (default) -- do not compute frames that cannot reach the output
+"""
+import torch
+import torch.nn as nn
+
+import future_od.models.transformer as transformer
+from future_od.models.paper import (CDetrBackbone, CDetrDetectorSpatioTemporal, FuturePredCore,
+                                    PositionalEncoder, SeparateEncoder)
+from future_od.models.st_detr import SpatioTemporalDETR, SpatioTemporalDETRArgs
+from future_od.native import functional as Fn
+from future_od.parallel import FodDataParallel
+
+_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32,
+           torch.bfloat16: torch.bfloat16, torch.float32: torch.float32}
+
+
+def build_model(args, detr_args: SpatioTemporalDETRArgs):
+    Fn.PREP.clear()
+    num_images = getattr(args, "num_images", 2)
+    core = FuturePredCore(
+        separate_encoder=SeparateEncoder(
+            backbone=CDetrBackbone(name=getattr(args, "backbone", "resnet50"),
+                                   train_backbone=detr_args.lr_backbone > 0, dilation=False,
+                                   hidden_dim=detr_args.hidden_dim, pretrained=detr_args.pretrained_backbone),
+            imu_layers=nn.Sequential(nn.Linear(14, 128), nn.ReLU(inplace=True),
+                                     nn.Linear(128, detr_args.hidden_dim)),
+            transformer=transformer.TransformerEncoder(layers=nn.ModuleList(
+                transformer.TransformerEncoderLayer(D=detr_args.hidden_dim, Nhead=detr_args.enc_nheads,
+                                                    Dff=detr_args.dim_feedforward, use_egodeep=True)
+                for _ in range(detr_args.enc_layers)))),
+        joint_encoder=None,
+        detector=CDetrDetectorSpatioTemporal(
+            decoder=transformer.TransformerDecoder(
+                layers=nn.ModuleList([
+                    transformer.TransformerDecoderLayer(D=detr_args.hidden_dim, Nhead=detr_args.nheads,
+                                                        Dff=detr_args.dim_feedforward, dropout=0.1,
+                                                        num_images=num_images, use_slotstates=False)
+                    for _ in range(detr_args.dec_layers)]),
+                norm=nn.LayerNorm(detr_args.hidden_dim), return_intermediate=True, D=detr_args.hidden_dim),
+            num_classes=detr_args.num_classes, hidden_dim=detr_args.hidden_dim,
+            first_layer_special_when="always", num_queries=detr_args.num_queries, aux_loss=True,
+            image_memory_mode="attend one at a time"),
+        pos_encoder=PositionalEncoder(no_temporal=True))
+    core.compute_dtype = _DTYPES[getattr(args, "compute_dtype", "bf16")]
+    core.skip_dead_frames = bool(getattr(args, "skip_dead_frames", True))
+    model = SpatioTemporalDETR(args=detr_args, model=core)
+    model.to(args.device)
+    if getattr(args, "distributed", False):
+        model = FodDataParallel(model, device=args.device)
+    return model

@@ -94,10 +94,11 @@ int fod_conv2d_wgrad_acc(int dtype, const void* dy, const void* x, float* dw, co
 int fod_maxpool3x3s2(int dtype, const void* x, void* y, int Nimg, int H, int W, int C, int Ho, int Wo,
                      fod_stream_t stream);
 
-/* video f32 NCHW [F,C,H,W] -> dtype NHWC [F,H,W,Cp], channels C..Cp-1 zero.  The one read of the
- * [B,T,3,H,W] frame tensor (future_od/models/paper.py:146). */
-int fod_nchw_to_nhwc(int dtype, const float* src, void* dst, int F, int C, int H, int W, int Cp,
-                     fod_stream_t stream);
+/* video f32 NCHW -> dtype NHWC [F,H,W,Cp], channels C..Cp-1 zero.  Output frame f is read from
+ * src + (f / inner)*stride_outer + (f % inner)*stride_inner (elements), so a [B,T,3,H,W] clip can be
+ * folded frame-major without a copy.  The one read of the frame tensor (future_od/models/paper.py:146). */
+int fod_nchw_to_nhwc(int dtype, const float* src, void* dst, int F, int C, int H, int W, int Cp, int inner,
+                     long stride_outer, long stride_inner, fod_stream_t stream);
 
 /* dst[i0][i1][i2] = src[i0*s0 + i1*s1 + i2*s2] * scale[index on scale_axis]   (i2 >= valid2 -> 0)
  * src_dtype/dst_dtype independent.  Weight preparation (cast, transpose, BN-scale fold, channel pad)
@@ -145,7 +146,8 @@ enum {
   FOD_EW_RELU_MASK = 2, /* out = b[m] > 0 ? a : 0         */
   FOD_EW_SCALE = 3,     /* out = alpha * a                */
   FOD_EW_ADD3 = 4,      /* out = a + b[row(m)] + c        */
-  FOD_EW_RELU = 5       /* out = max(a, 0)                */
+  FOD_EW_RELU = 5,      /* out = max(a, 0)                */
+  FOD_EW_COPY_B = 6     /* out = b[row(m)]  (row broadcast; a only gives the shape) */
 };
 /* [rows, cols] contiguous element-wise helpers; row(m) as in fod_layernorm_fwd. */
 int fod_eltwise(int op, int dtype, void* out, const void* a, const void* b, const void* c, long rows,
@@ -166,12 +168,13 @@ int fod_refpoint_sine_fwd(int dtype, const void* ref_logit, float* ref, void* si
 int fod_refpoint_sine_bwd(int dtype, const void* dsine, const float* ref, const float* dref_extra,
                           void* dref_logit, int R, int D, fod_stream_t stream);
 
-/* boxes[l, r, :] = sigmoid(t[l, r, :] + [inverse_sigmoid(ref[r]), 0, 0])  f32 out  (paper.py:406-413) */
+/* boxes[l, r, :] = sigmoid(t[l, r, :] + [inverse_sigmoid(ref[r % ref_rows]), 0, 0])  f32 out
+ * (paper.py:406-413; the reference points are the same for every batch element) */
 int fod_box_finish_fwd(int dtype, const void* t, const float* ref, float* boxes, int levels, int R,
-                       fod_stream_t stream);
-/* dt (dtype) from dboxes (f32); dref f32 [R,2] += sum over levels */
+                       int ref_rows, fod_stream_t stream);
+/* dt (dtype) from dboxes (f32); dref f32 [ref_rows,2] += sum over levels and rows sharing the point */
 int fod_box_finish_bwd(int dtype, const float* dboxes, const float* boxes, const float* ref, void* dt,
-                       float* dref, int levels, int R, fod_stream_t stream);
+                       float* dref, int levels, int R, int ref_rows, fod_stream_t stream);
 
 /* Matching cost (ConditionalDETR HungarianMatcher, called at set_criterion.py:182,204):
  *   cost[l, b, m, j] = w_bbox*L1 + w_class*focal_cost + w_giou*(-GIoU), target j of sample b.
