@@ -11,6 +11,7 @@ into the product model.
 Citations are to /root/reference/<path>:<line>.
 """
 import math
+import re
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -179,6 +180,12 @@ def make_state_dict(cfg: Config, seed: int = 0, dtype=torch.float32) -> Dict[str
         if kind == "buffer":
             if leaf == "weight":
                 t = 0.5 + torch.rand(shape, generator=g)
+                # damp the residual branch (last BN of every block) so activations stay O(1..10)
+                # through 16 randomly initialised blocks; un-damped they reach 1e4 and the encoder's
+                # softmax saturates, which makes gradient comparisons ill-conditioned
+                if re.search(r"layer\d\.\d+\.(bn3|bn2)\.weight$", name) and (
+                        ".bn3." in name or cfg.backbone in ("resnet18", "resnet34")):
+                    t = t * 0.25
             elif leaf == "running_var":
                 t = 0.5 + torch.rand(shape, generator=g)
             else:
