@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frame-sequences/s, forward + backward, T=6, 900x1600, B=2 per GPU, bf16.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one synthetic batch: model(data) (backbone, encoder,
+decoder, matcher + set loss, post-processing / AP bookkeeping, exactly the reference's forward,
+future_od/models/st_detr.py:98-167) + loss.backward() (+ the gradient all-reduce when N > 1) +
+gradient clipping and the AdamW update (reference future_od/trainer.py:171-189).  Inputs are resident in
+HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "future-object-detection_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch                                                        # noqa: E402
+import torch.distributed as dist                                    # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+T_FRAMES, HEIGHT, WIDTH, BATCH_PER_GPU = 6, 900, 1600, 2
+
+
+def live_flops_per_sequence(num_images):
+    """Algorithmic FLOPs of one frame-sequence, forward + backward, live work only (SURVEY.md 8d table:
+    900x1600, T=6; K=2 -> 1.638 TFLOP, K=5 -> 4.082 TFLOP)."""
+    return {2: 1.638e12, 5: 4.082e12}.get(num_images)
+
+
+def build(args, device, distributed, num_images, dtype="bf16"):
+    from types import SimpleNamespace
+    from future_od.models.st_detr import SpatioTemporalDETRArgs
+    from runs._model import build_model
+    torch.manual_seed(0)
+    a = SimpleNamespace(device=device, distributed=distributed, compute_dtype=dtype, num_images=num_images)
+    detr = SpatioTemporalDETRArgs(num_classes=8, num_queries=128, lr_backbone=1e-4, pretrained_backbone=False)
+    return build_model(a, detr), detr
+
+
+def cpu_baseline(num_images, cores):
+    """The oracle (plain-PyTorch fp32 restatement of the reference graph) on this box's host cores:
+    ONE frame-sequence (B=1), forward + backward, same shapes.  Checker code used as the baseline leg
+    only; it is never on the product path."""
+    from future_od.datasets.synthetic import make_batch
+    from oracle import criterion as ocrit
+    from oracle import stdetr as O
+    torch.set_num_threads(cores)
+    cfg = O.Config(num_images=num_images)
+    sd = O.make_state_dict(cfg, 0)
+    for k, (_, kind) in O.param_spec(cfg).items():
+        if kind == "param":
+            sd[k].requires_grad_(True)
+    data = make_batch(1, T_FRAMES, HEIGHT, WIDTH, seed=1, max_boxes=40)
+    t0 = time.perf_counter()
+    out = O.core_forward(sd, cfg, data["video"], O.imu_from_data(data), skip_dead=True)
+    loss, _, _ = ocrit.total_loss(cfg, out, data)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "frame-sequences/s", "cores": cores, "kind": "port",
+            "sample": f"1 frame-sequence (B=1, T={T_FRAMES}, {HEIGHT}x{WIDTH}, num_images={num_images}), fp32, "
+                      f"forward+backward incl. set loss, live frames only, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--num-images", type=int, default=5, help="decoder cross-attention blocks K (5 = all past frames live)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dtype", default="bf16")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", init_method="env://")
+    assert world == a.gpus or not distributed, (world, a.gpus)
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    from future_od.datasets.synthetic import make_batch
+    from future_od.native import lib as L
+    from future_od.optim import FusedAdamW
+
+    model, detr = build(a, device, distributed, a.num_images, a.dtype)
+    model.train()
+    opt = FusedAdamW(model.parameters(), lr=detr.lr, weight_decay=detr.weight_decay, max_norm=detr.max_norm)
+    data = make_batch(BATCH_PER_GPU, T_FRAMES, HEIGHT, WIDTH, seed=1234 + rank, device=device)
+
+    def step():
+        opt.zero_grad()
+        out, _state, loss, stats, od = model(data=data, distributed=distributed)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=device)
+    if distributed:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    seqs = BATCH_PER_GPU * world * a.steps
+    value = seqs / dt
+
+    result = {
+        "metric": "frame-sequences/sec fwd+bwd, T=6 900x1600", "value": value, "unit": "frame-sequences/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": f"spatiotemporal ConditionalDETR (ResNet-50, 6 enc + 6 dec layers, 128 queries), "
+                               f"T={T_FRAMES} frames {HEIGHT}x{WIDTH}, batch {BATCH_PER_GPU}/GPU, "
+                               f"num_images K={a.num_images} ({a.num_images} past frames live), random-init weights; "
+                               f"step = forward (incl. Hungarian set loss, post-proc, AP bookkeeping) + backward + "
+                               f"clip + AdamW",
+                   "global_batch": BATCH_PER_GPU * world, "frames": T_FRAMES, "resolution": [HEIGHT, WIDTH],
+                   "num_images": a.num_images, "parallelism": f"dp{world}"},
+        "final_loss": float(loss.detach()),
+    }
+    fl = live_flops_per_sequence(a.num_images)
+    if fl:
+        result["model_tflops_per_gpu"] = fl * BATCH_PER_GPU * a.steps / dt / 1e12
+        result["model_frac_of_bf16_peak"] = result["model_tflops_per_gpu"] / PEAK_BF16_TFLOPS
+
+    if rank == 0 and not a.no_roofline:
+        # dominant kernel: time every entry point with events on the launching stream for a few more steps
+        L.PROFILER.start()
+        nprof = 2
+        for _ in range(nprof):
+            step()
+        L.PROFILER.stop()
+        summ = L.PROFILER.summary()
+        total = sum(v["seconds"] for v in summ.values())
+        top = sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])
+        name, rec = top[0]
+        achieved = rec["work"] / rec["seconds"] / 1e12
+        result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
+                              "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                              "avg_launch_us": 1e6 * rec["seconds"] / rec["calls"], "launches_per_step": rec["calls"] / nprof,
+                              "share_of_device_time": rec["seconds"] / total}
+        result["kernel_breakdown"] = {k: {"ms_per_step": 1e3 * v["seconds"] / nprof, "calls_per_step": v["calls"] / nprof,
+                                          "tflops": (v["work"] / v["seconds"] / 1e12) if v["work"] else None}
+                                      for k, v in top[:12]}
+    if distributed:
+        dist.barrier()
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(a.num_images, min(os.cpu_count() or 1, 64))
+    if rank == 0:
+        print(json.dumps(result))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,56 +1,84 @@
-// Fused AdamW + global-norm clipping over flat f32 spans (torch.optim.AdamW / clip_grad_norm_
-// semantics; reference future_od/trainer.py:186-188, runs/_helper.py:84-107).  HBM-bound: one read
-// of p, g, m, v and one write of p, m, v per step.
+// Global-norm gradient clipping + AdamW over MANY parameter tensors in two launches (a table of
+// pointers instead of one launch per tensor): torch.optim.AdamW / clip_grad_norm_ semantics, reference
+// future_od/trainer.py:186-188 and runs/_helper.py:84-107.  HBM-bound: reads p, g, m, v once, writes
+// p, m, v once.  Every tensor is processed as its dense storage order, so parameter, gradient and both
+// moments must share one memory layout (the host wrapper checks).
 #include "common.h"
 
 namespace {
 
-__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                             float* __restrict__ v, long n, float lr, float b1, float b2, float eps, float wd,
-                             float bc1, float bc2, const float* __restrict__ clip) {
-  const float cs = clip ? *clip : 1.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float gr = g[i] * cs;
-    float pv = p[i] * (1.f - lr * wd);
-    const float mv = b1 * m[i] + (1.f - b1) * gr;
-    const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
-    m[i] = mv;
-    v[i] = vv;
-    const float denom = sqrtf(vv) / sqrtf(bc2) + eps;
-    pv -= (lr / bc1) * (mv / denom);
-    p[i] = pv;
-  }
-}
+constexpr int CHUNK = 65536;   // elements per block
 
-__global__ void sqnorm_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+struct Slot {
+  long n;
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  float lr, wd;
+};
+
+__global__ __launch_bounds__(256) void multi_sqnorm_kernel(const long* __restrict__ ptrs, const long* __restrict__ numel,
+                                                           const int* __restrict__ blk_tensor,
+                                                           const int* __restrict__ blk_chunk, float* __restrict__ out) {
   __shared__ float red[4];
+  const int t = blk_tensor[blockIdx.x];
+  const long base = (long)blk_chunk[blockIdx.x] * CHUNK;
+  const long end = min(numel[t], base + CHUNK);
+  const float* g = reinterpret_cast<const float*>(ptrs[t * 4 + 1]);
   float s = 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += g[i] * g[i];
+  for (long i = base + threadIdx.x; i < end; i += 256) s += g[i] * g[i];
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+__global__ __launch_bounds__(256) void multi_adamw_kernel(const long* __restrict__ ptrs, const long* __restrict__ numel,
+                                                          const float* __restrict__ lr_wd,
+                                                          const int* __restrict__ blk_tensor,
+                                                          const int* __restrict__ blk_chunk, float b1, float b2,
+                                                          float eps, float bc1, float bc2,
+                                                          const float* __restrict__ sqnorm, float max_norm) {
+  const int t = blk_tensor[blockIdx.x];
+  const long base = (long)blk_chunk[blockIdx.x] * CHUNK;
+  const long end = min(numel[t], base + CHUNK);
+  float* p = reinterpret_cast<float*>(ptrs[t * 4 + 0]);
+  const float* g = reinterpret_cast<const float*>(ptrs[t * 4 + 1]);
+  float* m = reinterpret_cast<float*>(ptrs[t * 4 + 2]);
+  float* v = reinterpret_cast<float*>(ptrs[t * 4 + 3]);
+  const float lr = lr_wd[t * 2], wd = lr_wd[t * 2 + 1];
+  float cs = 1.f;
+  if (max_norm > 0.f && sqnorm) cs = fminf(1.f, max_norm / (sqrtf(*sqnorm) + 1e-6f));   // clip_grad_norm_
+  const float step = lr / bc1, rs2 = 1.f / sqrtf(bc2);
+  for (long i = base + threadIdx.x; i < end; i += 256) {
+    const float gr = g[i] * cs;
+    const float mv = b1 * m[i] + (1.f - b1) * gr;
+    const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mv;
+    v[i] = vv;
+    p[i] = p[i] * (1.f - lr * wd) - step * (mv / (sqrtf(vv) * rs2 + eps));
+  }
+}
+
 }  // namespace
 
-extern "C" int fod_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
-                              float beta1, float beta2, float eps, float weight_decay, float bias_c1, float bias_c2,
-                              const float* clip_coef, hipStream_t stream) {
-  FOD_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0, "adamw: bad args");
-  long blocks = (n + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adamw_kernel, dim3((int)blocks), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, n, lr,
-                     beta1, beta2, eps, weight_decay, bias_c1, bias_c2, clip_coef);
+extern "C" int fod_multi_sqnorm_acc(const long* ptrs, const long* numel, const int* blk_tensor, const int* blk_chunk,
+                                    int nblocks, float* out, hipStream_t stream) {
+  FOD_REQUIRE(ptrs && numel && blk_tensor && blk_chunk && out && nblocks > 0, "multi_sqnorm: bad args");
+  hipLaunchKernelGGL(multi_sqnorm_kernel, dim3(nblocks), dim3(256), 0, stream, ptrs, numel, blk_tensor, blk_chunk, out);
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }
 
-extern "C" int fod_grad_sqnorm_acc(const float* grad, long n, float* out, hipStream_t stream) {
-  FOD_REQUIRE(grad && out && n > 0, "grad_sqnorm: bad args");
-  long blocks = (n + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3((int)blocks), dim3(256), 0, stream, grad, n, out);
+extern "C" int fod_multi_adamw(const long* ptrs, const long* numel, const float* lr_wd, const int* blk_tensor,
+                               const int* blk_chunk, int nblocks, float beta1, float beta2, float eps, float bias_c1,
+                               float bias_c2, const float* sqnorm, float max_norm, hipStream_t stream) {
+  FOD_REQUIRE(ptrs && numel && lr_wd && blk_tensor && blk_chunk && nblocks > 0, "multi_adamw: bad args");
+  hipLaunchKernelGGL(multi_adamw_kernel, dim3(nblocks), dim3(256), 0, stream, ptrs, numel, lr_wd, blk_tensor,
+                     blk_chunk, beta1, beta2, eps, bias_c1, bias_c2, sqnorm, max_norm);
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }
+
+extern "C" int fod_multi_chunk(void) { return CHUNK; }

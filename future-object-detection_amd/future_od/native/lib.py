@@ -70,10 +70,10 @@ SIGNATURES = {
     "fod_set_loss_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "fod_od_map": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p],
     "fod_post_proc": [_p, _p, _p, _p, _i, _i, _f, _f, _p],
-    "fod_adamw_step": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _f, _p, _p],
-    "fod_grad_sqnorm_acc": [_p, _l, _p, _p],
+    "fod_multi_sqnorm_acc": [_p, _p, _p, _p, _i, _p, _p],
+    "fod_multi_adamw": [_p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p, _f, _p],
 }
-EXPORTS = sorted(list(SIGNATURES) + ["fod_last_error", "fod_abi_version"])
+EXPORTS = sorted(list(SIGNATURES) + ["fod_last_error", "fod_abi_version", "fod_multi_chunk"])
 
 
 def _load():
@@ -108,3 +108,47 @@ def call(name, *args):
     rc = getattr(LIB, name)(*args)
     if rc != 0:
         raise FodError(f"{name} failed ({rc}): {last_error()}")
+
+
+class Profiler:
+    """Optional per-entry-point timing with events on the launching stream (bench.py's roofline leg).
+
+    Disabled (the default) it costs one attribute test per call."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []          # (name, work, start_event, end_event)
+        self.pending_work = 0.0
+
+    def start(self):
+        self.enabled = True
+        self.records = []
+
+    def stop(self):
+        self.enabled = False
+
+    def summary(self):
+        import torch
+        torch.cuda.synchronize()
+        agg = {}
+        for name, work, e0, e1 in self.records:
+            a = agg.setdefault(name, [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += e0.elapsed_time(e1) * 1e-3
+            a[2] += work
+        return {k: {"calls": v[0], "seconds": v[1], "work": v[2]} for k, v in agg.items()}
+
+
+PROFILER = Profiler()
+_plain_call = call
+
+
+def call(name, *args, work=0.0, tag=None):   # noqa: F811  (profiling wrapper around the plain call)
+    if not PROFILER.enabled:
+        return _plain_call(name, *args)
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _plain_call(name, *args)
+    e1.record()
+    PROFILER.records.append((tag or name, work, e0, e1))

@@ -7,7 +7,11 @@ import math
 import torch
 
 from . import lib as L
-from .lib import F32, BF16, AttnShape, ConvGeom, Epilogue, call
+from .lib import F32, BF16, AttnShape, ConvGeom, Epilogue
+
+
+def call(name, *args, **kw):
+    return L.call(name, *args, **kw)
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -77,7 +81,8 @@ def gemm_nt(a, b, *, a_row_mod=0, m_rows=None, scale=None, shift=None, residual=
     else:
         _chk(out, "out"); assert out.numel() == M * N
     call("fod_gemm_nt", dt(a), ptr(a), K, a_row_mod, ptr(b), K, ptr(out), N, M, N, K,
-         _epi(scale, shift, residual, N, residual_row_mod, relu_mask, N, relu, out_f32), stream())
+         _epi(scale, shift, residual, N, residual_row_mod, relu_mask, N, relu, out_f32), stream(),
+         work=2.0 * M * N * K)
     return out
 
 
@@ -89,7 +94,8 @@ def gemm_tn_acc(g, x, dw, row_scale=None):
     assert x.numel() // K2 == M and dw.numel() == N1 * K2, (g.shape, x.shape, dw.shape)
     if row_scale is not None:
         _chk(row_scale, "row_scale", torch.float32); assert row_scale.numel() == N1
-    call("fod_gemm_tn_acc", dt(g), ptr(g), N1, ptr(x), K2, ptr(dw), K2, M, N1, K2, ptr(row_scale), stream())
+    call("fod_gemm_tn_acc", dt(g), ptr(g), N1, ptr(x), K2, ptr(dw), K2, M, N1, K2, ptr(row_scale), stream(),
+         work=2.0 * M * N1 * K2)
     return dw
 
 
@@ -111,6 +117,11 @@ def conv_geom(x_shape, cout, k, stride, pad):
     return ConvGeom(n, h, w, cin, ho, wo, cout, k, k, stride, pad)
 
 
+def _conv_flops(g):
+    """Algorithmic FLOPs of one conv pass: 2 * output pixels * Cout * kh*kw*Cin (same for dgrad, wgrad)."""
+    return 2.0 * g.Nimg * g.Ho * g.Wo * g.Cout * g.kh * g.kw * g.Cin
+
+
 def conv2d_fwd(x, w, geom, *, scale=None, shift=None, residual=None, relu=False):
     """x NHWC, w [Cout, kh, kw, Cin] (same dtype) -> y NHWC."""
     _chk(x, "x"); _chk(w, "w", x.dtype)
@@ -123,7 +134,7 @@ def conv2d_fwd(x, w, geom, *, scale=None, shift=None, residual=None, relu=False)
     if residual is not None:
         _chk(residual, "residual", x.dtype); assert residual.shape == y.shape
     call("fod_conv2d_fwd", dt(x), ptr(x), ptr(w), ptr(y), C.byref(geom),
-         _epi(scale, shift, residual, geom.Cout, 0, None, 0, relu), stream())
+         _epi(scale, shift, residual, geom.Cout, 0, None, 0, relu), stream(), work=_conv_flops(geom))
     return y
 
 
@@ -137,7 +148,7 @@ def conv2d_dgrad(dy, w_t, geom, *, residual=None, relu_mask=None):
         if v is not None:
             _chk(v, "residual/mask", dy.dtype); assert v.shape == dx.shape
     call("fod_conv2d_dgrad", dt(dy), ptr(dy), ptr(w_t), ptr(dx), C.byref(geom),
-         _epi(None, None, residual, geom.Cin, 0, relu_mask, geom.Cin, False), stream())
+         _epi(None, None, residual, geom.Cin, 0, relu_mask, geom.Cin, False), stream(), work=_conv_flops(geom))
     return dx
 
 
@@ -148,7 +159,8 @@ def conv2d_wgrad_acc(dy, x, dw, geom, row_scale=None):
     assert dw.numel() == geom.Cout * geom.kh * geom.kw * geom.Cin
     if row_scale is not None:
         _chk(row_scale, "row_scale", torch.float32); assert row_scale.numel() == geom.Cout
-    call("fod_conv2d_wgrad_acc", dt(dy), ptr(dy), ptr(x), ptr(dw), C.byref(geom), ptr(row_scale), stream())
+    call("fod_conv2d_wgrad_acc", dt(dy), ptr(dy), ptr(x), ptr(dw), C.byref(geom), ptr(row_scale), stream(),
+         work=_conv_flops(geom))
     return dw
 
 
@@ -216,8 +228,9 @@ def attn_fwd(q1, k1, v, scale, q2=None, k2=None):
     shp, H = _attn_shape(q1, k1, v, scale)
     o = torch.empty_like(q1)
     lse2 = torch.empty((q1.shape[0], H, q1.shape[1]), dtype=torch.float32, device=q1.device)
+    parts = 2 if q2 is not None else 1
     call("fod_attn_fwd", dt(q1), ptr(q1), ptr(k1), ptr(q2), ptr(k2), ptr(v), ptr(o), ptr(lse2),
-         C.byref(shp), stream())
+         C.byref(shp), stream(), work=2.0 * shp.B * H * shp.Tq * shp.S * 32 * (parts + 1))
     return o, lse2
 
 
@@ -235,7 +248,8 @@ def attn_bwd(q1, k1, v, o, dout, lse2, scale, q2=None, k2=None):
         dq2, dk2 = torch.empty_like(q2), torch.empty_like(k2)
     delta = torch.empty_like(lse2)
     call("fod_attn_bwd", dt(q1), ptr(q1), ptr(k1), ptr(q2), ptr(k2), ptr(v), ptr(o), ptr(dout), ptr(lse2),
-         ptr(delta), ptr(dq1), ptr(dk1), ptr(dq2), ptr(dk2), ptr(dv), C.byref(shp), stream())
+         ptr(delta), ptr(dq1), ptr(dk1), ptr(dq2), ptr(dk2), ptr(dv), C.byref(shp), stream(),
+         work=2.0 * shp.B * H * shp.Tq * shp.S * 32 * (3 * (2 if q2 is not None else 1) + 2))
     return dq1, dk1, dq2, dk2, dv
 
 

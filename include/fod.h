@@ -218,13 +218,18 @@ int fod_od_map(const float* scores, const float* boxes, const float* anno_boxes,
 int fod_post_proc(const float* logits, const float* boxes, float* class_scores, float* boxes_px, int R,
                   int C, float img_h, float img_w, fod_stream_t stream);
 
-/* Fused AdamW step over one flat f32 parameter span (torch.optim.AdamW semantics, runs/_helper.py:105)
- * with the gradient pre-scaled by *clip_coef (device scalar from fod_grad_sqnorm_acc / clip). */
-int fod_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long n, float lr,
-                   float beta1, float beta2, float eps, float weight_decay, float bias_c1, float bias_c2,
-                   const float* clip_coef, fod_stream_t stream);
-/* out[0] += sum(g^2) */
-int fod_grad_sqnorm_acc(const float* grad, long n, float* out, fod_stream_t stream);
+/* Gradient clipping + AdamW over many tensors in two launches (torch.optim.AdamW + clip_grad_norm_
+ * semantics; reference future_od/trainer.py:186-188, runs/_helper.py:84-107).  Device tables:
+ *   ptrs  i64 [T,4] = {param, grad, exp_avg, exp_avg_sq} f32 pointers (same dense layout each),
+ *   numel i64 [T], lr_wd f32 [T,2]; block b works on elements [blk_chunk[b]*C, +C) of tensor
+ *   blk_tensor[b], C = fod_multi_chunk().  sqnorm: device scalar = sum g^2 (from fod_multi_sqnorm_acc,
+ *   which ADDS into it); the update scales g by min(1, max_norm/(sqrt(sqnorm)+1e-6)) when max_norm > 0. */
+int fod_multi_sqnorm_acc(const long* ptrs, const long* numel, const int* blk_tensor, const int* blk_chunk,
+                         int nblocks, float* out, fod_stream_t stream);
+int fod_multi_adamw(const long* ptrs, const long* numel, const float* lr_wd, const int* blk_tensor,
+                    const int* blk_chunk, int nblocks, float beta1, float beta2, float eps, float bias_c1,
+                    float bias_c2, const float* sqnorm, float max_norm, fod_stream_t stream);
+int fod_multi_chunk(void);
 
 #ifdef __cplusplus
 }

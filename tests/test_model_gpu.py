@@ -154,15 +154,16 @@ def test_bf16_mode_tracks_fp32():
         loss.backward()
         with torch.no_grad():
             raw, _ = model._model(data["video"], imu=torch.cat([data[k] for k in model._imu_keys], dim=2))
-        outs[dt] = (raw["pred_logits"].float(), raw["pred_boxes"].float(), float(loss),
+        outs[dt] = (raw["pred_logits"].float(), raw["pred_boxes"].float(), float(loss.detach()),
                     {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None})
     a, b = outs[torch.float32], outs[torch.bfloat16]
     rel_close(b[0], a[0], 6e-2, "bf16 logits")
     assert float((b[1] - a[1]).abs().max()) < 2e-2
     assert abs(b[2] - a[2]) < 5e-2 * abs(a[2])
     cos = []
+    top = max(float(v.norm()) for v in a[3].values())
     for n in a[3]:
         x, y = a[3][n].flatten(), b[3][n].flatten()
-        if float(x.norm()) > 0:
+        if float(x.norm()) > 1e-5 * top:      # skip gradients that are zero by construction (softmax-invariant biases)
             cos.append(float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-30)))
     assert min(cos) > 0.9 and np.mean(cos) > 0.98, (min(cos), np.mean(cos))
