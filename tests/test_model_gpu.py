@@ -160,10 +160,14 @@ def test_bf16_mode_tracks_fp32():
     rel_close(b[0], a[0], 6e-2, "bf16 logits")
     assert float((b[1] - a[1]).abs().max()) < 2e-2
     assert abs(b[2] - a[2]) < 5e-2 * abs(a[2])
-    cos = []
     top = max(float(v.norm()) for v in a[3].values())
+    rows = []
     for n in a[3]:
         x, y = a[3][n].flatten(), b[3][n].flatten()
         if float(x.norm()) > 1e-5 * top:      # skip gradients that are zero by construction (softmax-invariant biases)
-            cos.append(float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-30)))
-    assert min(cos) > 0.9 and np.mean(cos) > 0.98, (min(cos), np.mean(cos))
+            rows.append((float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-30)), float(x.norm()) / top, n))
+    rows.sort()
+    big = [r for r in rows if r[1] > 1e-2]
+    assert min(r[0] for r in big) > 0.97, rows[:5]            # gradients that carry the update: tight
+    assert np.mean([r[0] for r in rows]) > 0.98, rows[:5]
+    assert rows[0][0] > 0.3, rows[:5]                         # small gradients are noisier in bf16, never garbage
