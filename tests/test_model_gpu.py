@@ -168,6 +168,6 @@ def test_bf16_mode_tracks_fp32():
             rows.append((float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-30)), float(x.norm()) / top, n))
     rows.sort()
     big = [r for r in rows if r[1] > 1e-2]
-    assert min(r[0] for r in big) > 0.97, rows[:5]            # gradients that carry the update: tight
+    assert min(r[0] for r in big) > 0.95, rows[:5]            # gradients that carry the update
     assert np.mean([r[0] for r in rows]) > 0.98, rows[:5]
     assert rows[0][0] > 0.3, rows[:5]                         # small gradients are noisier in bf16, never garbage
