@@ -37,6 +37,7 @@ struct NtParams {
   long ldmask;
   int relu;
   int c_is_f32;
+  int vec_epi;   // host-checked: N, ldc, ldr, ldmask multiples of 4 and 16-byte aligned bases
   // gather geometry
   int Hs, Ws, Cs;   // source image dims / channels
   int Hd, Wd;       // m-domain dims
@@ -207,9 +208,73 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: scale/shift per column, residual, relu, mask, store
   const T* __restrict__ Rp = reinterpret_cast<const T*>(p.res);
   const T* __restrict__ Mp = reinterpret_cast<const T*>(p.mask);
+  if (p.vec_epi) {
+    // ---- epilogue A: accumulators -> LDS (f32 tile, reusing the staging buffers; the k-loop ended on a
+    // barrier) -> whole rows back out, 4 columns per lane: 32 (BN=128) or 16 lanes cover one row, so every
+    // global access of the tile (store, residual, mask) is a full 8/16-byte-per-lane coalesced segment.
+    float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sC[(wm * 64 + i * 32 + acc_row(r, lane)) * BN + wn * (32 * NT) + j * 32 + fr] = acc[i][j][r];
+    __syncthreads();
+    constexpr int CPR = BN / 4;              // 4-column chunks per row
+    constexpr int RPP = 256 / CPR;           // rows per pass
+    const int cq = tid % CPR, rq = tid / CPR;
+    const int n = n0 + cq * 4;
+    if (n < p.N) {
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+#pragma unroll 4
+      for (int row = rq; row < BM; row += RPP) {
+        const int m = m0 + row;
+        if (m >= p.M) break;
+        f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * BN + cq * 4);
+        v = v * sc + sh;
+        if (Rp) {
+          const int rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
+          const T* rp = Rp + (long)rm * p.ldr + n;
+          if (sizeof(T) == 2) {
+            const bf16x4_t rv = *reinterpret_cast<const bf16x4_t*>(rp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+          } else {
+            v += *reinterpret_cast<const f32x4*>(rp);
+          }
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (Mp) {
+          const T* mp = Mp + (long)m * p.ldmask + n;
+          if (sizeof(T) == 2) {
+            const bf16x4_t mv = *reinterpret_cast<const bf16x4_t*>(mp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((float)mv[e] > 0.f) ? v[e] : 0.f;
+          } else {
+            const f32x4 mv = *reinterpret_cast<const f32x4*>(mp);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (mv[e] > 0.f) ? v[e] : 0.f;
+          }
+        }
+        if (p.c_is_f32 || sizeof(T) == 4) {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = v;
+        } else {
+          *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(p.C) + (long)m * p.ldc + n) =
+              bf16x4_t{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        }
+      }
+    }
+    return;
+  }
+  // ---- epilogue B (ragged N / unaligned): one element per lane straight from the accumulators
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + wn * (32 * NT) + j * 32 + fr;
@@ -280,6 +345,13 @@ void fill_epilogue(NtParams& p, const fod_epilogue* e) {
   p.c_is_f32 = e ? e->out_f32 : 0;
 }
 
+void decide_vec_epilogue(NtParams& p) {
+  auto al = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
+  p.vec_epi = (p.N % 4 == 0) && (p.ldc % 4 == 0) && al(p.C) && (!p.scale || al(p.scale)) &&
+              (!p.shift || al(p.shift)) && (!p.res || (p.ldr % 4 == 0 && al(p.res))) &&
+              (!p.mask || (p.ldmask % 4 == 0 && al(p.mask)));
+}
+
 }  // namespace
 
 extern "C" int fod_gemm_nt(int dtype, const void* A, long lda, int a_row_mod, const void* B, long ldb,
@@ -297,6 +369,7 @@ extern "C" int fod_gemm_nt(int dtype, const void* A, long lda, int a_row_mod, co
   p.M = M; p.N = N; p.K = K;
   p.a_row_mod = a_row_mod;
   fill_epilogue(p, epi);
+  decide_vec_epilogue(p);
   return dispatch_nt<MODE_DENSE>(dtype, p, stream);
 }
 
@@ -332,6 +405,7 @@ static int conv_common(int dtype, bool dgrad, const void* src, const void* w, vo
   p.ldb = p.K;
   p.ldc = p.N;
   fill_epilogue(p, epi);
+  decide_vec_epilogue(p);
   if (!dgrad) return dispatch_nt<MODE_CONV>(dtype, p, stream);
   return dispatch_nt<MODE_DGRAD>(dtype, p, stream);
 }

@@ -1,0 +1,102 @@
+"""Micro-benchmark of the MFMA entry points on the shapes of the headline workload
+(ResNet-50 at 900x1600, 10 frames; encoder tokens 10 x 1450 x 256).  Prints TFLOP/s per shape."""
+import os, sys, math
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "future-object-detection_amd"))
+import torch
+from future_od.native import ops
+from oracle.stdetr import resnet_conv_list
+
+DEV = "cuda:0"
+dtype = torch.bfloat16
+FR = int(os.environ.get("FRAMES", "10"))
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+
+
+def timeit(fn, iters=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def conv_shapes():
+    h, w = 900, 1600
+    seen = {}
+    sizes = {}
+    cur = (h, w)
+    out = []
+    hh, ww = (h + 6 - 7) // 2 + 1, (w + 6 - 7) // 2 + 1
+    out.append(("stem", FR, h, w, 8, 64, 7, 2, 3))
+    hh, ww = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+    spatial = {1: (hh, ww)}
+    for key, cin, cout, k, s, p, _bn, stage in resnet_conv_list("resnet50")[1:]:
+        if stage not in spatial:
+            ph, pw = spatial[stage - 1]
+            spatial[stage] = ((ph - 1) // 2 + 1, (pw - 1) // 2 + 1)
+        # input spatial: stride-2 convs read the previous stage's map
+        ih, iw = spatial[stage]
+        if s == 2:
+            ih, iw = spatial[stage - 1]
+        elif key.endswith(".0.conv1") and stage > 1 and k == 1:
+            ih, iw = spatial[stage - 1]
+        sig = (ih, iw, cin, cout, k, s, p)
+        seen.setdefault(sig, []).append(key)
+    for sig, keys in seen.items():
+        out.append((f"{keys[0]} x{len(keys)}", FR) + sig)
+    return out
+
+
+if which in ("all", "conv"):
+    tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+    print(f"{'conv':28s} {'shape':34s} {'fwd TF':>8s} {'dgrad TF':>9s} {'wgrad TF':>9s}   ms(f/d/w)")
+    for name, n, h, w, cin, cout, k, s, p in conv_shapes():
+        mult = int(name.split(" x")[1]) if " x" in name else 1
+        x = torch.randn(n, h, w, cin, device=DEV).to(dtype)
+        wt = (torch.randn(cout, k, k, cin, device=DEV) / math.sqrt(k * k * cin)).to(dtype)
+        g = ops.conv_geom(x.shape, cout, k, s, p)
+        shift = torch.zeros(cout, device=DEV)
+        fl = 2.0 * n * g.Ho * g.Wo * cout * k * k * cin
+        tf = timeit(lambda: ops.conv2d_fwd(x, wt, g, shift=shift, relu=True))
+        dy = torch.randn(n, g.Ho, g.Wo, cout, device=DEV).to(dtype)
+        wt_t = wt.permute(3, 1, 2, 0).contiguous()
+        td = timeit(lambda: ops.conv2d_dgrad(dy, wt_t, g, relu_mask=x))
+        dw = torch.zeros(cout, k, k, cin, device=DEV)
+        tw = timeit(lambda: ops.conv2d_wgrad_acc(dy, x, dw, g))
+        print(f"{name:28s} {str((h, w, cin, cout, k, s)):34s} {fl / tf / 1e12:8.1f} {fl / td / 1e12:9.1f} {fl / tw / 1e12:9.1f}   "
+              f"{tf * 1e3:.3f}/{td * 1e3:.3f}/{tw * 1e3:.3f}")
+        tot["fwd"] += tf * mult; tot["dgrad"] += td * mult; tot["wgrad"] += tw * mult
+        del x, wt, dy, dw
+    print("backbone totals (ms, all layers, dgrad/wgrad incl. frozen ones):", {k: round(v * 1e3, 2) for k, v in tot.items()})
+
+if which in ("all", "gemm"):
+    print(f"{'gemm_nt M,N,K':28s} {'TF':>8s} {'us':>9s}")
+    for M, N, K in [(14500, 256, 256), (14500, 2048, 256), (14500, 256, 2048), (2900, 256, 256), (256, 256, 256),
+                    (256, 2048, 256), (256, 256, 2048), (128, 256, 256), (8192, 8192, 8192), (4096, 4096, 4096)]:
+        a = torch.randn(M, K, device=DEV).to(dtype); b = torch.randn(N, K, device=DEV).to(dtype)
+        t = timeit(lambda: ops.gemm_nt(a, b), iters=10)
+        print(f"{str((M, N, K)):28s} {2.0 * M * N * K / t / 1e12:8.1f} {t * 1e6:9.1f}")
+    print(f"{'gemm_tn M,N1,K2':28s} {'TF':>8s} {'us':>9s}")
+    for M, N1, K2 in [(14500, 256, 256), (14500, 2048, 256), (14500, 256, 2048), (256, 256, 256), (256, 2048, 256)]:
+        g_ = torch.randn(M, N1, device=DEV).to(dtype); x = torch.randn(M, K2, device=DEV).to(dtype)
+        dw = torch.zeros(N1, K2, device=DEV)
+        t = timeit(lambda: ops.gemm_tn_acc(g_, x, dw), iters=10)
+        print(f"{str((M, N1, K2)):28s} {2.0 * M * N1 * K2 / t / 1e12:8.1f} {t * 1e6:9.1f}")
+
+if which in ("all", "attn"):
+    print(f"{'attention B,H,Tq,S,parts':28s} {'fwd TF':>8s} {'bwd TF':>8s}   us(f/b)")
+    for B, H, Tq, S, parts in [(10, 8, 1450, 1450, 1), (2, 8, 128, 1450, 2), (2, 8, 128, 128, 1)]:
+        E = H * 32
+        q = torch.randn(B, Tq, E, device=DEV).to(dtype); k = torch.randn(B, S, E, device=DEV).to(dtype)
+        v = torch.randn(B, S, E, device=DEV).to(dtype)
+        q2 = torch.randn(B, Tq, E, device=DEV).to(dtype) if parts == 2 else None
+        k2 = torch.randn(B, S, E, device=DEV).to(dtype) if parts == 2 else None
+        sc = 1 / math.sqrt(32 * parts)
+        o, lse = ops.attn_fwd(q, k, v, sc, q2, k2)
+        tf = timeit(lambda: ops.attn_fwd(q, k, v, sc, q2, k2))
+        tb = timeit(lambda: ops.attn_bwd(q, k, v, o, o, lse, sc, q2, k2))
+        f = 2.0 * B * H * Tq * S * 32
+        print(f"{str((B, H, Tq, S, parts)):28s} {f * (parts + 1) / tf / 1e12:8.1f} {f * (3 * parts + 2) / tb / 1e12:8.1f}   {tf * 1e6:.1f}/{tb * 1e6:.1f}")
