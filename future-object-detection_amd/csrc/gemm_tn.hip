@@ -28,6 +28,7 @@ struct TnParams {
   long ldg, ldx, ldw;
   int M, N1, K2;
   const float* rscale;
+  float* colsum;     // optional f32 [N1]: += column sums of G (bias gradient), done by the blockIdx.x == 0 blocks
   int m_per_split;
   int Hs, Ws, Cs, Hd, Wd, kh, kw, stride, pad;
 };
@@ -75,8 +76,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
   constexpr int CHR = 128 / VEC;          // 16-byte chunks per tile row
   constexpr int RPP = 256 / CHR;          // rows per pass
   constexpr int PASSES = MSTEP / RPP;
-  __shared__ __attribute__((aligned(16))) unsigned char sG[MSTEP * PITCH];
-  __shared__ __attribute__((aligned(16))) unsigned char sX[MSTEP * PITCH];
+  __shared__ __attribute__((aligned(16))) unsigned char sGb[2][MSTEP * PITCH];
+  __shared__ __attribute__((aligned(16))) unsigned char sXb[2][MSTEP * PITCH];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1;
@@ -126,12 +127,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
       rx[ps] = vx;
     }
   };
-  auto store_step = [&]() {
+  float csum[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) csum[e] = 0.f;
+  const bool do_colsum = p.colsum != nullptr && blockIdx.x == 0;
+  auto store_step = [&](int buf) {
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const int row = prow + ps * RPP;
-      *reinterpret_cast<uint4*>(sG + row * PITCH + chunk * 16) = rg[ps];
-      *reinterpret_cast<uint4*>(sX + row * PITCH + chunk * 16) = rx[ps];
+      *reinterpret_cast<uint4*>(sGb[buf] + row * PITCH + chunk * 16) = rg[ps];
+      *reinterpret_cast<uint4*>(sXb[buf] + row * PITCH + chunk * 16) = rx[ps];
+      if (do_colsum) {
+        T tmp[VEC];
+        __builtin_memcpy(tmp, &rg[ps], 16);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) csum[e] += to_f32(tmp[e]);
+      }
     }
   };
 
@@ -143,11 +154,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  if (mb < mend) load_step(mb);
+  int buf = 0;
+  if (mb < mend) {
+    load_step(mb);
+    store_step(0);
+  }
+  __syncthreads();
   for (int ms = mb; ms < mend; ms += MSTEP) {
-    store_step();
-    __syncthreads();
-    if (ms + MSTEP < mend) load_step(ms + MSTEP);
+    const bool more = ms + MSTEP < mend;
+    if (more) load_step(ms + MSTEP);
+    const unsigned char* sG = sGb[buf];
+    const unsigned char* sX = sXb[buf];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       Frag<T> fa[2], fb[2];
@@ -160,7 +177,27 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) mma16(fa[a], fb[b], acc[a][b]);
     }
+    if (more) store_step(buf ^ 1);
     __syncthreads();
+    buf ^= 1;
+  }
+  if (do_colsum && g_ok) {
+    // threads sharing a chunk (same columns, different rows) differ by multiples of CHR: reduce through LDS
+    float* red = reinterpret_cast<float*>(sGb[0]);       // 256 * VEC floats <= one staging buffer
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[tid * VEC + e] = csum[e];
+  }
+  if (do_colsum) {
+    __syncthreads();
+    if (tid < CHR && g_ok) {
+      const float* red = reinterpret_cast<const float*>(sGb[0]);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float s = 0.f;
+        for (int r = 0; r < RPP; ++r) s += red[(r * CHR + tid) * VEC + e];
+        atomicAdd(p.colsum + gi + e, s);
+      }
+    }
   }
 
 #pragma unroll
@@ -202,9 +239,13 @@ __global__ void colsum_kernel(const T* __restrict__ G, long ldg, int M, int N, i
 }
 
 int pick_splits(int tiles, int M) {
-  int s = 1024 / (tiles > 0 ? tiles : 1);
-  const int max_s = (M + 255) / 256;
+  // enough blocks to cover the 256 CUs ~1.5x, at least two 32-row steps per block, and a cap on the
+  // atomic traffic (each block adds a 64 KB f32 tile; chip-wide atomic rate is ~1.3 TB/s)
+  if (tiles < 1) tiles = 1;
+  int s = (384 + tiles - 1) / tiles;
+  const int max_s = (M + 63) / 64;
   if (s > max_s) s = max_s;
+  if (s * tiles > 768) s = 768 / tiles;
   if (s < 1) s = 1;
   return s;
 }
@@ -230,7 +271,7 @@ int launch_tn(int dtype, TnParams& p, hipStream_t stream) {
 }  // namespace
 
 extern "C" int fod_gemm_tn_acc(int dtype, const void* G, long ldg, const void* X, long ldx, float* dW,
-                               long ldw, int M, int N1, int K2, const float* row_scale,
+                               long ldw, int M, int N1, int K2, const float* row_scale, float* colsum,
                                hipStream_t stream) {
   const int vec = dtype == FOD_BF16 ? 8 : 4;
   FOD_REQUIRE(G && X && dW, "gemm_tn: null operand");
@@ -243,6 +284,7 @@ extern "C" int fod_gemm_tn_acc(int dtype, const void* G, long ldg, const void* X
   p.ldg = ldg; p.ldx = ldx; p.ldw = ldw;
   p.M = M; p.N1 = N1; p.K2 = K2;
   p.rscale = row_scale;
+  p.colsum = colsum;
   return launch_tn<MODE_DENSE>(dtype, p, stream);
 }
 

@@ -151,10 +151,9 @@ class _PaddedInLinear(torch.autograd.Function):
         g = dy.contiguous()
         if relu:
             g = ops.eltwise(Fn.L.EW_RELU_MASK, g, y)
-        dw = torch.zeros((N, Ip), dtype=torch.float32, device=x.device)
-        ops.gemm_tn_acc(g, x, dw)
-        db = torch.zeros(N, dtype=torch.float32, device=x.device)
-        ops.colsum_acc(g, db)
+        dw = Fn.zeros_f32((N, Ip), x.device)
+        db = Fn.zeros_f32((N,), x.device)
+        ops.gemm_tn_acc(g, x, dw, colsum=db)
         return None, dw[:, :I], db, None, None
 
 

@@ -162,13 +162,13 @@ class BackboneFn(Function):
 
         def wgrad(gy, xin, cw, geom, scale):
             co, ci, kh, kw = cw.weight.shape
-            dw = torch.zeros((co, kh, kw, ci), dtype=torch.float32, device=dev)
+            dw = Fn.zeros_f32((co, kh, kw, ci), dev)
             ops.conv2d_wgrad_acc(gy, xin, dw, geom, row_scale=scale)
             grads[id(cw.weight)] = dw.permute(0, 3, 1, 2)       # OIHW view, channels_last strides
 
         if proj.weight.requires_grad:
             wgrad(g, ctx.x_last, proj, ctx.geom_p, None)
-            db = torch.zeros(proj.weight.shape[0], dtype=torch.float32, device=dev)
+            db = Fn.zeros_f32((proj.weight.shape[0],), dev)
             ops.colsum_acc(g.view(-1, g.shape[-1]), db)
             grads[id(proj.bias)] = db
         tape = ctx.tape

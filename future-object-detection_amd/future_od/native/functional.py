@@ -39,6 +39,52 @@ class _Prepared:
 PREP = _Prepared()
 
 
+class _ZeroArena:
+    """Zero-initialised f32 scratch for gradient accumulation targets (the `_acc` kernels add into
+    their output).  One big buffer is cleared with ONE fill per step instead of one fill launch per
+    gradient tensor (~1300 per step).  Slices stay valid until the next `recycle()`, which the
+    optimizer's zero_grad() calls once the gradients have been consumed; until the first recycle()
+    the arena is off and `zeros()` falls back to torch.zeros."""
+
+    def __init__(self):
+        self.buf = None
+        self.off = 0
+        self.high = 0
+        self.active = False
+        self.extra = []
+
+    def recycle(self, device):
+        device = torch.device(device)
+        need = max(self.high, 1 << 20)
+        if self.buf is None or self.buf.device != device or self.buf.numel() < need:
+            self.buf = torch.zeros(int(need * 1.25), dtype=torch.float32, device=device)
+        elif self.off:
+            self.buf[:self.off].zero_()
+        self.off = 0
+        self.high = 0
+        self.extra = []
+        self.active = True
+
+    def zeros(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= d
+        n_al = (n + 63) // 64 * 64           # keep every slice 256-byte aligned
+        self.high += n_al
+        if not self.active or self.buf.device != torch.device(device) or self.off + n_al > self.buf.numel():
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        out = self.buf[self.off:self.off + n].view(shape)
+        self.off += n_al
+        return out
+
+
+ARENA = _ZeroArena()
+
+
+def zeros_f32(shape, device):
+    return ARENA.zeros(tuple(shape), device)
+
+
 def _pad_to(n, v):
     return (n + v - 1) // v * v
 
@@ -128,13 +174,15 @@ class LinearFn(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(g, prep_linear(weight, dtype, True)).view(x.shape)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        dbp = zeros_f32((Np,), x.device) if want_db else None
         if ctx.needs_input_grad[1]:
-            dwp = torch.zeros((Np, K), dtype=torch.float32, device=x.device)
-            ops.gemm_tn_acc(g, x.view(-1, K), dwp)
+            dwp = zeros_f32((Np, K), x.device)
+            ops.gemm_tn_acc(g, x.view(-1, K), dwp, colsum=dbp)      # bias gradient from the same pass
             dw = dwp[:N] if Np != N else dwp
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            dbp = torch.zeros(Np, dtype=torch.float32, device=x.device)
+        elif want_db:
             ops.colsum_acc(g, dbp)
+        if want_db:
             db = dbp[:N] if Np != N else dbp
         return dx, dw, db, None, None
 
@@ -165,7 +213,7 @@ class AddFn(Function):
                 db = _sum_periodic(g.view(rows, cols), mod).view(bshape)
             else:
                 assert not mod
-                out = torch.zeros((rows // div, cols), dtype=torch.float32, device=g.device)
+                out = zeros_f32((rows // div, cols), g.device)
                 ops.colsum_acc(g.view(rows, cols), out, group_rows=div)
                 db = cast(out, g.dtype).view(bshape)
         return (g.view(ashape) if ctx.needs_input_grad[0] else None), db, None, None
@@ -243,14 +291,14 @@ class LayerNormFn(Function):
     def backward(ctx, dy):
         s, mean, rstd, gamma = ctx.saved_tensors
         D = gamma.numel()
-        dg = torch.zeros(D, dtype=torch.float32, device=dy.device)
-        db = torch.zeros(D, dtype=torch.float32, device=dy.device)
+        dg = zeros_f32((D,), dy.device)
+        db = zeros_f32((D,), dy.device)
         dx = ops.layernorm_bwd(dy.contiguous(), s, mean, rstd, gamma, dg, db)
         dres = None
         if ctx.res_shape is not None and ctx.needs_input_grad[1]:
             if ctx.res_row_div:
                 rows = dx.numel() // D
-                out = torch.zeros((rows // ctx.res_row_div, D), dtype=torch.float32, device=dy.device)
+                out = zeros_f32((rows // ctx.res_row_div, D), dy.device)
                 ops.colsum_acc(dx.view(rows, D), out, group_rows=ctx.res_row_div)
                 dres = cast(out, dx.dtype).view(ctx.res_shape)
             else:
@@ -334,7 +382,7 @@ class ZeroGradAnchor(Function):
 
     @staticmethod
     def backward(ctx, g):
-        return (g,) + tuple(torch.zeros(s, dtype=torch.float32, device=d) for s, d in ctx.shapes)
+        return (g,) + tuple(zeros_f32(s, d) for s, d in ctx.shapes)
 
 
 class CastFn(Function):

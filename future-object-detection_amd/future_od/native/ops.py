@@ -86,15 +86,17 @@ def gemm_nt(a, b, *, a_row_mod=0, m_rows=None, scale=None, shift=None, residual=
     return out
 
 
-def gemm_tn_acc(g, x, dw, row_scale=None):
-    """dw[N1,K2] (f32) += g[M,N1]^T . x[M,K2]."""
+def gemm_tn_acc(g, x, dw, row_scale=None, colsum=None):
+    """dw[N1,K2] (f32) += g[M,N1]^T . x[M,K2];  colsum[N1] (f32, optional) += column sums of g."""
     _chk(g, "g"); _chk(x, "x", g.dtype); _chk(dw, "dw", torch.float32)
     N1, K2 = g.shape[-1], x.shape[-1]
     M = g.numel() // N1
     assert x.numel() // K2 == M and dw.numel() == N1 * K2, (g.shape, x.shape, dw.shape)
     if row_scale is not None:
         _chk(row_scale, "row_scale", torch.float32); assert row_scale.numel() == N1
-    call("fod_gemm_tn_acc", dt(g), ptr(g), N1, ptr(x), K2, ptr(dw), K2, M, N1, K2, ptr(row_scale), stream(),
+    if colsum is not None:
+        _chk(colsum, "colsum", torch.float32); assert colsum.numel() == N1
+    call("fod_gemm_tn_acc", dt(g), ptr(g), N1, ptr(x), K2, ptr(dw), K2, M, N1, K2, ptr(row_scale), ptr(colsum), stream(),
          work=2.0 * M * N1 * K2)
     return dw
 

@@ -31,7 +31,13 @@ class FusedAdamW(torch.optim.Optimizer):
         self.last_grad_norm = None
 
     def zero_grad(self, set_to_none=True):
-        super().zero_grad(set_to_none=set_to_none)
+        """Drops the gradients (set_to_none) and recycles the zero arena they were accumulated in."""
+        super().zero_grad(set_to_none=True)
+        from future_od.native import functional as Fn
+        for grp in self.param_groups:
+            if grp["params"]:
+                Fn.ARENA.recycle(grp["params"][0].device)
+                break
 
     def _state_for(self, p):
         st = self.state[p]

@@ -63,9 +63,10 @@ int fod_gemm_nt(int dtype, const void* A, long lda, int a_row_mod, const void* B
                 long ldc, int M, int N, int K, const fod_epilogue* epi, fod_stream_t stream);
 
 /* dW[i,j] += row_scale[i] * sum_m G[m,i] * X[m,j]     G:[M,N1] ldg, X:[M,K2] ldx, dW f32 [N1,K2] ldw
- * Replaces autograd's Linear weight-gradient (loss.backward(), future_od/trainer.py:180). */
+ * colsum (optional, f32 [N1]) += sum_m G[m,i]: the bias gradient from the same pass over G.
+ * Replaces autograd's Linear weight/bias gradients (loss.backward(), future_od/trainer.py:180). */
 int fod_gemm_tn_acc(int dtype, const void* G, long ldg, const void* X, long ldx, float* dW, long ldw,
-                    int M, int N1, int K2, const float* row_scale, fod_stream_t stream);
+                    int M, int N1, int K2, const float* row_scale, float* colsum, fod_stream_t stream);
 
 /* out[g, n] += sum over rows m of group g of G[m, n];  group g = m / group_rows (group_rows <= 0:
  * one group).  Bias gradients and sums over a broadcast dimension. */

@@ -236,3 +236,13 @@ def test_layernorm(dtype, D):
     y, s, _, _ = ops.layernorm_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), residual=rb.to(DEV), res_row_div=5)
     ref = F.layer_norm((x.float() + rb.float().repeat_interleave(5, 0)[:rows]).to(dtype).float(), (D,), gamma, beta, 1e-5)
     check(y, ref, dtype, 2, "ln bcast")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_tn_fused_colsum(dtype):
+    M, N1, K2 = 777, 264, 136
+    g, x = rnd((M, N1), dtype, 1), rnd((M, K2), dtype, 2)
+    dw, cs = torch.zeros(N1, K2, device=DEV), torch.zeros(N1, device=DEV)
+    ops.gemm_tn_acc(g.to(DEV), x.to(DEV), dw, colsum=cs)
+    check(dw, g.float().t() @ x.float(), torch.float32 if dtype == torch.float32 else dtype, math.sqrt(M), "tn")
+    check(cs, g.float().sum(0), torch.float32, math.sqrt(M), "fused colsum")
