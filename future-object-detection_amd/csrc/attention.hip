@@ -60,11 +60,15 @@ FOD_DEVINL void zero_acc(f32x16& a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <typename T, int PARTS>
+// SPLIT = false: each wave owns its own 32 queries and walks all keys (long query sequences).
+// SPLIT = true : the 4 waves of a block share 32 queries and each walks every 4th key tile; partial
+//                (max, sum, O) states are merged through LDS.  Used when Tq is small (decoder queries:
+//                Tq = 128 would otherwise give 16 blocks that each walk 46 key tiles serially).
+template <typename T, int PARTS, bool SPLIT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 31, fh = lane >> 5;
-  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const int q0 = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + wave) * 32;
   if (q0 >= p.Tq) return;
   const int h = blockIdx.y, b = blockIdx.z;
   const int q = min(q0 + fr, p.Tq - 1);
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   f32x16 oacc;
   zero_acc<T>(oacc);
 
-  for (int k0 = 0; k0 < p.S; k0 += 32) {
+  for (int k0 = SPLIT ? wave * 32 : 0; k0 < p.S; k0 += SPLIT ? 128 : 32) {
     const int kr = min(k0 + fr, p.S - 1);
     f32x16 sacc;
     zero_acc<T>(sacc);
@@ -125,6 +129,35 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
       mma16(fv, fp, oacc);
     }
   }
+  if (SPLIT) {
+    __shared__ float s_m[4][32], s_l[4][32], s_o[4][32][33];
+    if (fh == 0) {
+      s_m[wave][fr] = m;
+      s_l[wave][fr] = l;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s_o[wave][acc_row(r, lane)][fr] = oacc[r];
+    __syncthreads();
+    if (wave != 0) return;
+    float mstar = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) mstar = fmaxf(mstar, s_m[w][fr]);
+    float sc[4];
+    l = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      sc[w] = exp2f(s_m[w][fr] - mstar);      // a wave that saw no key has m = -inf -> weight 0
+      l += s_l[w][fr] * sc[w];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += s_o[w][acc_row(r, lane)][fr] * sc[w];
+      oacc[r] = v;
+    }
+    m = mstar;
+  }
   if (q0 + fr < p.Tq) {
     T* op = reinterpret_cast<T*>(p.o) + (long)b * p.o_bs + (long)q * p.o_ts + h * 32;
     store_acc_t<T>(op, oacc, fh, 1.f / l);
@@ -134,11 +167,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 
 // ------------------------------------------------------------------------------------------------
 // dq pass: wave owns 32 queries.  Also writes delta[q] = sum_d dO[q,d] * O[q,d].
-template <typename T, int PARTS>
+template <typename T, int PARTS, bool SPLIT>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 31, fh = lane >> 5;
-  const int q0 = (blockIdx.x * 4 + wave) * 32;
+  const int q0 = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + wave) * 32;
   if (q0 >= p.Tq) return;
   const int h = blockIdx.y, b = blockIdx.z;
   const int q = min(q0 + fr, p.Tq - 1);
@@ -164,14 +197,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   dl += __shfl_xor(dl, 32);
   const long sidx = ((long)b * p.H + h) * p.Tq + q;
   const float lse2 = p.lse2[sidx];
-  if (fh == 0 && q0 + fr < p.Tq) p.delta[sidx] = dl;
+  if (fh == 0 && q0 + fr < p.Tq && (!SPLIT || wave == 0)) p.delta[sidx] = dl;
 
   const float c = p.scale * LOG2E;
   f32x16 dq[PARTS];
 #pragma unroll
   for (int pt = 0; pt < PARTS; ++pt) zero_acc<T>(dq[pt]);
 
-  for (int k0 = 0; k0 < p.S; k0 += 32) {
+  for (int k0 = SPLIT ? wave * 32 : 0; k0 < p.S; k0 += SPLIT ? 128 : 32) {
     const int kr = min(k0 + fr, p.S - 1);
     f32x16 sacc, dpacc;
     zero_acc<T>(sacc);
@@ -206,6 +239,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
         mma16(fkt, fds, dq[pt]);             // dQ^T[d, q] += sum_k K[k,d] dS^T[k,q]
       }
     }
+  }
+  if (SPLIT) {   // the four partial dQ^T tiles just add
+    __shared__ float s_dq[3][PARTS][32][33];
+    if (wave > 0) {
+#pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_dq[wave - 1][pt][acc_row(r, lane)][fr] = dq[pt][r];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        dq[pt][r] += s_dq[0][pt][acc_row(r, lane)][fr] + s_dq[1][pt][acc_row(r, lane)][fr] +
+                     s_dq[2][pt][acc_row(r, lane)][fr];
   }
   if (q0 + fr < p.Tq) {
     T* d1 = reinterpret_cast<T*>(p.dq1) + (long)b * p.q_bs + (long)q * p.q_ts + h * 32;
@@ -305,12 +355,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
 template <typename T, int PARTS>
 int launch_all(int which, const AttnParams& p, hipStream_t stream) {
   const dim3 block(256);
+  // few queries: spend the block's four waves on the key dimension instead (see attn_fwd_kernel)
+  const bool split = p.Tq <= 512 && p.S >= 128;
   if (which == 0) {
-    const dim3 grid(ceil_div(p.Tq, 128), p.H, p.B);
-    hipLaunchKernelGGL((attn_fwd_kernel<T, PARTS>), grid, block, 0, stream, p);
+    if (split)
+      hipLaunchKernelGGL((attn_fwd_kernel<T, PARTS, true>), dim3(ceil_div(p.Tq, 32), p.H, p.B), block, 0, stream, p);
+    else
+      hipLaunchKernelGGL((attn_fwd_kernel<T, PARTS, false>), dim3(ceil_div(p.Tq, 128), p.H, p.B), block, 0, stream, p);
   } else if (which == 1) {
-    const dim3 grid(ceil_div(p.Tq, 128), p.H, p.B);
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, PARTS>), grid, block, 0, stream, p);
+    if (split)
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, PARTS, true>), dim3(ceil_div(p.Tq, 32), p.H, p.B), block, 0, stream, p);
+    else
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, PARTS, false>), dim3(ceil_div(p.Tq, 128), p.H, p.B), block, 0, stream, p);
   } else {
     const dim3 grid(ceil_div(p.S, 128), p.H, p.B);
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, PARTS>), grid, block, 0, stream, p);

@@ -29,6 +29,7 @@ struct TnParams {
   int M, N1, K2;
   const float* rscale;
   float* colsum;     // optional f32 [N1]: += column sums of G (bias gradient), done by the blockIdx.x == 0 blocks
+  int accumulate;    // 0: outputs are all-zero on entry (caller's guarantee) -> a single M-split may plain-store
   int m_per_split;
   int Hs, Ws, Cs, Hd, Wd, kh, kw, stride, pad;
 };
@@ -195,23 +196,39 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
       for (int e = 0; e < VEC; ++e) {
         float s = 0.f;
         for (int r = 0; r < RPP; ++r) s += red[(r * CHR + tid) * VEC + e];
-        atomicAdd(p.colsum + gi + e, s);
+        if (gridDim.z != 1) atomicAdd(p.colsum + gi + e, s);
+        else if (p.accumulate) p.colsum[gi + e] += s;
+        else p.colsum[gi + e] = s;
       }
     }
   }
 
+  // A CU issues ~one 256-B atomic wave-instruction per 50 ns (12.8 us for a 128x128 tile), so atomics
+  // are used only when several M-splits add into the same tile.
+  const bool single = gridDim.z == 1;
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int j = j0 + wj * 64 + b * 32 + (lane & 31);
     if (j >= p.K2) continue;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
+      float old[16];
+      if (single && p.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {            // independent loads first, then the stores
+          const int i = i0 + wi * 64 + a * 32 + acc_row(r, lane);
+          old[r] = (i < p.N1) ? p.dW[(long)i * p.ldw + j] : 0.f;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = i0 + wi * 64 + a * 32 + acc_row(r, lane);
         if (i >= p.N1) continue;
         const float v = acc[a][b][r] * (p.rscale ? p.rscale[i] : 1.f);
-        atomicAdd(p.dW + (long)i * p.ldw + j, v);
+        float* dst = p.dW + (long)i * p.ldw + j;
+        if (!single) atomicAdd(dst, v);
+        else if (p.accumulate) *dst = old[r] + v;
+        else *dst = v;
       }
     }
   }
@@ -239,13 +256,18 @@ __global__ void colsum_kernel(const T* __restrict__ G, long ldg, int M, int N, i
 }
 
 int pick_splits(int tiles, int M) {
-  // enough blocks to cover the 256 CUs ~1.5x, at least two 32-row steps per block, and a cap on the
-  // atomic traffic (each block adds a 64 KB f32 tile; chip-wide atomic rate is ~1.3 TB/s)
+  // Cost model: a block pays ~12.8 us of f32 atomics for its 128x128 tile (per-CU atomic issue rate)
+  // unless it is the only M-split (then plain stores), and ~0.5 us per 32-row step.
+  //  - small M: one split, no atomics;
+  //  - long reductions (>= 1536 rows per split still left): ~1024 blocks, atomics are < 20 % of a block;
+  //  - otherwise ~1.5 blocks per CU with at least 512 rows each.
   if (tiles < 1) tiles = 1;
-  int s = (384 + tiles - 1) / tiles;
-  const int max_s = (M + 63) / 64;
+  if (M <= 512) return 1;
+  int s = 1024 / tiles;
+  if (s >= 1 && M / s >= 1536) return s;
+  s = (384 + tiles - 1) / tiles;
+  const int max_s = M / 512;
   if (s > max_s) s = max_s;
-  if (s * tiles > 768) s = 768 / tiles;
   if (s < 1) s = 1;
   return s;
 }
@@ -272,7 +294,7 @@ int launch_tn(int dtype, TnParams& p, hipStream_t stream) {
 
 extern "C" int fod_gemm_tn_acc(int dtype, const void* G, long ldg, const void* X, long ldx, float* dW,
                                long ldw, int M, int N1, int K2, const float* row_scale, float* colsum,
-                               hipStream_t stream) {
+                               int accumulate, hipStream_t stream) {
   const int vec = dtype == FOD_BF16 ? 8 : 4;
   FOD_REQUIRE(G && X && dW, "gemm_tn: null operand");
   FOD_REQUIRE(M > 0 && N1 > 0 && K2 > 0, "gemm_tn: empty problem");
@@ -285,11 +307,13 @@ extern "C" int fod_gemm_tn_acc(int dtype, const void* G, long ldg, const void* X
   p.M = M; p.N1 = N1; p.K2 = K2;
   p.rscale = row_scale;
   p.colsum = colsum;
+  p.accumulate = accumulate;
   return launch_tn<MODE_DENSE>(dtype, p, stream);
 }
 
 extern "C" int fod_conv2d_wgrad_acc(int dtype, const void* dy, const void* x, float* dw,
-                                    const fod_conv_geom* g, const float* row_scale, hipStream_t stream) {
+                                    const fod_conv_geom* g, const float* row_scale, int accumulate,
+                                    hipStream_t stream) {
   const int vec = dtype == FOD_BF16 ? 8 : 4;
   FOD_REQUIRE(dy && x && dw && g, "conv_wgrad: null operand");
   FOD_REQUIRE(g->Cin % vec == 0 && g->Cout % vec == 0, "conv_wgrad: channels %d/%d must be multiples of %d",
@@ -309,6 +333,7 @@ extern "C" int fod_conv2d_wgrad_acc(int dtype, const void* dy, const void* x, fl
   p.Hs = g->H; p.Ws = g->W; p.Cs = g->Cin;
   p.Hd = g->Ho; p.Wd = g->Wo;
   p.kh = g->kh; p.kw = g->kw; p.stride = g->stride; p.pad = g->pad;
+  p.accumulate = accumulate;
   return launch_tn<MODE_CONV>(dtype, p, stream);
 }
 

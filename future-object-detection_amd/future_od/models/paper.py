@@ -153,7 +153,7 @@ class _PaddedInLinear(torch.autograd.Function):
             g = ops.eltwise(Fn.L.EW_RELU_MASK, g, y)
         dw = Fn.zeros_f32((N, Ip), x.device)
         db = Fn.zeros_f32((N,), x.device)
-        ops.gemm_tn_acc(g, x, dw, colsum=db)
+        ops.gemm_tn_acc(g, x, dw, colsum=db, zeroed=True)
         return None, dw[:, :I], db, None, None
 
 

@@ -163,7 +163,7 @@ class BackboneFn(Function):
         def wgrad(gy, xin, cw, geom, scale):
             co, ci, kh, kw = cw.weight.shape
             dw = Fn.zeros_f32((co, kh, kw, ci), dev)
-            ops.conv2d_wgrad_acc(gy, xin, dw, geom, row_scale=scale)
+            ops.conv2d_wgrad_acc(gy, xin, dw, geom, row_scale=scale, zeroed=True)
             grads[id(cw.weight)] = dw.permute(0, 3, 1, 2)       # OIHW view, channels_last strides
 
         if proj.weight.requires_grad:

@@ -178,7 +178,7 @@ class LinearFn(Function):
         dbp = zeros_f32((Np,), x.device) if want_db else None
         if ctx.needs_input_grad[1]:
             dwp = zeros_f32((Np, K), x.device)
-            ops.gemm_tn_acc(g, x.view(-1, K), dwp, colsum=dbp)      # bias gradient from the same pass
+            ops.gemm_tn_acc(g, x.view(-1, K), dwp, colsum=dbp, zeroed=True)   # bias gradient from the same pass
             dw = dwp[:N] if Np != N else dwp
         elif want_db:
             ops.colsum_acc(g, dbp)

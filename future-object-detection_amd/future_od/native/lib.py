@@ -45,11 +45,11 @@ _EP, _CG, _AS = C.POINTER(Epilogue), C.POINTER(ConvGeom), C.POINTER(AttnShape)
 # name -> argtypes, exactly the prototypes of include/fod.h (stream last unless host-only)
 SIGNATURES = {
     "fod_gemm_nt": [_i, _p, _l, _i, _p, _l, _p, _l, _i, _i, _i, _EP, _p],
-    "fod_gemm_tn_acc": [_i, _p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _p],
+    "fod_gemm_tn_acc": [_i, _p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p],
     "fod_colsum_acc": [_i, _p, _l, _i, _i, _i, _p, _p],
     "fod_conv2d_fwd": [_i, _p, _p, _p, _CG, _EP, _p],
     "fod_conv2d_dgrad": [_i, _p, _p, _p, _CG, _EP, _p],
-    "fod_conv2d_wgrad_acc": [_i, _p, _p, _p, _CG, _p, _p],
+    "fod_conv2d_wgrad_acc": [_i, _p, _p, _p, _CG, _p, _i, _p],
     "fod_maxpool3x3s2": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "fod_nchw_to_nhwc": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _p],
     "fod_permute3_cast": [_i, _i, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _i, _p],

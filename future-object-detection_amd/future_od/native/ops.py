@@ -86,7 +86,7 @@ def gemm_nt(a, b, *, a_row_mod=0, m_rows=None, scale=None, shift=None, residual=
     return out
 
 
-def gemm_tn_acc(g, x, dw, row_scale=None, colsum=None):
+def gemm_tn_acc(g, x, dw, row_scale=None, colsum=None, zeroed=False):
     """dw[N1,K2] (f32) += g[M,N1]^T . x[M,K2];  colsum[N1] (f32, optional) += column sums of g."""
     _chk(g, "g"); _chk(x, "x", g.dtype); _chk(dw, "dw", torch.float32)
     N1, K2 = g.shape[-1], x.shape[-1]
@@ -96,7 +96,8 @@ def gemm_tn_acc(g, x, dw, row_scale=None, colsum=None):
         _chk(row_scale, "row_scale", torch.float32); assert row_scale.numel() == N1
     if colsum is not None:
         _chk(colsum, "colsum", torch.float32); assert colsum.numel() == N1
-    call("fod_gemm_tn_acc", dt(g), ptr(g), N1, ptr(x), K2, ptr(dw), K2, M, N1, K2, ptr(row_scale), ptr(colsum), stream(),
+    call("fod_gemm_tn_acc", dt(g), ptr(g), N1, ptr(x), K2, ptr(dw), K2, M, N1, K2, ptr(row_scale), ptr(colsum),
+         0 if zeroed else 1, stream(),
          work=2.0 * M * N1 * K2)
     return dw
 
@@ -154,14 +155,15 @@ def conv2d_dgrad(dy, w_t, geom, *, residual=None, relu_mask=None):
     return dx
 
 
-def conv2d_wgrad_acc(dy, x, dw, geom, row_scale=None):
+def conv2d_wgrad_acc(dy, x, dw, geom, row_scale=None, zeroed=False):
     _chk(dy, "dy"); _chk(x, "x", dy.dtype); _chk(dw, "dw", torch.float32)
     assert tuple(dy.shape) == (geom.Nimg, geom.Ho, geom.Wo, geom.Cout)
     assert tuple(x.shape) == (geom.Nimg, geom.H, geom.W, geom.Cin)
     assert dw.numel() == geom.Cout * geom.kh * geom.kw * geom.Cin
     if row_scale is not None:
         _chk(row_scale, "row_scale", torch.float32); assert row_scale.numel() == geom.Cout
-    call("fod_conv2d_wgrad_acc", dt(dy), ptr(dy), ptr(x), ptr(dw), C.byref(geom), ptr(row_scale), stream(),
+    call("fod_conv2d_wgrad_acc", dt(dy), ptr(dy), ptr(x), ptr(dw), C.byref(geom), ptr(row_scale),
+         0 if zeroed else 1, stream(),
          work=_conv_flops(geom))
     return dw
 

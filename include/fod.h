@@ -64,9 +64,12 @@ int fod_gemm_nt(int dtype, const void* A, long lda, int a_row_mod, const void* B
 
 /* dW[i,j] += row_scale[i] * sum_m G[m,i] * X[m,j]     G:[M,N1] ldg, X:[M,K2] ldx, dW f32 [N1,K2] ldw
  * colsum (optional, f32 [N1]) += sum_m G[m,i]: the bias gradient from the same pass over G.
- * Replaces autograd's Linear weight/bias gradients (loss.backward(), future_od/trainer.py:180). */
+ * Replaces autograd's Linear weight/bias gradients (loss.backward(), future_od/trainer.py:180).
+ * accumulate = 1: outputs are added to (always correct).  accumulate = 0: the caller guarantees dW and
+ * colsum are all-zero on entry; a launch that needs only one M-split then uses plain stores. */
 int fod_gemm_tn_acc(int dtype, const void* G, long ldg, const void* X, long ldx, float* dW, long ldw,
-                    int M, int N1, int K2, const float* row_scale, float* colsum, fod_stream_t stream);
+                    int M, int N1, int K2, const float* row_scale, float* colsum, int accumulate,
+                    fod_stream_t stream);
 
 /* out[g, n] += sum over rows m of group g of G[m, n];  group g = m / group_rows (group_rows <= 0:
  * one group).  Bias gradients and sums over a broadcast dimension. */
@@ -89,7 +92,7 @@ int fod_conv2d_dgrad(int dtype, const void* dy, const void* w_t, void* dx, const
                      const fod_epilogue* epi, fod_stream_t stream);
 /* dw[co][r][s][ci] += row_scale[co] * sum_pixels dy * x   (f32, channels_last OIHW) */
 int fod_conv2d_wgrad_acc(int dtype, const void* dy, const void* x, float* dw, const fod_conv_geom* g,
-                         const float* row_scale, fod_stream_t stream);
+                         const float* row_scale, int accumulate, fod_stream_t stream);
 
 /* 3x3 stride-2 pad-1 max pooling, NHWC (torchvision ResNet stem; forward only: stem is frozen). */
 int fod_maxpool3x3s2(int dtype, const void* x, void* y, int Nimg, int H, int W, int C, int Ho, int Wo,
