@@ -106,16 +106,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
   const T* __restrict__ Ap = reinterpret_cast<const T*>(p.A);
   const T* __restrict__ Bp = reinterpret_cast<const T*>(p.B);
 
-  // Register staging ring: tile t lives in ring[t % 3]; two tiles are in flight while a third is being
-  // consumed from LDS, so a block alone on its CU (small problems) still overlaps global latency.
-  struct Stage {
-    uint4 a[4];
-    uint4 b[BROWS];
-  };
-  Stage st0, st1, st2;
-  auto load_tile = [&](int kt, Stage& st) {
-    uint4* ra = st.a;
-    uint4* rb = st.b;
+  uint4 ra[4], rb[BROWS];
+  auto load_tile = [&](int kt) {
     const int k = kt * BK + cc * VEC;
     const bool kin = k < p.K;
     int r = 0, s = 0, c = k;
@@ -150,13 +142,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
       rb[i] = v;
     }
   };
-  auto store_tile = [&](int buf, const Stage& st) {
+  auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<uint4*>(sA + buf * BM * ROW_BYTES + lds_off(r0 + 32 * i, cc)) = st.a[i];
+      *reinterpret_cast<uint4*>(sA + buf * BM * ROW_BYTES + lds_off(r0 + 32 * i, cc)) = ra[i];
 #pragma unroll
     for (int i = 0; i < BROWS; ++i)
-      *reinterpret_cast<uint4*>(sB + buf * BN * ROW_BYTES + lds_off(r0 + 32 * i, cc)) = st.b[i];
+      *reinterpret_cast<uint4*>(sB + buf * BN * ROW_BYTES + lds_off(r0 + 32 * i, cc)) = rb[i];
   };
 
   f32x16 acc[2][NT];
@@ -168,13 +160,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nkt = (p.K + BK - 1) / BK;
-  load_tile(0, st0);
-  if (nkt > 1) load_tile(1, st1);
-  store_tile(0, st0);
+  load_tile(0);
+  store_tile(0);
   __syncthreads();
 
   const int fr = lane & 31, fh = lane >> 5;
-  auto compute = [&](int buf) {
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) load_tile(kt + 1);
     const unsigned char* a_s = sA + buf * BM * ROW_BYTES;
     const unsigned char* b_s = sB + buf * BN * ROW_BYTES;
 #pragma unroll
@@ -211,21 +204,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) mma16(fa[i], fb[j], acc[i][j]);
     }
-  };
-  // step k: LDS buffer k&1 holds tile k; tile k+1 is in flight in ring[(k+1)%3]; issue tile k+2.
-#define FOD_NT_STEP(k, LD, ST)                        \
-  if ((k) < nkt) {                                    \
-    if ((k) + 2 < nkt) load_tile((k) + 2, LD);        \
-    compute((k) & 1);                                 \
-    if ((k) + 1 < nkt) store_tile(((k) + 1) & 1, ST); \
-    __syncthreads();                                  \
+    if (kt + 1 < nkt) store_tile(buf ^ 1);
+    __syncthreads();
   }
-  for (int kt = 0; kt < nkt; kt += 3) {
-    FOD_NT_STEP(kt, st2, st1)
-    FOD_NT_STEP(kt + 1, st0, st2)
-    FOD_NT_STEP(kt + 2, st1, st0)
-  }
-#undef FOD_NT_STEP
 
   const T* __restrict__ Rp = reinterpret_cast<const T*>(p.res);
   const T* __restrict__ Mp = reinterpret_cast<const T*>(p.mask);

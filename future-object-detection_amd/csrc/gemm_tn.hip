@@ -101,15 +101,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     xs = tap - xr * p.kw;
   }
 
-  // register staging ring (step t in ring[t % 3], two steps in flight): see gemm_nt.hip
-  struct Stage {
-    uint4 g[PASSES];
-    uint4 x[PASSES];
-  };
-  Stage st0, st1, st2;
-  auto load_step = [&](int m_start, Stage& st) {
-    uint4* rg = st.g;
-    uint4* rx = st.x;
+  uint4 rg[PASSES], rx[PASSES];
+  auto load_step = [&](int m_start) {
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const int m = m_start + prow + ps * RPP;
@@ -139,15 +132,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 #pragma unroll
   for (int e = 0; e < VEC; ++e) csum[e] = 0.f;
   const bool do_colsum = p.colsum != nullptr && blockIdx.x == 0;
-  auto store_step = [&](int buf, const Stage& st) {
+  auto store_step = [&](int buf) {
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const int row = prow + ps * RPP;
-      *reinterpret_cast<uint4*>(sGb[buf] + row * PITCH + chunk * 16) = st.g[ps];
-      *reinterpret_cast<uint4*>(sXb[buf] + row * PITCH + chunk * 16) = st.x[ps];
+      *reinterpret_cast<uint4*>(sGb[buf] + row * PITCH + chunk * 16) = rg[ps];
+      *reinterpret_cast<uint4*>(sXb[buf] + row * PITCH + chunk * 16) = rx[ps];
       if (do_colsum) {
         T tmp[VEC];
-        __builtin_memcpy(tmp, &st.g[ps], 16);
+        __builtin_memcpy(tmp, &rg[ps], 16);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) csum[e] += to_f32(tmp[e]);
       }
@@ -162,12 +155,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const int nst = mb < mend ? (mend - mb + MSTEP - 1) / MSTEP : 0;
-  if (nst > 0) load_step(mb, st0);
-  if (nst > 1) load_step(mb + MSTEP, st1);
-  if (nst > 0) store_step(0, st0);
+  int buf = 0;
+  if (mb < mend) {
+    load_step(mb);
+    store_step(0);
+  }
   __syncthreads();
-  auto compute = [&](int buf) {
+  for (int ms = mb; ms < mend; ms += MSTEP) {
+    const bool more = ms + MSTEP < mend;
+    if (more) load_step(ms + MSTEP);
     const unsigned char* sG = sGb[buf];
     const unsigned char* sX = sXb[buf];
 #pragma unroll
@@ -182,20 +178,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) mma16(fa[a], fb[b], acc[a][b]);
     }
-  };
-#define FOD_TN_STEP(k, LD, ST)                                   \
-  if ((k) < nst) {                                               \
-    if ((k) + 2 < nst) load_step(mb + ((k) + 2) * MSTEP, LD);    \
-    compute((k) & 1);                                            \
-    if ((k) + 1 < nst) store_step(((k) + 1) & 1, ST);            \
-    __syncthreads();                                             \
+    if (more) store_step(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
   }
-  for (int t = 0; t < nst; t += 3) {
-    FOD_TN_STEP(t, st2, st1)
-    FOD_TN_STEP(t + 1, st0, st2)
-    FOD_TN_STEP(t + 2, st1, st0)
-  }
-#undef FOD_TN_STEP
   if (do_colsum && g_ok) {
     // threads sharing a chunk (same columns, different rows) differ by multiples of CHR: reduce through LDS
     float* red = reinterpret_cast<float*>(sGb[0]);       // 256 * VEC floats <= one staging buffer
