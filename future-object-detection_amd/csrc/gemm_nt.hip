@@ -38,6 +38,7 @@ struct NtParams {
   int relu;
   int c_is_f32;
   int vec_epi;   // host-checked: N, ldc, ldr, ldmask multiples of 4 and 16-byte aligned bases
+  unsigned a_bytes, b_bytes;   // extents of A and B for the buffer descriptors (< 4 GiB, host-checked)
   // gather geometry
   int Hs, Ws, Cs;   // source image dims / channels
   int Hd, Wd;       // m-domain dims
@@ -69,8 +70,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
   const int cc = tid & 7;     // 16-byte chunk column handled by this thread
   const int r0 = tid >> 3;    // first tile row handled by this thread (then +32, +64, +96)
 
-  // ---- per-row gather state (fixed over the k loop)
-  long a_base[4];
+  // Operands are read with raw buffer loads: an out-of-range chunk (row tail, k tail, conv padding) gets the
+  // byte offset OOB, which the hardware range check turns into zeros -- no branch and no select around
+  // the load, so hipcc keeps counted vmcnt waits and the staged tile stays in flight during the MFMAs.
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
+
+  // ---- per-row gather state (fixed over the k loop); offsets in BYTES
+  unsigned a_base[4];
   int a_h[4], a_w[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -78,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
     const bool valid = m < p.M;
     if (MODE == MODE_DENSE) {
       const int row = p.a_row_mod > 0 ? (m % p.a_row_mod) : m;
-      a_base[i] = valid ? (long)row * p.lda : -1;
+      a_base[i] = valid ? (unsigned)((long)row * p.lda * (long)sizeof(T)) : OOB;
       a_h[i] = a_w[i] = 0;
     } else {
       const int hw = p.Hd * p.Wd;
@@ -86,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
       const int rem = m - img * hw;
       const int ph = rem / p.Wd;
       const int pw = rem - ph * p.Wd;
-      a_base[i] = (long)img * p.Hs * p.Ws * p.Cs;
+      a_base[i] = (unsigned)((long)img * p.Hs * p.Ws * p.Cs * (long)sizeof(T));
       if (MODE == MODE_CONV) {
         a_h[i] = valid ? ph * p.stride - p.pad : -(1 << 28);
         a_w[i] = pw * p.stride - p.pad;
@@ -96,18 +104,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
       }
     }
   }
-  long b_base[BROWS];
+  unsigned b_base[BROWS];
 #pragma unroll
   for (int i = 0; i < BROWS; ++i) {
     const int n = n0 + r0 + 32 * i;
-    b_base[i] = (n < p.N) ? (long)n * p.ldb : -1;
+    b_base[i] = (n < p.N) ? (unsigned)((long)n * p.ldb * (long)sizeof(T)) : OOB;
   }
 
-  const T* __restrict__ Ap = reinterpret_cast<const T*>(p.A);
-  const T* __restrict__ Bp = reinterpret_cast<const T*>(p.B);
-
-  uint4 ra[4], rb[BROWS];
-  auto load_tile = [&](int kt) {
+  auto bload = [](const auto& rs, unsigned off) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+    uint4 u;
+    __builtin_memcpy(&u, &v, 16);
+    return u;
+  };
+  // Register staging ring: tile t lives in ring[t % 3]; two tiles are in flight while a third is consumed
+  // from LDS, so a block that is alone on its CU (small problems) still overlaps global latency.
+  struct Stage {
+    uint4 a[4];
+    uint4 b[BROWS];
+  };
+  Stage st0, st1, st2;
+  auto load_tile = [&](int kt, Stage& st) {
+    uint4* ra = st.a;
+    uint4* rb = st.b;
     const int k = kt * BK + cc * VEC;
     const bool kin = k < p.K;
     int r = 0, s = 0, c = k;
@@ -117,38 +136,35 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
       r = tap / p.kw;
       s = tap - r * p.kw;
     }
+    const unsigned kb = (unsigned)k * (unsigned)sizeof(T);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
+      unsigned off;
       if (MODE == MODE_DENSE) {
-        if (kin && a_base[i] >= 0) v = *reinterpret_cast<const uint4*>(Ap + a_base[i] + k);
+        off = (kin && a_base[i] != OOB) ? a_base[i] + kb : OOB;
       } else if (MODE == MODE_CONV) {
         const int hs = a_h[i] + r, ws = a_w[i] + s;
-        if (kin && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws)
-          v = *reinterpret_cast<const uint4*>(Ap + a_base[i] + ((long)hs * p.Ws + ws) * p.Cs + c);
+        const bool ok = kin && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
+        off = ok ? a_base[i] + (unsigned)((hs * p.Ws + ws) * p.Cs + c) * (unsigned)sizeof(T) : OOB;
       } else {
         const int th = a_h[i] - r, tw = a_w[i] - s;
         const int sm = p.stride - 1;   // stride is 1 or 2
         const int hs = th >> (p.stride >> 1), ws = tw >> (p.stride >> 1);
-        if (kin && th >= 0 && tw >= 0 && ((th | tw) & sm) == 0 && hs < p.Hs && ws < p.Ws)
-          v = *reinterpret_cast<const uint4*>(Ap + a_base[i] + ((long)hs * p.Ws + ws) * p.Cs + c);
+        const bool ok = kin && th >= 0 && tw >= 0 && ((th | tw) & sm) == 0 && hs < p.Hs && ws < p.Ws;
+        off = ok ? a_base[i] + (unsigned)((hs * p.Ws + ws) * p.Cs + c) * (unsigned)sizeof(T) : OOB;
       }
-      ra[i] = v;
+      ra[i] = bload(rsA, off);
     }
 #pragma unroll
-    for (int i = 0; i < BROWS; ++i) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (kin && b_base[i] >= 0) v = *reinterpret_cast<const uint4*>(Bp + b_base[i] + k);
-      rb[i] = v;
-    }
+    for (int i = 0; i < BROWS; ++i) rb[i] = bload(rsB, (kin && b_base[i] != OOB) ? b_base[i] + kb : OOB);
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const Stage& st) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<uint4*>(sA + buf * BM * ROW_BYTES + lds_off(r0 + 32 * i, cc)) = ra[i];
+      *reinterpret_cast<uint4*>(sA + buf * BM * ROW_BYTES + lds_off(r0 + 32 * i, cc)) = st.a[i];
 #pragma unroll
     for (int i = 0; i < BROWS; ++i)
-      *reinterpret_cast<uint4*>(sB + buf * BN * ROW_BYTES + lds_off(r0 + 32 * i, cc)) = rb[i];
+      *reinterpret_cast<uint4*>(sB + buf * BN * ROW_BYTES + lds_off(r0 + 32 * i, cc)) = st.b[i];
   };
 
   f32x16 acc[2][NT];
@@ -160,14 +176,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nkt = (p.K + BK - 1) / BK;
-  load_tile(0);
-  store_tile(0);
+  load_tile(0, st0);
+  if (nkt > 1) load_tile(1, st1);
+  store_tile(0, st0);
   __syncthreads();
 
   const int fr = lane & 31, fh = lane >> 5;
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nkt) load_tile(kt + 1);
+  auto compute = [&](int buf) {
     const unsigned char* a_s = sA + buf * BM * ROW_BYTES;
     const unsigned char* b_s = sB + buf * BN * ROW_BYTES;
 #pragma unroll
@@ -204,9 +219,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) mma16(fa[i], fb[j], acc[i][j]);
     }
-    if (kt + 1 < nkt) store_tile(buf ^ 1);
-    __syncthreads();
+  };
+  // step k: LDS buffer k&1 holds tile k; tile k+1 is in flight in ring[(k+1)%3]; issue tile k+2.
+#define FOD_NT_STEP(k, LD, ST)                        \
+  if ((k) < nkt) {                                    \
+    if ((k) + 2 < nkt) load_tile((k) + 2, LD);        \
+    compute((k) & 1);                                 \
+    if ((k) + 1 < nkt) store_tile(((k) + 1) & 1, ST); \
+    __syncthreads();                                  \
   }
+  for (int kt = 0; kt < nkt; kt += 3) {
+    FOD_NT_STEP(kt, st2, st1)
+    FOD_NT_STEP(kt + 1, st0, st2)
+    FOD_NT_STEP(kt + 2, st1, st0)
+  }
+#undef FOD_NT_STEP
 
   const T* __restrict__ Rp = reinterpret_cast<const T*>(p.res);
   const T* __restrict__ Mp = reinterpret_cast<const T*>(p.mask);
@@ -370,6 +397,12 @@ extern "C" int fod_gemm_nt(int dtype, const void* A, long lda, int a_row_mod, co
   p.a_row_mod = a_row_mod;
   fill_epilogue(p, epi);
   decide_vec_epilogue(p);
+  const long esz = dtype == FOD_BF16 ? 2 : 4;
+  const long a_rows = a_row_mod > 0 ? a_row_mod : M;
+  const long ab = ((a_rows - 1) * lda + K) * esz, bb = ((long)(N - 1) * ldb + K) * esz;
+  FOD_REQUIRE(ab < 0xFFFFFFF0L - 16 && bb < 0xFFFFFFF0L - 16, "gemm_nt: operand larger than 4 GiB");
+  p.a_bytes = (unsigned)ab;
+  p.b_bytes = (unsigned)bb;
   return dispatch_nt<MODE_DENSE>(dtype, p, stream);
 }
 
@@ -406,6 +439,11 @@ static int conv_common(int dtype, bool dgrad, const void* src, const void* w, vo
   p.ldc = p.N;
   fill_epilogue(p, epi);
   decide_vec_epilogue(p);
+  const long esz = dtype == FOD_BF16 ? 2 : 4;
+  const long ab = (long)g->Nimg * p.Hs * p.Ws * p.Cs * esz, bb = (long)p.N * p.K * esz;
+  FOD_REQUIRE(ab < 0xFFFFFFF0L - 16 && bb < 0xFFFFFFF0L - 16, "conv: operand larger than 4 GiB");
+  p.a_bytes = (unsigned)ab;
+  p.b_bytes = (unsigned)bb;
   if (!dgrad) return dispatch_nt<MODE_CONV>(dtype, p, stream);
   return dispatch_nt<MODE_DGRAD>(dtype, p, stream);
 }
