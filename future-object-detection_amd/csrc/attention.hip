@@ -28,6 +28,7 @@ struct AttnParams {
   void *dq1, *dq2, *dk1, *dk2, *dv;
   int B, H, Tq, S;
   long q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
+  long k2_bs, k2_ts, dk2_bs, dk2_ts;   // part-2 keys may be shared by the batch (k2_bs = 0) and have their own pitch
   float scale;
 };
 
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         Frag<T> fk;
-        frag_load_contig(fk, Kp[pt] + (long)b * p.k_bs + (long)kr * p.k_ts + h * 32 + 16 * s + 8 * fh);
+        frag_load_contig(fk, Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)kr * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
         mma16(fk, fq[pt][s], sacc);
       }
     float mx = -INFINITY;
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
 #pragma unroll
       for (int pt = 0; pt < PARTS; ++pt) {
         Frag<T> fk;
-        frag_load_contig(fk, Kp[pt] + (long)b * p.k_bs + (long)kr * p.k_ts + h * 32 + 16 * s + 8 * fh);
+        frag_load_contig(fk, Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)kr * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
         mma16(fk, fq[pt][s], sacc);
       }
       Frag<T> fv;
@@ -234,7 +235,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
 #pragma unroll
       for (int pt = 0; pt < PARTS; ++pt) {
         Frag<T> fkt;   // K^T: row = d (lane), kappa = key
-        frag_gather_accorder(fkt, Kp[pt] + (long)b * p.k_bs + (long)k0 * p.k_ts + h * 32 + fr, p.k_ts, s, fh,
+        frag_gather_accorder(fkt, Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)k0 * (pt ? p.k2_ts : p.k_ts) + h * 32 + fr,
+                             (pt ? p.k2_ts : p.k_ts), s, fh,
                              p.S - k0);
         mma16(fkt, fds, dq[pt]);             // dQ^T[d, q] += sum_k K[k,d] dS^T[k,q]
       }
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
     frag_load_contig(fv[s], Vp + 16 * s + 8 * fh);
 #pragma unroll
     for (int pt = 0; pt < PARTS; ++pt)
-      frag_load_contig(fk[pt][s], Kp[pt] + (long)b * p.k_bs + (long)key * p.k_ts + h * 32 + 16 * s + 8 * fh);
+      frag_load_contig(fk[pt][s], Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)key * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
   }
   const float c = p.scale * LOG2E;
   f32x16 dk[PARTS], dv;
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
     T* d1 = reinterpret_cast<T*>(p.dk1) + (long)b * p.k_bs + (long)key * p.k_ts + h * 32;
     store_acc_t<T>(d1, dk[0], fh, 1.f);
     if (PARTS == 2) {
-      T* d2 = reinterpret_cast<T*>(p.dk2) + (long)b * p.k_bs + (long)key * p.k_ts + h * 32;
+      T* d2 = reinterpret_cast<T*>(p.dk2) + (long)b * p.dk2_bs + (long)key * p.dk2_ts + h * 32;
       store_acc_t<T>(d2, dk[PARTS - 1], fh, 1.f);
     }
   }
@@ -389,11 +391,18 @@ int fill(AttnParams& p, const fod_attn_shape* s) {
   p.B = s->B; p.H = s->H; p.Tq = s->Tq; p.S = s->S;
   p.q_bs = s->q_batch_stride; p.q_ts = s->q_token_stride;
   p.k_bs = s->k_batch_stride; p.k_ts = s->k_token_stride;
+  const bool own2 = s->k2_token_stride != 0;
+  p.k2_bs = own2 ? s->k2_batch_stride : p.k_bs;
+  p.k2_ts = own2 ? s->k2_token_stride : p.k_ts;
+  const bool ownd = s->dk2_token_stride != 0;
+  p.dk2_bs = ownd ? s->dk2_batch_stride : p.k_bs;
+  p.dk2_ts = ownd ? s->dk2_token_stride : p.k_ts;
   p.v_bs = s->v_batch_stride; p.v_ts = s->v_token_stride;
   p.o_bs = s->o_batch_stride; p.o_ts = s->o_token_stride;
   p.scale = s->scale;
   FOD_REQUIRE(p.q_ts % 8 == 0 && p.k_ts % 8 == 0 && p.v_ts % 8 == 0 && p.o_ts % 8 == 0 && p.q_bs % 8 == 0 &&
-                  p.k_bs % 8 == 0 && p.v_bs % 8 == 0 && p.o_bs % 8 == 0,
+                  p.k_bs % 8 == 0 && p.v_bs % 8 == 0 && p.o_bs % 8 == 0 && p.k2_bs % 8 == 0 && p.k2_ts % 8 == 0 &&
+                  p.dk2_bs % 8 == 0 && p.dk2_ts % 8 == 0,
               "attention: strides must be multiples of 8 elements");
   return FOD_OK;
 }

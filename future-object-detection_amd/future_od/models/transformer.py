@@ -134,25 +134,25 @@ class SlotToImageAttention(Attention):
         self.D, self.Nhead = D, Nhead
         self.store_attention = False
 
-    def forward(self, x, qpos, query_sine, mem, mem_pos, is_first):
+    def forward(self, x, qpos, query_sine, side, layer, image, is_first):
+        """`side` (functional.MemorySide) holds this image's value / key_content projections for ALL layers
+        and the projected positional table; this call uses the (layer, image) slots."""
         B, M, D = x.shape
-        N = mem.shape[1]
-        v = _lin(mem, self.value)
         qc = _lin(x, self.query_content)
         if is_first:
             qc = Fn.add(qc, _lin(qpos, self.query_pos), b_row_mod=M)
         qs = _lin(query_sine, self.query_sine)
         if qs.dim() == 2:
             qs = Fn.expand_rows(qs, B).view(B, M, D)
-        ks_tab = _lin(mem_pos, self.key_pos)                       # [N, D], batch independent
-        kc = _lin(mem, self.key_content)
         if is_first:
-            kc = Fn.add(kc, ks_tab, b_row_mod=N)
-        ks = Fn.expand_rows(ks_tab, B).view(B, N, D)
+            # reference: k_content += k_sine in the first layer.  q_c.(k_c + k_s) + q_s.k_s == q_c.k_c + (q_c + q_s).k_s,
+            # so the addition moves to the (tiny) query side and the key slots are used as they are
+            qs = Fn.add(qs, qc)
         # per head: q = [qc | qs], k = [kc | ks] (64 wide), scale (2D/heads)^-0.5
-        a = Fn.attention(qc, kc, v, 1.0 / math.sqrt(2 * D // self.Nhead), q2=qs, k2=ks)
+        a = Fn.hoisted_cross_attention(qc, qs, side, layer, image, 1.0 / math.sqrt(2 * D // self.Nhead))
         if self.store_attention:
-            self.stored_attention = _head_mean_weights(qc, kc, qs, ks, self.Nhead)
+            kc, ks, _v = side.slots(layer, image)
+            self.stored_attention = _head_mean_weights(qc, kc, qs, ks.unsqueeze(0).expand(B, -1, -1), self.Nhead)
         return _lin(a, self.fun.out_proj)
 
 
@@ -187,11 +187,11 @@ class TransformerDecoderLayer(nn.Module):
         self.norm_out = nn.LayerNorm(D)
         self.Nhead, self.D = Nhead, D
 
-    def forward(self, x, qpos, query_sine, mems, mem_poss, is_first=False):
+    def forward(self, x, qpos, query_sine, side, layer, is_first=False):
         o = self.self_attend(x, qpos)
         x = Fn.layer_norm(x, self.norm_sa.weight, self.norm_sa.bias, residual=o)
-        for i, (mem, mpos) in enumerate(zip(mems, mem_poss)):
-            o = self.image_attend[i](x, qpos, query_sine, mem, mpos, is_first)
+        for i in range(side.K):
+            o = self.image_attend[i](x, qpos, query_sine, side, layer, i, is_first)
             x = Fn.layer_norm(x, self.norm_ia[i].weight, self.norm_ia[i].bias, residual=o)
         h = _lin(x, self.feedforward[0], relu=True)
         return Fn.layer_norm(x, self.norm_out.weight, self.norm_out.bias, residual=_lin(h, self.feedforward[3]))
@@ -218,6 +218,14 @@ class TransformerDecoder(nn.Module):
         """x [B,M,D] query content; qpos [M,D] learned query positions (shared by the batch)."""
         B, M, D = x.shape
         ref, sine0 = Fn.RefPointSineFn.apply(self.ref_point_head(qpos), D)     # [M,2] f32, [M,D]
+        # memory side, hoisted out of the layer loop: one GEMM per image for every layer's value /
+        # key_content projection, one GEMM for every (layer, image) key_pos projection of the table
+        K = len(mems)
+        big = [Fn.wide_linear(mems[j], [m for layer in self.layers
+                                        for m in (layer.image_attend[j].value, layer.image_attend[j].key_content)])
+               for j in range(K)]
+        ks_all = Fn.wide_linear(mem_poss[0], [layer.image_attend[j].key_pos for layer in self.layers for j in range(K)])
+        side = Fn.MemorySide(big, ks_all, len(self.layers), K, D)
         inter = []
         for lid, layer in enumerate(self.layers):
             special = lid == 0 and first_layer_special
@@ -225,7 +233,7 @@ class TransformerDecoder(nn.Module):
                 q_sine = sine0
             else:
                 q_sine = Fn.mul(self.query_scale(x).view(B * M, D), sine0, b_row_mod=M).view(B, M, D)
-            x = layer(x, qpos, q_sine, mems, mem_poss, is_first=special)
+            x = layer(x, qpos, q_sine, side, lid, is_first=special)
             if self.return_intermediate:
                 inter.append(Fn.layer_norm(x, self.norm.weight, self.norm.bias))
         if not self.return_intermediate:

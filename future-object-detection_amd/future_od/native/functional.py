@@ -407,3 +407,154 @@ def cast_ad(x, dtype, pad_cols=None):
     if x.dtype == dtype and pad_cols in (None, x.shape[-1]):
         return x
     return CastFn.apply(x.contiguous(), dtype, pad_cols)
+
+
+# ------------------------------------------------------------------------------------------------
+# Memory side of the decoder, hoisted out of the layer loop.
+#
+# The value / key_content projections of an image memory and the key_pos projection of the positional
+# table do not depend on the decoder state, only on (memory, weights).  Instead of 2*L small GEMMs per
+# image inside the layer loop (plus their 4*L backward GEMMs), every image gets ONE GEMM against the
+# row-concatenated weights of all layers, the positional table gets ONE GEMM for all (layer, image)
+# pairs, and each cross-attention reads / writes its [*, D] column slot of those wide buffers through
+# the attention kernels' stride arguments.
+# ------------------------------------------------------------------------------------------------
+class _CatCache:
+    def __init__(self):
+        self.store = {}
+
+    def get(self, weights, biases, dtype):
+        key = (tuple(w.data_ptr() for w in weights), dtype)
+        ver = tuple(w._version for w in weights) + tuple(b._version for b in biases)
+        hit = self.store.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        D_out, D_in = weights[0].shape
+        P = len(weights)
+        wcat = torch.empty((P * D_out, D_in), dtype=dtype, device=weights[0].device)
+        bcat = torch.empty((P * D_out,), dtype=torch.float32, device=weights[0].device)
+        for i, (w, b) in enumerate(zip(weights, biases)):
+            ops.permute3_cast(w.detach(), dtype, (1, D_out, D_in), (0, D_in, 1), out=wcat[i * D_out:(i + 1) * D_out])
+            ops.permute3_cast(b.detach(), torch.float32, (1, 1, D_out), (0, 0, 1), out=bcat[i * D_out:(i + 1) * D_out])
+        wcat_t = ops.permute3_cast(wcat, dtype, (1, D_in, P * D_out), (0, 1, D_in)).view(D_in, P * D_out)
+        val = (wcat, bcat, wcat_t)
+        if len(self.store) > 64:
+            self.store.clear()
+        self.store[key] = (ver, val)
+        return val
+
+
+CAT = _CatCache()
+
+
+class WideLinearFn(Function):
+    """y[*, P*D] = x[*, Din] @ cat_p(W_p)^T + cat_p(b_p): P Linear layers sharing one input, one GEMM.
+    `x_grad=False` for an input without gradient (the positional table).  When `batch_sum` > 1 the
+    incoming gradient is [batch_sum, rows, P*D] although x is [rows, Din] (x was shared by the batch)."""
+
+    @staticmethod
+    def forward(ctx, x, batch_sum, *params):
+        P = len(params) // 2
+        weights, biases = params[:P], params[P:]
+        wcat, bcat, _ = CAT.get(weights, biases, x.dtype)
+        y = ops.gemm_nt(x, wcat, shift=bcat).view(*x.shape[:-1], wcat.shape[0])
+        ctx.save_for_backward(x)
+        ctx.params, ctx.batch_sum = params, batch_sum
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        P = len(ctx.params) // 2
+        weights, biases = ctx.params[:P], ctx.params[P:]
+        D_out, D_in = weights[0].shape
+        _, _, wcat_t = CAT.get(weights, biases, x.dtype)
+        dy = dy.contiguous()
+        if ctx.batch_sum > 1:
+            dy = _sum_leading(dy, ctx.batch_sum)
+        g = dy.view(-1, P * D_out)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm_nt(g, wcat_t).view(x.shape)
+        dw = zeros_f32((P * D_out, D_in), x.device)
+        db = zeros_f32((P * D_out,), x.device)
+        ops.gemm_tn_acc(g, x.view(-1, D_in), dw, colsum=db, zeroed=True)
+        gw = [dw[i * D_out:(i + 1) * D_out] for i in range(P)]
+        gb = [db[i * D_out:(i + 1) * D_out] for i in range(P)]
+        return (dx, None) + tuple(gw) + tuple(gb)
+
+
+def _sum_leading(t, n):
+    """[n, ...] -> [...] : sum over the (tiny) leading dim."""
+    acc = t[0]
+    for i in range(1, n):
+        acc = ops.eltwise(L.EW_ADD, acc.contiguous(), t[i].contiguous())
+    return acc.contiguous()
+
+
+def wide_linear(x, linears, batch_sum=1):
+    ws = [m.weight for m in linears]
+    bs = [m.bias for m in linears]
+    return WideLinearFn.apply(x.contiguous(), batch_sum, *ws, *bs)
+
+
+class MemorySide:
+    """Per-forward holder of the hoisted projections and of the gradient buffers their slots are written to."""
+
+    def __init__(self, big, ks_all, n_layers, n_images, D):
+        self.big = big              # list over images: [B, N, 2*L*D]  (per layer: [value | key_content])
+        self.ks_all = ks_all        # [N, L*K*D]                         (per (layer, image): key_pos(pos))
+        self.L, self.K, self.D = n_layers, n_images, D
+        self.dbig = [None] * n_images
+        self.dks = None
+
+    def slots(self, layer, image):
+        D = self.D
+        b = self.big[image]
+        v = b[..., (2 * layer) * D:(2 * layer + 1) * D]
+        kc = b[..., (2 * layer + 1) * D:(2 * layer + 2) * D]
+        q = layer * self.K + image
+        ks = self.ks_all[:, q * D:(q + 1) * D]
+        return kc, ks, v
+
+
+class HoistedCrossAttnFn(Function):
+    """softmax((q1.kc + q2.ks) * scale) v with kc / v / ks taken as column slots of the hoisted buffers.
+    Gradients of the slots are written in place into MemorySide.dbig / .dks; the buffers are handed to
+    autograd once, by the call that runs LAST in the backward sweep (layer 0; image 0 for ks), when every
+    slot has been filled -- all earlier (higher-layer) calls return None for them."""
+
+    @staticmethod
+    def forward(ctx, q1, q2, big_j, ks_all, side, layer, image, scale):
+        kc, ks, v = side.slots(layer, image)
+        o, lse2 = ops.attn_fwd(q1, kc, v, scale, q2, ks)
+        ctx.save_for_backward(q1, q2, o, lse2)
+        ctx.side, ctx.layer, ctx.image, ctx.scale = side, layer, image, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q1, q2, o, lse2 = ctx.saved_tensors
+        side, layer, image, D = ctx.side, ctx.layer, ctx.image, ctx.side.D
+        kc, ks, v = side.slots(layer, image)
+        if side.dbig[image] is None:
+            side.dbig[image] = torch.empty_like(side.big[image])
+        if side.dks is None:
+            B = q1.shape[0]
+            side.dks = torch.empty((B,) + tuple(side.ks_all.shape), dtype=side.ks_all.dtype, device=q1.device)
+        db = side.dbig[image]
+        dv = db[..., (2 * layer) * D:(2 * layer + 1) * D]
+        dkc = db[..., (2 * layer + 1) * D:(2 * layer + 2) * D]
+        qi = layer * side.K + image
+        dks = side.dks[..., qi * D:(qi + 1) * D]
+        dq1, _, dq2, _, _ = ops.attn_bwd(q1, kc, v, o, do.contiguous(), lse2, ctx.scale, q2, ks,
+                                         dk1_out=dkc, dv_out=dv, dk2_out=dks)
+        g_big = side.dbig[image] if layer == 0 else None
+        # ks_all is shared by the batch: its gradient is the sum of the per-batch slots
+        g_ks = _sum_leading(side.dks, side.dks.shape[0]) if (layer == 0 and image == 0) else None
+        return dq1, dq2, g_big, g_ks, None, None, None, None
+
+
+def hoisted_cross_attention(q1, q2, side, layer, image, scale):
+    return HoistedCrossAttnFn.apply(q1.contiguous(), q2.contiguous(), side.big[image], side.ks_all, side, layer,
+                                    image, scale)

@@ -36,7 +36,9 @@ class AttnShape(C.Structure):
                 ("k_batch_stride", C.c_long), ("k_token_stride", C.c_long),
                 ("v_batch_stride", C.c_long), ("v_token_stride", C.c_long),
                 ("o_batch_stride", C.c_long), ("o_token_stride", C.c_long),
-                ("scale", C.c_float)]
+                ("scale", C.c_float),
+                ("k2_batch_stride", C.c_long), ("k2_token_stride", C.c_long),
+                ("dk2_batch_stride", C.c_long), ("dk2_token_stride", C.c_long)]
 
 
 _i, _l, _f, _p = C.c_int, C.c_long, C.c_float, C.c_void_p

@@ -198,11 +198,14 @@ def clip_to_nhwc_frame_major(video, dtype, cpad):
     return out
 
 
-def permute3_cast(src, dst_dtype, dims, strides, valid2=None, scale=None, scale_axis=-1):
+def permute3_cast(src, dst_dtype, dims, strides, valid2=None, scale=None, scale_axis=-1, out=None):
     """dst[i0,i1,i2] = src.flat[i0*s0+i1*s1+i2*s2] * scale[...]; src f32/bf16 (any strides as given)."""
     assert src.is_cuda
     d0, d1, d2 = dims
-    out = torch.empty(dims, dtype=dst_dtype, device=src.device)
+    if out is None:
+        out = torch.empty(dims, dtype=dst_dtype, device=src.device)
+    else:
+        assert out.is_contiguous() and out.dtype == dst_dtype and out.numel() == d0 * d1 * d2
     v2 = d2 if valid2 is None else valid2
     span = 1 + (d0 - 1) * strides[0] + (d1 - 1) * strides[1] + (v2 - 1) * strides[2]
     assert span <= src.untyped_storage().nbytes() // src.element_size() - src.storage_offset(), (dims, strides)
@@ -214,23 +217,52 @@ def permute3_cast(src, dst_dtype, dims, strides, valid2=None, scale=None, scale_
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def _attn_shape(q, k, v, scale):
-    B, Tq, E = q.shape
-    S = k.shape[1]
-    assert E % 32 == 0 and k.shape == (B, S, E) and v.shape == (B, S, E), (q.shape, k.shape, v.shape)
+def _bt(t, name, dtype):
+    """(batch_stride, token_stride) of a [B,T,E] tensor (or a batch-shared [T,E] table: batch stride 0)
+    whose channel dim is contiguous; strides in elements, multiples of 8."""
+    if not t.is_cuda or t.dtype != dtype:
+        raise L.FodError(f"{name}: expected a {dtype} device tensor")
+    if t.stride(-1) != 1:
+        raise L.FodError(f"{name}: channel dim must be contiguous, strides {t.stride()}")
+    bs, ts = (0, t.stride(0)) if t.dim() == 2 else (t.stride(0), t.stride(1))
+    if bs % 8 or ts % 8 or t.data_ptr() % 16:
+        raise L.FodError(f"{name}: strides/pointer must be 16-byte multiples, got {t.stride()}")
+    return bs, ts
+
+
+def _attn_shape(q1, k1, v, o, scale, k2=None, dk2=None):
+    dtp = q1.dtype
+    B, Tq, E = q1.shape
+    S = k1.shape[1]
+    assert E % 32 == 0 and k1.shape == (B, S, E) and v.shape == (B, S, E) and o.shape == (B, Tq, E), \
+        (q1.shape, k1.shape, v.shape, o.shape)
     H = E // 32
-    return AttnShape(B, H, Tq, S, Tq * E, E, S * E, E, S * E, E, Tq * E, E, scale), H
+    qb, qt = _bt(q1, "q1", dtp)
+    kb, kt = _bt(k1, "k1", dtp)
+    vb, vt = _bt(v, "v", dtp)
+    ob, ot = _bt(o, "o", dtp)
+    k2b = k2t = d2b = d2t = 0
+    if k2 is not None:
+        assert k2.shape[-2:] == (S, E)
+        k2b, k2t = _bt(k2, "k2", dtp)
+    if dk2 is not None:
+        assert dk2.shape == (B, S, E)
+        d2b, d2t = _bt(dk2, "dk2", dtp)
+    return AttnShape(B, H, Tq, S, qb, qt, kb, kt, vb, vt, ob, ot, scale, k2b, k2t, d2b, d2t), H
+
+
+def _same_bt(a, b, name):
+    if a.shape != b.shape or a.stride() != b.stride():
+        raise L.FodError(f"{name}: gradient slot must have the layout of its operand ({a.stride()} vs {b.stride()})")
 
 
 def attn_fwd(q1, k1, v, scale, q2=None, k2=None):
-    """[B,T,H*32] tensors; returns (o [B,Tq,H*32], lse2 f32 [B,H,Tq])."""
-    for t, n in ((q1, "q1"), (k1, "k1"), (v, "v")):
-        _chk(t, n, q1.dtype)
+    """q* [B,Tq,H*32], k1/v [B,S,H*32] (any batch/token strides), k2 [B,S,E] or a batch-shared table [S,E];
+    returns (o [B,Tq,H*32] contiguous, lse2 f32 [B,H,Tq])."""
+    o = torch.empty(q1.shape, dtype=q1.dtype, device=q1.device)
     if q2 is not None:
-        _chk(q2, "q2", q1.dtype); _chk(k2, "k2", q1.dtype)
-        assert q2.shape == q1.shape and k2.shape == k1.shape
-    shp, H = _attn_shape(q1, k1, v, scale)
-    o = torch.empty_like(q1)
+        _same_bt(q1, q2, "q2")
+    shp, H = _attn_shape(q1, k1, v, o, scale, k2)
     lse2 = torch.empty((q1.shape[0], H, q1.shape[1]), dtype=torch.float32, device=q1.device)
     parts = 2 if q2 is not None else 1
     call("fod_attn_fwd", dt(q1), ptr(q1), ptr(k1), ptr(q2), ptr(k2), ptr(v), ptr(o), ptr(lse2),
@@ -238,18 +270,25 @@ def attn_fwd(q1, k1, v, scale, q2=None, k2=None):
     return o, lse2
 
 
-def attn_bwd(q1, k1, v, o, dout, lse2, scale, q2=None, k2=None):
-    for t, n in ((q1, "q1"), (k1, "k1"), (v, "v"), (o, "o"), (dout, "dout")):
-        _chk(t, n, q1.dtype)
+def attn_bwd(q1, k1, v, o, dout, lse2, scale, q2=None, k2=None, dk1_out=None, dv_out=None, dk2_out=None):
+    """Gradients (dq1, dk1, dq2, dk2, dv).  dk1_out / dv_out / dk2_out: optional destinations (e.g. slots of a
+    larger gradient buffer); dk1_out / dv_out must have k1's / v's strides, dk2_out is always per batch element."""
     _chk(lse2, "lse2", torch.float32)
-    assert o.shape == q1.shape and dout.shape == q1.shape
-    shp, H = _attn_shape(q1, k1, v, scale)
-    assert lse2.shape == (q1.shape[0], H, q1.shape[1])
-    dq1, dk1, dv = torch.empty_like(q1), torch.empty_like(k1), torch.empty_like(v)
+    _chk(o, "o", q1.dtype); _chk(dout, "dout", q1.dtype)
+    assert dout.shape == q1.shape
+    dq1 = torch.empty(q1.shape, dtype=q1.dtype, device=q1.device)
+    _same_bt(dq1, q1, "q1 (must be contiguous)")
+    dk1 = dk1_out if dk1_out is not None else torch.empty_strided(k1.shape, k1.stride(), dtype=k1.dtype, device=k1.device)
+    dv = dv_out if dv_out is not None else torch.empty_strided(v.shape, v.stride(), dtype=v.dtype, device=v.device)
+    _same_bt(dk1, k1, "dk1"); _same_bt(dv, v, "dv")
     dq2 = dk2 = None
     if q2 is not None:
-        _chk(q2, "q2", q1.dtype); _chk(k2, "k2", q1.dtype)
-        dq2, dk2 = torch.empty_like(q2), torch.empty_like(k2)
+        _same_bt(q1, q2, "q2")
+        dq2 = torch.empty_like(dq1)
+        B, S, E = k1.shape
+        dk2 = dk2_out if dk2_out is not None else torch.empty((B, S, E), dtype=k1.dtype, device=k1.device)
+    shp, H = _attn_shape(q1, k1, v, o, scale, k2, dk2)
+    assert lse2.shape == (q1.shape[0], H, q1.shape[1])
     delta = torch.empty_like(lse2)
     call("fod_attn_bwd", dt(q1), ptr(q1), ptr(k1), ptr(q2), ptr(k2), ptr(v), ptr(o), ptr(dout), ptr(lse2),
          ptr(delta), ptr(dq1), ptr(dk1), ptr(dq2), ptr(dk2), ptr(dv), C.byref(shp), stream(),

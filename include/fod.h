@@ -118,6 +118,10 @@ typedef struct fod_attn_shape {
   long v_batch_stride, v_token_stride;   /* v, dv */
   long o_batch_stride, o_token_stride;   /* o, dout */
   float scale;                           /* applied to the raw score */
+  /* optional (0 = same as k_*): part-2 keys with their own pitch; k2_batch_stride = 0 shares one key
+   * table across the batch (the projected positional table).  dk2 is always written per batch element. */
+  long k2_batch_stride, k2_token_stride;
+  long dk2_batch_stride, dk2_token_stride;
 } fod_attn_shape;
 
 /* o = softmax((q1.k1 + q2.k2) * scale) v per head; head h = channels [32h, 32h+32) of every tensor.
