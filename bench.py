@@ -76,16 +76,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="tiny shapes, gloo backend, every rank on cuda:0: exercises the N>1 code path on a 1-GPU box")
     a = ap.parse_args()
+    global T_FRAMES, HEIGHT, WIDTH
+    if a.rehearse:
+        T_FRAMES, HEIGHT, WIDTH = 4, 128, 192
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    if a.rehearse:
+        local = 0
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend="gloo" if a.rehearse else "nccl", init_method="env://")
     assert world == a.gpus or not distributed, (world, a.gpus)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
@@ -156,6 +163,7 @@ def main():
         top = sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])
         name, rec = top[0]
         achieved = rec["work"] / rec["seconds"] / 1e12
+        result["device_ms_per_step_profiled"] = 1e3 * total / nprof
         result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
                               "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
                               "avg_launch_us": 1e6 * rec["seconds"] / rec["calls"], "launches_per_step": rec["calls"] / nprof,
