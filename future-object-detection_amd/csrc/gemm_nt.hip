@@ -15,6 +15,8 @@
 // Tile 128 x (64|128) x 128 bytes-of-k, 256 threads = 4 waves (2x2), 32x32 MFMA tiles, double-buffered
 // LDS with one barrier per k-tile, register-staged global->LDS copies, XOR-swizzled 16-byte chunks
 // (chunk ^ ((row>>1)&7): conflict-free for ds_read_b128 fragments and ds_write_b128 staging).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -241,6 +243,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
     // ---- epilogue A: accumulators -> LDS (f32 tile, reusing the staging buffers; the k-loop ended on a
     // barrier) -> whole rows back out, 4 columns per lane: 32 (BN=128) or 16 lanes cover one row, so every
     // global access of the tile (store, residual, mask) is a full 8/16-byte-per-lane coalesced segment.
+    // The residual / mask rows of a whole batch of passes are requested up front (clamped addresses, no
+    // branches) so their latency overlaps the LDS staging instead of being paid once per row.
+    typedef typename std::conditional<sizeof(T) == 2, bf16x4_t, f32x4>::type VT;
+    constexpr int CPR = BN / 4;              // 4-column chunks per row
+    constexpr int RPP = 256 / CPR;           // rows per pass
+    constexpr int NPASS = BM / RPP;
+    constexpr int PB = sizeof(T) == 2 ? NPASS : NPASS / 2;   // passes per prefetch batch (register budget)
+    const int cq = tid % CPR, rq = tid / CPR;
+    const int n = n0 + cq * 4;
+    const int nc = min(n, p.N - 4);          // clamped column for the prefetches (N % 4 == 0)
+    VT rres[PB], rmsk[PB];
+    auto prefetch = [&](int base) {
+#pragma unroll
+      for (int ps = 0; ps < PB; ++ps) {
+        const int m = min(m0 + rq + (base + ps) * RPP, p.M - 1);
+        if (Rp) {
+          const int rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
+          rres[ps] = *reinterpret_cast<const VT*>(Rp + (long)rm * p.ldr + nc);
+        }
+        if (Mp) rmsk[ps] = *reinterpret_cast<const VT*>(Mp + (long)m * p.ldmask + nc);
+      }
+    };
+    prefetch(0);
     float* sC = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -250,52 +275,37 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
         for (int r = 0; r < 16; ++r)
           sC[(wm * 64 + i * 32 + acc_row(r, lane)) * BN + wn * (32 * NT) + j * 32 + fr] = acc[i][j][r];
     __syncthreads();
-    constexpr int CPR = BN / 4;              // 4-column chunks per row
-    constexpr int RPP = 256 / CPR;           // rows per pass
-    const int cq = tid % CPR, rq = tid / CPR;
-    const int n = n0 + cq * 4;
-    if (n < p.N) {
-      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-      if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-#pragma unroll 4
-      for (int row = rq; row < BM; row += RPP) {
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + nc);
+    if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + nc);
+#pragma unroll
+    for (int base = 0; base < NPASS; base += PB) {
+      if (base > 0) prefetch(base);
+#pragma unroll
+      for (int ps = 0; ps < PB; ++ps) {
+        const int row = rq + (base + ps) * RPP;
         const int m = m0 + row;
-        if (m >= p.M) break;
         f32x4 v = *reinterpret_cast<const f32x4*>(sC + row * BN + cq * 4);
         v = v * sc + sh;
         if (Rp) {
-          const int rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
-          const T* rp = Rp + (long)rm * p.ldr + n;
-          if (sizeof(T) == 2) {
-            const bf16x4_t rv = *reinterpret_cast<const bf16x4_t*>(rp);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
-          } else {
-            v += *reinterpret_cast<const f32x4*>(rp);
-          }
+          for (int e = 0; e < 4; ++e) v[e] += (float)rres[ps][e];
         }
         if (p.relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (Mp) {
-          const T* mp = Mp + (long)m * p.ldmask + n;
-          if (sizeof(T) == 2) {
-            const bf16x4_t mv = *reinterpret_cast<const bf16x4_t*>(mp);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ((float)mv[e] > 0.f) ? v[e] : 0.f;
-          } else {
-            const f32x4 mv = *reinterpret_cast<const f32x4*>(mp);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (mv[e] > 0.f) ? v[e] : 0.f;
-          }
+          for (int e = 0; e < 4; ++e) v[e] = ((float)rmsk[ps][e] > 0.f) ? v[e] : 0.f;
         }
-        if (p.c_is_f32 || sizeof(T) == 4) {
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = v;
-        } else {
-          *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(p.C) + (long)m * p.ldc + n) =
-              bf16x4_t{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        if (m < p.M && n < p.N) {
+          if (p.c_is_f32 || sizeof(T) == 4) {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = v;
+          } else {
+            *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(p.C) + (long)m * p.ldc + n) =
+                bf16x4_t{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+          }
         }
       }
     }

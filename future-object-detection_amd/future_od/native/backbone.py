@@ -164,7 +164,8 @@ class BackboneFn(Function):
             co, ci, kh, kw = cw.weight.shape
             dw = Fn.zeros_f32((co, kh, kw, ci), dev)
             ops.conv2d_wgrad_acc(gy, xin, dw, geom, row_scale=scale, zeroed=True)
-            grads[id(cw.weight)] = dw.permute(0, 3, 1, 2)       # OIHW view, channels_last strides
+            # OIHW view of the [co][kh][kw][ci] buffer (channels_last strides; plain view for 1x1 kernels)
+            grads[id(cw.weight)] = dw.view(co, ci, 1, 1) if kh == 1 and kw == 1 else dw.permute(0, 3, 1, 2)
 
         if proj.weight.requires_grad:
             wgrad(g, ctx.x_last, proj, ctx.geom_p, None)
