@@ -54,6 +54,57 @@ FOD_DEVINL void store_acc_t(T* rowptr, const f32x16& acc, int fh, float mul) {
               acc[4 * g + 3] * mul);
 }
 
+// Column-wise ("transposed") operand fragments of a [32 rows][32 cols] tile whose rows are `stride` elements
+// apart in memory (V^T for O^T += V^T.P^T, K^T for dQ, dO^T / Q^T for dV / dK), rows in acc-order kappa:
+//   f32 : gathered straight from global, one dword per lane per element (coalesced over the 32 columns);
+//   bf16: the wave stages the tile in its private 2 KB LDS slab with two 16-byte loads per lane and reads it
+//         back transposed with ds_read_b64_tr_b16 (a 2-byte global gather costs 16 load instructions per
+//         fragment pair and is address-unit bound).  64-byte LDS rows: the four rows of a 16-lane group land
+//         16 banks apart and the two column halves 8 banks apart -> conflict-free.
+//   Wave-private, so no barrier: LDS operations of one wave execute in order.
+template <typename T>
+struct TransTile;
+template <>
+struct TransTile<float> {
+  const float* base;
+  long stride;
+  int nrows;
+  FOD_DEVINL void stage(const float* b, long st, int nr, unsigned char*, int) {
+    base = b; stride = st; nrows = nr;
+  }
+  FOD_DEVINL void frag(Frag<float>& f, int s, int lane) const {
+    frag_gather_accorder(f, base + (lane & 31), stride, s, lane >> 5, nrows);
+  }
+};
+template <>
+struct TransTile<__bf16> {
+  const unsigned char* lds;
+  FOD_DEVINL void stage(const __bf16* b, long st, int nr, unsigned char* slab, int lane) {
+    const int chunk = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (lane >> 2) + 16 * i;
+      const int rc = min(row, nr - 1);                      // clamped (nr >= 1), zeroed below if out of range
+      uint4 v = *reinterpret_cast<const uint4*>(b + (long)rc * st + chunk * 8);
+      if (row >= nr) v = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(slab + row * 64 + chunk * 16) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lds = slab;
+  }
+  FOD_DEVINL void frag(Frag<__bf16>& f, int s, int lane) const {
+    const int g = lane >> 4, idx = lane & 15;
+    const int q = idx >> 2, pp = idx & 3, h = g >> 1;
+    const int col = 16 * (g & 1) + 4 * pp;
+    const int r0 = 16 * s + 4 * h + q;
+    typedef __attribute__((address_space(3))) short4_t* lds_s4;
+    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(lds + r0 * 64 + col * 2));
+    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(lds + (r0 + 8) * 64 + col * 2));
+    short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    __builtin_memcpy(&f, tmp, 16);
+  }
+};
+
 template <typename T>
 FOD_DEVINL void zero_acc(f32x16& a) {
 #pragma unroll
@@ -88,6 +139,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   float m = -INFINITY, l = 0.f;
   f32x16 oacc;
   zero_acc<T>(oacc);
+  __shared__ __attribute__((aligned(16))) unsigned char slab_v[4][2048];
+  TransTile<T> tv;
 
   for (int k0 = SPLIT ? wave * 32 : 0; k0 < p.S; k0 += SPLIT ? 128 : 32) {
     const int kr = min(k0 + fr, p.S - 1);
@@ -122,11 +175,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     m = m_new;
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+    tv.stage(Vp + (long)k0 * p.v_ts, p.v_ts, p.S - k0, slab_v[wave], lane);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       Frag<T> fp, fv;
       frag_from_acc(fp, sacc, s);
-      frag_gather_accorder(fv, Vp + (long)k0 * p.v_ts + fr, p.v_ts, s, fh, p.S - k0);
+      tv.frag(fv, s, lane);
       mma16(fv, fp, oacc);
     }
   }
@@ -204,6 +258,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   f32x16 dq[PARTS];
 #pragma unroll
   for (int pt = 0; pt < PARTS; ++pt) zero_acc<T>(dq[pt]);
+  __shared__ __attribute__((aligned(16))) unsigned char slab_k[4][PARTS][2048];
+  TransTile<T> tk[PARTS];
 
   for (int k0 = SPLIT ? wave * 32 : 0; k0 < p.S; k0 += SPLIT ? 128 : 32) {
     const int kr = min(k0 + fr, p.S - 1);
@@ -229,15 +285,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
       sacc[r] = pr * (dpacc[r] - dl) * p.scale;      // dS^T
     }
 #pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt)
+      tk[pt].stage(Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)k0 * (pt ? p.k2_ts : p.k_ts) + h * 32,
+                   (pt ? p.k2_ts : p.k_ts), p.S - k0, slab_k[wave][pt], lane);
+#pragma unroll
     for (int s = 0; s < 2; ++s) {
       Frag<T> fds;
       frag_from_acc(fds, sacc, s);
 #pragma unroll
       for (int pt = 0; pt < PARTS; ++pt) {
         Frag<T> fkt;   // K^T: row = d (lane), kappa = key
-        frag_gather_accorder(fkt, Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)k0 * (pt ? p.k2_ts : p.k_ts) + h * 32 + fr,
-                             (pt ? p.k2_ts : p.k_ts), s, fh,
-                             p.S - k0);
+        tk[pt].frag(fkt, s, lane);
         mma16(fkt, fds, dq[pt]);             // dQ^T[d, q] += sum_k K[k,d] dS^T[k,q]
       }
     }
@@ -299,6 +357,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
   for (int pt = 0; pt < PARTS; ++pt) zero_acc<T>(dk[pt]);
   const float* lse_b = p.lse2 + ((long)b * p.H + h) * p.Tq;
   const float* del_b = p.delta + ((long)b * p.H + h) * p.Tq;
+  __shared__ __attribute__((aligned(16))) unsigned char slab_q[4][PARTS + 1][2048];
+  TransTile<T> tdo, tq[PARTS];
 
   for (int q0 = 0; q0 < p.Tq; q0 += 32) {
     const int qr = min(q0 + fr, p.Tq - 1);
@@ -326,18 +386,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
       dpacc[r] = pr * (dpacc[r] - del_b[qc]) * p.scale;   // dS
       sacc[r] = pr;                                       // P
     }
+    tdo.stage(dOb + (long)q0 * p.o_ts, p.o_ts, p.Tq - q0, slab_q[wave][PARTS], lane);
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt)
+      tq[pt].stage(Qp[pt] + (long)b * p.q_bs + (long)q0 * p.q_ts + h * 32, p.q_ts, p.Tq - q0, slab_q[wave][pt], lane);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       Frag<T> fp, fds, fdot;
       frag_from_acc(fp, sacc, s);
       frag_from_acc(fds, dpacc, s);
-      frag_gather_accorder(fdot, dOb + (long)q0 * p.o_ts + fr, p.o_ts, s, fh, p.Tq - q0);
+      tdo.frag(fdot, s, lane);
       mma16(fdot, fp, dv);                    // dV^T[d, key] += sum_q dO[q,d] P[q,key]
 #pragma unroll
       for (int pt = 0; pt < PARTS; ++pt) {
         Frag<T> fqt;
-        frag_gather_accorder(fqt, Qp[pt] + (long)b * p.q_bs + (long)q0 * p.q_ts + h * 32 + fr, p.q_ts, s, fh,
-                             p.Tq - q0);
+        tq[pt].frag(fqt, s, lane);
         mma16(fqt, fds, dk[pt]);              // dK^T[d, key] += sum_q Q[q,d] dS[q,key]
       }
     }
