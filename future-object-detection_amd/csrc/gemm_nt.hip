@@ -41,6 +41,7 @@ struct NtParams {
   int c_is_f32;
   int vec_epi;   // host-checked: N, ldc, ldr, ldmask multiples of 4 and 16-byte aligned bases
   unsigned a_bytes, b_bytes;   // extents of A and B for the buffer descriptors (< 4 GiB, host-checked)
+  int gx, gy;                  // tile grid (n-tiles, m-tiles); launched as a 1-D grid of gx * roundup(gy, 8)
   // gather geometry
   int Hs, Ws, Cs;   // source image dims / channels
   int Hd, Wd;       // m-domain dims
@@ -67,8 +68,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int n0 = blockIdx.x * BN;
-  const int m0 = blockIdx.y * BM;
+  // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each), so block
+  // ids congruent mod 8 share an L2: give each XCD whole m-tiles (all of an m-tile's n-tiles re-read the
+  // same gathered A rows; neighbouring m-tiles share 3x3 halo rows) instead of striping n-tiles over XCDs.
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int nt_i = slot % p.gx;
+  const int mt_i = (slot / p.gx) * 8 + xcd;
+  if (mt_i >= p.gy) return;
+  const int n0 = nt_i * BN;
+  const int m0 = mt_i * BM;
   const int cc = tid & 7;     // 16-byte chunk column handled by this thread
   const int r0 = tid >> 3;    // first tile row handled by this thread (then +32, +64, +96)
 
@@ -344,14 +352,18 @@ template <typename T, int MODE>
 int launch_nt(const NtParams& p, hipStream_t stream) {
   const bool narrow = p.N <= 64;
   const dim3 block(256);
+  NtParams q = p;
+  q.gy = ceil_div(p.M, BM);
   if (narrow) {
-    const dim3 grid(ceil_div(p.N, 64), ceil_div(p.M, BM));
+    q.gx = ceil_div(p.N, 64);
+    const dim3 grid(q.gx * ((q.gy + 7) / 8 * 8));
     const size_t lds = 2 * (BM + 64) * ROW_BYTES;
-    hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 1>), grid, block, lds, stream, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 1>), grid, block, lds, stream, q);
   } else {
-    const dim3 grid(ceil_div(p.N, 128), ceil_div(p.M, BM));
+    q.gx = ceil_div(p.N, 128);
+    const dim3 grid(q.gx * ((q.gy + 7) / 8 * 8));
     const size_t lds = 2 * (BM + 128) * ROW_BYTES;
-    hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 2>), grid, block, lds, stream, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 2>), grid, block, lds, stream, q);
   }
   FOD_LAUNCH_CHECK();
   return FOD_OK;
