@@ -31,7 +31,6 @@ struct TnParams {
   float* colsum;     // optional f32 [N1]: += column sums of G (bias gradient), done by the blockIdx.x == 0 blocks
   int accumulate;    // 0: outputs are all-zero on entry (caller's guarantee) -> a single M-split may plain-store
   int m_per_split;
-  int tj, ti, nsplit;  // tile grid and number of M-splits; launched 1-D as ti*tj * roundup(nsplit, 8)
   int Hs, Ws, Cs, Hd, Wd, kh, kw, stride, pad;
 };
 
@@ -83,16 +82,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1;
-  // XCD-aware order (see gemm_nt.hip): all (i, j) tiles of one M-split re-read the same G / X rows, so a
-  // split's tiles go to ONE XCD (block ids congruent mod 8) and its rows are fetched into one L2 only.
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int ntile = p.ti * p.tj;
-  const int tile = slot % ntile;
-  const int split = (slot / ntile) * 8 + xcd;
-  if (split >= p.nsplit) return;
-  const int bx = tile % p.tj, by = tile / p.tj;
-  const int j0 = bx * 128, i0 = by * 128;
-  const int mb = split * p.m_per_split;
+  const int j0 = blockIdx.x * 128, i0 = blockIdx.y * 128;
+  const int mb = blockIdx.z * p.m_per_split;
   const int mend = min(p.M, mb + p.m_per_split);
   const int chunk = tid % CHR, prow = tid / CHR;
 
@@ -140,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
   float csum[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) csum[e] = 0.f;
-  const bool do_colsum = p.colsum != nullptr && bx == 0;
+  const bool do_colsum = p.colsum != nullptr && blockIdx.x == 0;
   auto store_step = [&](int buf) {
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
@@ -205,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
       for (int e = 0; e < VEC; ++e) {
         float s = 0.f;
         for (int r = 0; r < RPP; ++r) s += red[(r * CHR + tid) * VEC + e];
-        if (p.nsplit != 1) atomicAdd(p.colsum + gi + e, s);
+        if (gridDim.z != 1) atomicAdd(p.colsum + gi + e, s);
         else if (p.accumulate) p.colsum[gi + e] += s;
         else p.colsum[gi + e] = s;
       }
@@ -214,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 
   // A CU issues ~one 256-B atomic wave-instruction per 50 ns (12.8 us for a 128x128 tile), so atomics
   // are used only when several M-splits add into the same tile.
-  const bool single = p.nsplit == 1;
+  const bool single = gridDim.z == 1;
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int j = j0 + wj * 64 + b * 32 + (lane & 31);
@@ -286,10 +277,7 @@ int launch_tn(int dtype, TnParams& p, hipStream_t stream) {
   const int tj = ceil_div(p.K2, 128), ti = ceil_div(p.N1, 128);
   const int splits = pick_splits(ti * tj, p.M);
   p.m_per_split = ((p.M + splits - 1) / splits + MSTEP - 1) / MSTEP * MSTEP;
-  p.tj = tj;
-  p.ti = ti;
-  p.nsplit = ceil_div(p.M, p.m_per_split);
-  const dim3 grid(ti * tj * ((p.nsplit + 7) / 8 * 8));
+  const dim3 grid(tj, ti, ceil_div(p.M, p.m_per_split));
   if (dtype == FOD_BF16)
     hipLaunchKernelGGL((gemm_tn_kernel<__bf16, MODE>), grid, dim3(256), 0, stream, p);
   else if (dtype == FOD_F32)
