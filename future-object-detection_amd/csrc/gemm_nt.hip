@@ -138,6 +138,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
     __builtin_memcpy(&u, &v, 16);
     return u;
   };
+  // running tap decode of this thread's chunk column (see load_tile)
+  int tap_r = 0, tap_s = 0, tap_c = cc * VEC;
+  const int tap_w = MODE == MODE_DGRAD_S2 ? p.n_s : p.kw;
+  if (MODE != MODE_DENSE) {
+    const int tap = tap_c / p.Cs;
+    tap_c -= tap * p.Cs;
+    tap_r = tap / tap_w;
+    tap_s = tap - tap_r * tap_w;
+  }
   // Register staging ring: tile t lives in ring[t % 3]; two tiles are in flight while a third is consumed
   // from LDS, so a block that is alone on its CU (small problems) still overlaps global latency.
   struct Stage {
@@ -150,19 +159,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
     uint4* rb = st.b;
     const int k = kt * BK + cc * VEC;
     const bool kin = k < p.K;
-    int r = 0, s = 0, c = k;
+    // (r, s, c) of this thread's chunk: kept incrementally (tiles are requested in increasing order), the
+    // two integer divisions per tile were ~5 VALU instructions per MFMA
+    const int r = tap_r, s = tap_s, c = tap_c;
     unsigned kb = (unsigned)k * (unsigned)sizeof(T);     // byte offset of this chunk inside a B row
-    if (MODE == MODE_DGRAD_S2) {
-      const int tap = k / p.Cs;
-      c = k - tap * p.Cs;
-      r = tap / p.n_s;                                   // index into the class's compact tap list
-      s = tap - r * p.n_s;
+    if (MODE == MODE_DGRAD_S2)
       kb = (unsigned)(((p.r_first + 2 * r) * p.kw + p.s_first + 2 * s) * p.Cs + c) * (unsigned)sizeof(T);
-    } else if (MODE != MODE_DENSE) {
-      const int tap = k / p.Cs;
-      c = k - tap * p.Cs;
-      r = tap / p.kw;
-      s = tap - r * p.kw;
+    if (MODE != MODE_DENSE) {
+      tap_c += BK;
+      while (tap_c >= p.Cs) {
+        tap_c -= p.Cs;
+        if (++tap_s == tap_w) {
+          tap_s = 0;
+          ++tap_r;
+        }
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

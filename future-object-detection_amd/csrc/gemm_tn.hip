@@ -15,6 +15,8 @@
 //
 // Replaces autograd's conv2d/linear weight-gradient kernels behind reference
 // future_od/trainer.py:180 (loss.backward()).  Also: fod_colsum for the bias gradients.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -31,6 +33,8 @@ struct TnParams {
   float* colsum;     // optional f32 [N1]: += column sums of G (bias gradient), done by the blockIdx.x == 0 blocks
   int accumulate;    // 0: outputs are all-zero on entry (caller's guarantee) -> a single M-split may plain-store
   int m_per_split;
+  int tj, ti, nsplit, xcd_order;   // tile grid, number of M-splits, 1 = XCD-grouped 1-D launch
+  unsigned g_bytes, x_bytes;       // operand extents for the buffer descriptors (< 4 GiB, host-checked)
   int Hs, Ws, Cs, Hd, Wd, kh, kw, stride, pad;
 };
 
@@ -82,8 +86,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wi = wave >> 1, wj = wave & 1;
-  const int j0 = blockIdx.x * 128, i0 = blockIdx.y * 128;
-  const int mb = blockIdx.z * p.m_per_split;
+  int bx, by, split;
+  if (p.xcd_order) {
+    // all (i, j) tiles of one M-split re-read the same G / X rows: give a split's tiles to ONE XCD (block ids
+    // congruent mod 8 share an L2) so its rows cross the fabric once instead of once per XCD
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ntile = p.ti * p.tj;
+    const int tile = slot % ntile;
+    split = (slot / ntile) * 8 + xcd;
+    if (split >= p.nsplit) return;
+    bx = tile % p.tj;
+    by = tile / p.tj;
+  } else {
+    bx = blockIdx.x; by = blockIdx.y; split = blockIdx.z;
+  }
+  const int j0 = bx * 128, i0 = by * 128;
+  const int mb = split * p.m_per_split;
   const int mend = min(p.M, mb + p.m_per_split);
   const int chunk = tid % CHR, prow = tid / CHR;
 
@@ -101,46 +119,76 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     xs = tap - xr * p.kw;
   }
 
-  uint4 rg[PASSES], rx[PASSES];
-  auto load_step = [&](int m_start) {
+  // raw buffer loads: out-of-range chunks get the offset OOB and come back as zeros from the hardware
+  // range check -- no branches around the loads, so the staged steps stay in flight (see gemm_nt.hip)
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const auto rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.G), 0, p.g_bytes, 0x00020000);
+  const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.X), 0, p.x_bytes, 0x00020000);
+  auto bload = [](const auto& rs, unsigned off) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+    uint4 u;
+    __builtin_memcpy(&u, &v, 16);
+    return u;
+  };
+  struct Stage {
+    uint4 g[PASSES];
+    uint4 x[PASSES];
+  };
+  Stage st0, st1, st2;      // step t lives in ring[t % 3]; two steps in flight
+  // pixel coordinates of this thread's rows, advanced by MSTEP per requested step (steps are requested in
+  // increasing order): replaces two integer divisions per row per step
+  int px_img[PASSES], px_h[PASSES], px_w[PASSES];
+  if (MODE == MODE_CONV) {
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int m = mb + prow + ps * RPP;
+      const int hw = p.Hd * p.Wd;
+      px_img[ps] = m / hw;
+      const int rem = m - px_img[ps] * hw;
+      px_h[ps] = rem / p.Wd;
+      px_w[ps] = rem - px_h[ps] * p.Wd;
+    }
+  }
+  auto load_step = [&](int m_start, Stage& st) {
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const int m = m_start + prow + ps * RPP;
-      uint4 vg = make_uint4(0, 0, 0, 0), vx = make_uint4(0, 0, 0, 0);
-      if (m < mend) {
-        if (g_ok) vg = *reinterpret_cast<const uint4*>(Gp + (long)m * p.ldg + gi);
-        if (x_ok) {
-          if (MODE == MODE_DENSE) {
-            vx = *reinterpret_cast<const uint4*>(Xp + (long)m * p.ldx + xj);
-          } else {
-            const int hw = p.Hd * p.Wd;
-            const int img = m / hw;
-            const int rem = m - img * hw;
-            const int ph = rem / p.Wd;
-            const int pw = rem - ph * p.Wd;
-            const int hs = ph * p.stride - p.pad + xr, ws = pw * p.stride - p.pad + xs;
-            if ((unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws)
-              vx = *reinterpret_cast<const uint4*>(Xp + (((long)img * p.Hs + hs) * p.Ws + ws) * p.Cs + xc);
+      const bool in = m < mend;
+      unsigned og = (in && g_ok) ? (unsigned)(((long)m * p.ldg + gi) * (long)sizeof(T)) : OOB;
+      unsigned ox;
+      if (MODE == MODE_DENSE) {
+        ox = (in && x_ok) ? (unsigned)(((long)m * p.ldx + xj) * (long)sizeof(T)) : OOB;
+      } else {
+        const int img = px_img[ps], ph = px_h[ps], pw = px_w[ps];
+        const int hs = ph * p.stride - p.pad + xr, ws = pw * p.stride - p.pad + xs;
+        const bool ok = in && x_ok && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
+        ox = ok ? (unsigned)(((((long)img * p.Hs + hs) * p.Ws + ws) * p.Cs + xc) * (long)sizeof(T)) : OOB;
+        px_w[ps] += MSTEP;
+        while (px_w[ps] >= p.Wd) {
+          px_w[ps] -= p.Wd;
+          if (++px_h[ps] == p.Hd) {
+            px_h[ps] = 0;
+            ++px_img[ps];
           }
         }
       }
-      rg[ps] = vg;
-      rx[ps] = vx;
+      st.g[ps] = bload(rsG, og);
+      st.x[ps] = bload(rsX, ox);
     }
   };
   float csum[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) csum[e] = 0.f;
-  const bool do_colsum = p.colsum != nullptr && blockIdx.x == 0;
-  auto store_step = [&](int buf) {
+  const bool do_colsum = p.colsum != nullptr && bx == 0;
+  auto store_step = [&](int buf, const Stage& st) {
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
       const int row = prow + ps * RPP;
-      *reinterpret_cast<uint4*>(sGb[buf] + row * PITCH + chunk * 16) = rg[ps];
-      *reinterpret_cast<uint4*>(sXb[buf] + row * PITCH + chunk * 16) = rx[ps];
+      *reinterpret_cast<uint4*>(sGb[buf] + row * PITCH + chunk * 16) = st.g[ps];
+      *reinterpret_cast<uint4*>(sXb[buf] + row * PITCH + chunk * 16) = st.x[ps];
       if (do_colsum) {
         T tmp[VEC];
-        __builtin_memcpy(tmp, &rg[ps], 16);
+        __builtin_memcpy(tmp, &st.g[ps], 16);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) csum[e] += to_f32(tmp[e]);
       }
@@ -155,15 +203,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  int buf = 0;
-  if (mb < mend) {
-    load_step(mb);
-    store_step(0);
-  }
+  const int nst = mb < mend ? (mend - mb + MSTEP - 1) / MSTEP : 0;
+  if (nst > 0) load_step(mb, st0);
+  if (nst > 1) load_step(mb + MSTEP, st1);
+  if (nst > 0) store_step(0, st0);
   __syncthreads();
-  for (int ms = mb; ms < mend; ms += MSTEP) {
-    const bool more = ms + MSTEP < mend;
-    if (more) load_step(ms + MSTEP);
+  auto compute = [&](int buf) {
     const unsigned char* sG = sGb[buf];
     const unsigned char* sX = sXb[buf];
 #pragma unroll
@@ -178,10 +223,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) mma16(fa[a], fb[b], acc[a][b]);
     }
-    if (more) store_step(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
+  };
+#define FOD_TN_STEP(k, LD, ST)                                   \
+  if ((k) < nst) {                                               \
+    if ((k) + 2 < nst) load_step(mb + ((k) + 2) * MSTEP, LD);    \
+    compute((k) & 1);                                            \
+    if ((k) + 1 < nst) store_step(((k) + 1) & 1, ST);            \
+    __syncthreads();                                             \
   }
+  for (int t = 0; t < nst; t += 3) {
+    FOD_TN_STEP(t, st2, st1)
+    FOD_TN_STEP(t + 1, st0, st2)
+    FOD_TN_STEP(t + 2, st1, st0)
+  }
+#undef FOD_TN_STEP
   if (do_colsum && g_ok) {
     // threads sharing a chunk (same columns, different rows) differ by multiples of CHR: reduce through LDS
     float* red = reinterpret_cast<float*>(sGb[0]);       // 256 * VEC floats <= one staging buffer
@@ -196,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
       for (int e = 0; e < VEC; ++e) {
         float s = 0.f;
         for (int r = 0; r < RPP; ++r) s += red[(r * CHR + tid) * VEC + e];
-        if (gridDim.z != 1) atomicAdd(p.colsum + gi + e, s);
+        if (p.nsplit != 1) atomicAdd(p.colsum + gi + e, s);
         else if (p.accumulate) p.colsum[gi + e] += s;
         else p.colsum[gi + e] = s;
       }
@@ -205,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 
   // A CU issues ~one 256-B atomic wave-instruction per 50 ns (12.8 us for a 128x128 tile), so atomics
   // are used only when several M-splits add into the same tile.
-  const bool single = gridDim.z == 1;
+  const bool single = p.nsplit == 1;
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int j = j0 + wj * 64 + b * 32 + (lane & 31);
@@ -275,9 +330,16 @@ int pick_splits(int tiles, int M) {
 template <int MODE>
 int launch_tn(int dtype, TnParams& p, hipStream_t stream) {
   const int tj = ceil_div(p.K2, 128), ti = ceil_div(p.N1, 128);
-  const int splits = pick_splits(ti * tj, p.M);
+  int splits = pick_splits(ti * tj, p.M);
+  static const char* env_rows = getenv("FOD_TN_ROWS");       // experiment knobs (tools/): rows per split, XCD order
+  static const char* env_xcd = getenv("FOD_TN_XCD");
+  if (env_rows && atoi(env_rows) > 0 && p.M > 512) splits = ceil_div(p.M, atoi(env_rows));
   p.m_per_split = ((p.M + splits - 1) / splits + MSTEP - 1) / MSTEP * MSTEP;
-  const dim3 grid(tj, ti, ceil_div(p.M, p.m_per_split));
+  p.tj = tj;
+  p.ti = ti;
+  p.nsplit = ceil_div(p.M, p.m_per_split);
+  p.xcd_order = (env_xcd && atoi(env_xcd) > 0 && p.nsplit >= 8) ? 1 : 0;
+  const dim3 grid = p.xcd_order ? dim3(ti * tj * ((p.nsplit + 7) / 8 * 8)) : dim3(tj, ti, p.nsplit);
   if (dtype == FOD_BF16)
     hipLaunchKernelGGL((gemm_tn_kernel<__bf16, MODE>), grid, dim3(256), 0, stream, p);
   else if (dtype == FOD_F32)
@@ -308,6 +370,11 @@ extern "C" int fod_gemm_tn_acc(int dtype, const void* G, long ldg, const void* X
   p.rscale = row_scale;
   p.colsum = colsum;
   p.accumulate = accumulate;
+  const long esz = dtype == FOD_BF16 ? 2 : 4;
+  const long gb = ((long)(M - 1) * ldg + N1) * esz, xb = ((long)(M - 1) * ldx + K2) * esz;
+  FOD_REQUIRE(gb < 0xFFFFFFF0L - 16 && xb < 0xFFFFFFF0L - 16, "gemm_tn: operand larger than 4 GiB");
+  p.g_bytes = (unsigned)gb;
+  p.x_bytes = (unsigned)xb;
   return launch_tn<MODE_DENSE>(dtype, p, stream);
 }
 
@@ -334,6 +401,11 @@ extern "C" int fod_conv2d_wgrad_acc(int dtype, const void* dy, const void* x, fl
   p.Hd = g->Ho; p.Wd = g->Wo;
   p.kh = g->kh; p.kw = g->kw; p.stride = g->stride; p.pad = g->pad;
   p.accumulate = accumulate;
+  const long esz = dtype == FOD_BF16 ? 2 : 4;
+  const long gb = (long)p.M * g->Cout * esz, xb = (long)g->Nimg * g->H * g->W * g->Cin * esz;
+  FOD_REQUIRE(gb < 0xFFFFFFF0L - 16 && xb < 0xFFFFFFF0L - 16, "conv_wgrad: operand larger than 4 GiB");
+  p.g_bytes = (unsigned)gb;
+  p.x_bytes = (unsigned)xb;
   return launch_tn<MODE_CONV>(dtype, p, stream);
 }
 

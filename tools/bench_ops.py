@@ -60,10 +60,11 @@ if which in ("all", "conv"):
         g = ops.conv_geom(x.shape, cout, k, s, p)
         shift = torch.zeros(cout, device=DEV)
         fl = 2.0 * n * g.Ho * g.Wo * cout * k * k * cin
-        tf = timeit(lambda: ops.conv2d_fwd(x, wt, g, shift=shift, relu=True))
+        only_w = os.environ.get("ONLY_WGRAD") == "1"
+        tf = 1.0 if only_w else timeit(lambda: ops.conv2d_fwd(x, wt, g, shift=shift, relu=True))
         dy = torch.randn(n, g.Ho, g.Wo, cout, device=DEV).to(dtype)
         wt_t = wt.permute(3, 1, 2, 0).contiguous()
-        td = timeit(lambda: ops.conv2d_dgrad(dy, wt_t, g, relu_mask=x))
+        td = 1.0 if only_w else timeit(lambda: ops.conv2d_dgrad(dy, wt_t, g, relu_mask=x))
         dw = torch.zeros(cout, k, k, cin, device=DEV)
         tw = timeit(lambda: ops.conv2d_wgrad_acc(dy, x, dw, g))
         print(f"{name:28s} {str((h, w, cin, cout, k, s)):34s} {fl / tf / 1e12:8.1f} {fl / td / 1e12:9.1f} {fl / tw / 1e12:9.1f}   "
