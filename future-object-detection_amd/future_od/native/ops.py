@@ -23,7 +23,14 @@ def dt(t):
         raise L.FodError(f"unsupported activation dtype {t.dtype}") from None
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device.  The raw getter is ~30x cheaper than
+    building a torch.cuda.Stream object per launch (9 us -> 0.3 us; there are ~2500 launches per step)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -41,21 +41,15 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def _state_for(self, p):
         st = self.state[p]
-        if len(st) == 0:
-            st["step"] = torch.tensor(0.0)
+        if "exp_avg" not in st:
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         return st
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        assert closure is None
-        # all groups share betas/eps (as the reference's two groups do); lr / weight decay are per tensor
-        entries, keepalive = [], []
-        betas, eps = self.param_groups[0]["betas"], self.param_groups[0]["eps"]
-        step_no = None
+    def _build_plan(self):
+        """Slow path: (re)build the device tables for the current set of (param, grad, moment) pointers."""
+        entries, params, keepalive = [], [], []
         for grp in self.param_groups:
-            assert grp["betas"] == betas and grp["eps"] == eps
             for p in grp["params"]:
                 g = p.grad
                 if g is None:
@@ -63,34 +57,28 @@ class FusedAdamW(torch.optim.Optimizer):
                 if p.dtype != torch.float32 or not p.is_cuda:
                     raise L.FodError("FusedAdamW handles float32 device parameters only")
                 if g.dtype != torch.float32 or not _same_layout(g, p):
-                    g2 = torch.empty_like(p, memory_format=torch.preserve_format)
-                    g2.copy_(g)
-                    g = g2
-                    keepalive.append(g2)
+                    return None            # needs per-step copies: handled by the general path
                 st = self._state_for(p)
-                st["step"] += 1
-                step_no = float(st["step"]) if step_no is None else step_no
                 entries.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                                 p.numel(), grp["lr"], grp["weight_decay"]))
+                params.append(p)
         if not entries:
             return None
-        dev = self.param_groups[0]["params"][0].device
-        key = tuple(entries)
-        tab = self._tables.get(key)
-        if tab is None:
-            if len(self._tables) > 8:
-                self._tables.clear()
-            ptrs = torch.tensor([e[:4] for e in entries], dtype=torch.int64)
-            numel = torch.tensor([e[4] for e in entries], dtype=torch.int64)
-            lr_wd = torch.tensor([e[5:7] for e in entries], dtype=torch.float32)
-            bt, bc = [], []
-            for t, e in enumerate(entries):
-                for c in range((e[4] + self._chunk - 1) // self._chunk):
-                    bt.append(t)
-                    bc.append(c)
-            tab = tuple(x.to(dev) for x in (ptrs, numel, lr_wd, torch.tensor(bt, dtype=torch.int32),
-                                            torch.tensor(bc, dtype=torch.int32)))
-            self._tables[key] = tab
+        dev = params[0].device
+        ptrs = torch.tensor([e[:4] for e in entries], dtype=torch.int64)
+        numel = torch.tensor([e[4] for e in entries], dtype=torch.int64)
+        lr_wd = torch.tensor([e[5:7] for e in entries], dtype=torch.float32)
+        bt, bc = [], []
+        for t, e in enumerate(entries):
+            for c in range((e[4] + self._chunk - 1) // self._chunk):
+                bt.append(t)
+                bc.append(c)
+        tab = tuple(x.to(dev) for x in (ptrs, numel, lr_wd, torch.tensor(bt, dtype=torch.int32),
+                                        torch.tensor(bc, dtype=torch.int32)))
+        return {"params": params, "gptrs": [e[1] for e in entries], "tab": tab,
+                "lrs": [(g["lr"], g["weight_decay"]) for g in self.param_groups], "dev": dev}
+
+    def _launch(self, tab, dev, betas, eps):
         ptrs, numel, lr_wd, bt, bc = tab
         if self._sq is None or self._sq.device != dev:
             self._sq = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -101,9 +89,79 @@ class FusedAdamW(torch.optim.Optimizer):
             L.call("fod_multi_sqnorm_acc", ptr(ptrs), ptr(numel), ptr(bt), ptr(bc), nblocks, ptr(self._sq), stream())
             sq = self._sq
             self.last_grad_norm = self._sq      # device scalar holding the squared norm
-        bc1 = 1.0 - betas[0] ** step_no
-        bc2 = 1.0 - betas[1] ** step_no
+        bc1 = 1.0 - betas[0] ** self._step_no
+        bc2 = 1.0 - betas[1] ** self._step_no
         L.call("fod_multi_adamw", ptr(ptrs), ptr(numel), ptr(lr_wd), ptr(bt), ptr(bc), nblocks, betas[0], betas[1],
                eps, bc1, bc2, ptr(sq), self.max_norm, stream())
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        assert closure is None
+        betas, eps = self.param_groups[0]["betas"], self.param_groups[0]["eps"]
+        for grp in self.param_groups:
+            assert grp["betas"] == betas and grp["eps"] == eps    # lr / weight decay are per tensor, these are shared
+        self._step_no = getattr(self, "_step_no", 0) + 1
+        # fast path: the same tensors at the same addresses as last step (the gradient arena hands out the
+        # same slots every step) -> two launches, no per-parameter Python work beyond reading the pointers
+        plan = getattr(self, "_plan", None)
+        if plan is not None:
+            ok = plan["lrs"] == [(g["lr"], g["weight_decay"]) for g in self.param_groups]
+            if ok:
+                for p, gp in zip(plan["params"], plan["gptrs"]):
+                    g = p.grad
+                    if g is None or g.data_ptr() != gp:
+                        ok = False
+                        break
+            if ok:
+                self._launch(plan["tab"], plan["dev"], betas, eps)
+                return None
+        plan = self._build_plan()
+        self._plan = plan
+        if plan is not None:
+            self._launch(plan["tab"], plan["dev"], betas, eps)
+            return None
+        # general path: some gradient needs a layout/dtype copy first
+        entries, keepalive = [], []
+        for grp in self.param_groups:
+            for p in grp["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                if g.dtype != torch.float32 or not _same_layout(g, p):
+                    g2 = torch.empty_like(p, memory_format=torch.preserve_format)
+                    g2.copy_(g)
+                    g = g2
+                    keepalive.append(g2)
+                st = self._state_for(p)
+                entries.append((p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                                p.numel(), grp["lr"], grp["weight_decay"]))
+        if not entries:
+            return None
+        dev = self.param_groups[0]["params"][0].device
+        ptrs = torch.tensor([e[:4] for e in entries], dtype=torch.int64)
+        numel = torch.tensor([e[4] for e in entries], dtype=torch.int64)
+        lr_wd = torch.tensor([e[5:7] for e in entries], dtype=torch.float32)
+        bt, bc = [], []
+        for t, e in enumerate(entries):
+            for c in range((e[4] + self._chunk - 1) // self._chunk):
+                bt.append(t)
+                bc.append(c)
+        tab = tuple(x.to(dev) for x in (ptrs, numel, lr_wd, torch.tensor(bt, dtype=torch.int32),
+                                        torch.tensor(bc, dtype=torch.int32)))
+        self._launch(tab, dev, betas, eps)
         del keepalive
         return None
+
+    def state_dict(self):
+        """torch.optim.AdamW layout; the shared step counter is materialised per parameter."""
+        step_no = float(getattr(self, "_step_no", 0))
+        for st in self.state.values():
+            if "exp_avg" in st:
+                st["step"] = torch.tensor(step_no)
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        steps = [float(st["step"]) for st in self.state.values() if "step" in st]
+        self._step_no = int(max(steps)) if steps else 0
+        self._plan = None
