@@ -40,6 +40,20 @@ void fod_set_error(const char* fmt, ...);
     }                                                                   \
   } while (0)
 
+// In-kernel time stamps for tools/probe_stamps.hip (compiled with -DFOD_STAMPS); nothing in the product build.
+#ifdef FOD_STAMPS
+__device__ long long fod_stamps[32];
+#define FOD_STAMP(i)                                                                          \
+  do {                                                                                        \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)            \
+      fod_stamps[i] = wall_clock64();                                                         \
+  } while (0)
+#else
+#define FOD_STAMP(i) \
+  do {               \
+  } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 struct Elem;

@@ -19,6 +19,8 @@
 // Tile 128 x (64|128) x 128 bytes-of-k, 256 threads = 4 waves (2x2), 32x32 MFMA tiles, double-buffered
 // LDS with one barrier per k-tile, register-staged global->LDS copies, XOR-swizzled 16-byte chunks
 // (chunk ^ ((row>>1)&7): conflict-free for ds_read_b128 fragments and ds_write_b128 staging).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -61,7 +63,12 @@ constexpr int ROW_BYTES = 128;   // bytes of k per tile row
 
 FOD_DEVINL int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <typename T, int MODE, int NT>
+// GLDS = true : operand tiles go global -> LDS directly (buffer_load_dwordx4 ... lds, one 1 KB piece = 8 rows x
+//               128 B per wave-instruction).  The DMA writes lane-linear, so the XOR swizzle is applied to the
+//               per-lane SOURCE chunk instead (read side unchanged).  No staging VGPRs, no ds_write_b128 (whose
+//               ~79 B/clk/CU was the busiest LDS port of the register-staged loop).
+// GLDS = false: register-staged ring (kept for A/B measurements, env FOD_NT_GLDS=0).
+template <typename T, int MODE, int NT, bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int BK = ROW_BYTES / (int)sizeof(T);
@@ -76,6 +83,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  FOD_STAMP(0);
   // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each), so block
   // ids congruent mod 8 share an L2: give each XCD whole m-tiles (all of an m-tile's n-tiles re-read the
   // same gathered A rows; neighbouring m-tiles share 3x3 halo rows) instead of striping n-tiles over XCDs.
@@ -138,8 +146,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
     __builtin_memcpy(&u, &v, 16);
     return u;
   };
-  // running tap decode of this thread's chunk column (see load_tile)
-  int tap_r = 0, tap_s = 0, tap_c = cc * VEC;
+  // source chunk column of this thread: with LDS-DMA the lane's LDS slot is fixed (row r0 & 7, position cc of
+  // its 1 KB piece), so the swizzle (position = chunk ^ ((row>>1)&7), same for r0, r0+32, ...) picks the chunk
+  const int ccs = GLDS ? (cc ^ ((r0 >> 1) & 7)) : cc;
+  // running tap decode of this thread's chunk column (see tile_offsets)
+  int tap_r = 0, tap_s = 0, tap_c = ccs * VEC;
   const int tap_w = MODE == MODE_DGRAD_S2 ? p.n_s : p.kw;
   if (MODE != MODE_DENSE) {
     const int tap = tap_c / p.Cs;
@@ -154,10 +165,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
     uint4 b[BROWS];
   };
   Stage st0, st1, st2;
-  auto load_tile = [&](int kt, Stage& st) {
-    uint4* ra = st.a;
-    uint4* rb = st.b;
-    const int k = kt * BK + cc * VEC;
+  auto tile_offsets = [&](int kt, unsigned* offa, unsigned* offb) {
+    const int k = kt * BK + ccs * VEC;
     const bool kin = k < p.K;
     // (r, s, c) of this thread's chunk: kept incrementally (tiles are requested in increasing order), the
     // two integer divisions per tile were ~5 VALU instructions per MFMA
@@ -195,10 +204,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
         const bool ok = kin && th >= 0 && tw >= 0 && ((th | tw) & sm) == 0 && hs < p.Hs && ws < p.Ws;
         off = ok ? a_base[i] + (unsigned)((hs * p.Ws + ws) * p.Cs + c) * (unsigned)sizeof(T) : OOB;
       }
-      ra[i] = bload(rsA, off);
+      offa[i] = off;
     }
 #pragma unroll
-    for (int i = 0; i < BROWS; ++i) rb[i] = bload(rsB, (kin && b_base[i] != OOB) ? b_base[i] + kb : OOB);
+    for (int i = 0; i < BROWS; ++i) offb[i] = (kin && b_base[i] != OOB) ? b_base[i] + kb : OOB;
+  };
+  auto load_tile = [&](int kt, Stage& st) {
+    unsigned offa[4], offb[BROWS];
+    tile_offsets(kt, offa, offb);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st.a[i] = bload(rsA, offa[i]);
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) st.b[i] = bload(rsB, offb[i]);
+  };
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  auto issue_tile = [&](int kt, int buf) {     // LDS-DMA: lane l of the wave lands at piece base + 16*l
+    unsigned offa[4], offb[BROWS];
+    tile_offsets(kt, offa, offb);
+    const int piece_row = (r0 & ~7);           // 8 * wave
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsA, (lds_ptr)(sA + buf * BM * ROW_BYTES + (piece_row + 32 * i) * ROW_BYTES), 16, (int)offa[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rsB, (lds_ptr)(sB + buf * BN * ROW_BYTES + (piece_row + 32 * i) * ROW_BYTES), 16, (int)offb[i], 0, 0, 0);
   };
   auto store_tile = [&](int buf, const Stage& st) {
 #pragma unroll
@@ -217,11 +248,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // per-column scale / shift of the vectorised epilogue, requested before the k-loop: loaded after it they are
+  // a cold dependent miss (~1-2 us) on the critical path of every short launch
+  f32x4 epi_sc = {1.f, 1.f, 1.f, 1.f}, epi_sh = {0.f, 0.f, 0.f, 0.f};
+  if (p.vec_epi) {
+    const int nce = min(n0 + (tid % (BN / 4)) * 4, p.N - 4);
+    if (p.scale) epi_sc = *reinterpret_cast<const f32x4*>(p.scale + nce);
+    if (p.shift) epi_sh = *reinterpret_cast<const f32x4*>(p.shift + nce);
+  }
   const int nkt = (p.K + BK - 1) / BK;
-  load_tile(0, st0);
-  if (nkt > 1) load_tile(1, st1);
-  store_tile(0, st0);
+  if (GLDS) {
+    issue_tile(0, 0);
+  } else {
+    load_tile(0, st0);
+    if (nkt > 1) load_tile(1, st1);
+    FOD_STAMP(1);
+    store_tile(0, st0);
+  }
   __syncthreads();
+  FOD_STAMP(2);
 
   const int fr = lane & 31, fh = lane >> 5;
   auto compute = [&](int buf) {
@@ -270,12 +315,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
     if ((k) + 1 < nkt) store_tile(((k) + 1) & 1, ST); \
     __syncthreads();                                  \
   }
-  for (int kt = 0; kt < nkt; kt += 3) {
-    FOD_NT_STEP(kt, st2, st1)
-    FOD_NT_STEP(kt + 1, st0, st2)
-    FOD_NT_STEP(kt + 2, st1, st0)
+  if (GLDS) {
+    // the DMA of tile kt+1 flies during the MFMAs of tile kt; __syncthreads() waits for it (hipcc emits
+    // vmcnt(0) ahead of the barrier while an LDS-DMA is outstanding) and orders the LDS reuse
+    for (int kt = 0; kt < nkt; ++kt) {
+      if (kt + 1 < nkt) issue_tile(kt + 1, (kt + 1) & 1);
+      compute(kt & 1);
+      __syncthreads();
+    }
+  } else {
+    for (int kt = 0; kt < nkt; kt += 3) {
+      FOD_NT_STEP(kt, st2, st1)
+      FOD_NT_STEP(kt + 1, st0, st2)
+      FOD_NT_STEP(kt + 2, st1, st0)
+    }
   }
 #undef FOD_NT_STEP
+  FOD_STAMP(3);
 
   const T* __restrict__ Rp = reinterpret_cast<const T*>(p.res);
   const T* __restrict__ Mp = reinterpret_cast<const T*>(p.mask);
@@ -325,9 +381,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
         for (int r = 0; r < 16; ++r)
           sC[(wm * 64 + i * 32 + acc_row(r, lane)) * BN + wn * (32 * NT) + j * 32 + fr] = acc[i][j][r];
     __syncthreads();
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + nc);
-    if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + nc);
+    const f32x4 sc = epi_sc, sh = epi_sh;
 #pragma unroll
     for (int base = 0; base < NPASS; base += PB) {
       if (base > 0) prefetch(base);
@@ -360,6 +414,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
         }
       }
     }
+    FOD_STAMP(4);
     return;
   }
   // ---- epilogue B (ragged N / unaligned): one element per lane straight from the accumulators
@@ -392,22 +447,193 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Short-launch variant for the decoder's query-side GEMMs (M = batch x queries = a few hundred rows, 300+
+// launches per step).  At that size the tiled kernel above runs one block per CU with nothing to overlap:
+// in-kernel stamps (tools/probe_stamps.hip) show ~1.5 us before the first load, ~0.7 us per k-tile of
+// serial load -> ds_write -> barrier -> ds_read -> MFMA, and ~3 us of once-executed (instruction-cache cold)
+// epilogue code.  This kernel is built for latency instead:
+//   * 64 x 64 output tile per block (4x the blocks), the block's 4 waves split K four ways;
+//   * operand fragments go global -> VGPR in MFMA layout (lane = row, 16 B = 8 k), two 32-wide k units in
+//     flight per wave, no LDS and no barrier in the k-loop; for K = 256 every load of the launch is issued
+//     up front;
+//   * the 4 partial tiles meet in LDS once; bias / residual / mask rows are requested at kernel entry through
+//     buffer descriptors whose size is 0 for an absent operand (no branch around any load);
+//   * rolled loops, so the code is a few KB.
+__global__ __launch_bounds__(256) void gemm_nt_small_kernel(const NtParams p) {
+  typedef __bf16 T;
+  __shared__ __attribute__((aligned(16))) float sC[4][64][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+  FOD_STAMP(0);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
+  auto bload = [](const auto& rs, unsigned off) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+    Frag<T> f;
+    __builtin_memcpy(&f, &v, 16);
+    return f;
+  };
+
+  // ---- epilogue operands of this thread's 4 output rows (row = tid/16 + 16*pass, 4 columns at (tid%16)*4)
+  const int cq = tid & 15, rq = tid >> 4;
+  const int n = n0 + cq * 4;
+  const bool n_ok = n < p.N;
+  const int M1 = p.M - 1;
+  const auto rsScale = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.scale), 0, p.scale ? p.N * 4 : 0, 0x00020000);
+  const auto rsShift = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.shift), 0, p.shift ? p.N * 4 : 0, 0x00020000);
+  const auto rsRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, p.res ? 0x7FFFFFF0 : 0, 0x00020000);
+  const auto rsMask = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.mask), 0, p.mask ? 0x7FFFFFF0 : 0, 0x00020000);
+  f32x4 sc, sh;
+  {
+    const auto a = __builtin_amdgcn_raw_buffer_load_b128(rsScale, n_ok ? n * 4 : (int)OOB, 0, 0);
+    const auto b = __builtin_amdgcn_raw_buffer_load_b128(rsShift, n_ok ? n * 4 : (int)OOB, 0, 0);
+    __builtin_memcpy(&sc, &a, 16);
+    __builtin_memcpy(&sh, &b, 16);
+  }
+  bf16x4_t rres[4], rmsk[4];
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int m = min(m0 + rq + 16 * ps, M1);
+    const long rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
+    const auto a = __builtin_amdgcn_raw_buffer_load_b64(rsRes, n_ok ? (int)((rm * p.ldr + n) * 2) : (int)OOB, 0, 0);
+    const auto b = __builtin_amdgcn_raw_buffer_load_b64(rsMask, n_ok ? (int)(((long)m * p.ldmask + n) * 2) : (int)OOB, 0, 0);
+    __builtin_memcpy(&rres[ps], &a, 8);
+    __builtin_memcpy(&rmsk[ps], &b, 8);
+  }
+
+  // ---- this wave's share of K, in units of 32 elements (2 k-steps, 64 B per row)
+  const int units = (p.K + 31) >> 5;
+  const int per = (units + 3) >> 2;
+  const int ub = wave * per, ue = min(units, ub + per);
+  unsigned a_off[2], b_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int ma = m0 + i * 32 + fr;
+    const bool ok = ma < p.M;
+    if (p.a_row_mod > 0) ma %= p.a_row_mod;
+    a_off[i] = ok ? (unsigned)((long)ma * p.lda * 2) : OOB;
+    const int nb = n0 + i * 32 + fr;
+    b_off[i] = nb < p.N ? (unsigned)((long)nb * p.ldb * 2) : OOB;
+  }
+  struct Unit {
+    Frag<T> a[2][2], b[2][2];   // [k-step][32-row fragment]
+  };
+  auto load_unit = [&](int u, Unit& f) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int k = u * 32 + ks * 16 + fh * 8;
+      const bool kin = u < ue && k < p.K;        // K % 8 == 0: a 16-byte chunk is all in or all out
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        f.a[ks][i] = bload(rsA, (kin && a_off[i] != OOB) ? a_off[i] + k * 2 : OOB);
+        f.b[ks][i] = bload(rsB, (kin && b_off[i] != OOB) ? b_off[i] + k * 2 : OOB);
+      }
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto compute = [&](const Unit& f) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma16(f.a[ks][i], f.b[ks][j], acc[i][j]);
+  };
+  Unit f0, f1;
+  load_unit(ub, f0);
+  load_unit(ub + 1, f1);
+  FOD_STAMP(1);
+  for (int u = ub; u < ue; u += 2) {
+    compute(f0);
+    load_unit(u + 2, f0);            // past the wave's range: offsets are OOB, the loads return zeros at once
+    if (u + 1 < ue) compute(f1);
+    load_unit(u + 3, f1);
+  }
+
+  FOD_STAMP(2);
+  // ---- the four k-partials meet in LDS
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sC[wave][i * 32 + acc_row(r, lane)][j * 32 + fr] = acc[i][j][r];
+  __syncthreads();
+  FOD_STAMP(3);
+  const bool has_scale = p.scale != nullptr, has_mask = p.mask != nullptr;
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int row = rq + 16 * ps;
+    const int m = m0 + row;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&sC[0][row][cq * 4]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(&sC[w][row][cq * 4]);
+    if (has_scale) v = v * sc;
+    v += sh;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += (float)rres[ps][e];
+    if (p.relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (has_mask) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ((float)rmsk[ps][e] > 0.f) ? v[e] : 0.f;
+    }
+    if (m < p.M && n_ok) {
+      if (p.c_is_f32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = v;
+      } else {
+        *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(p.C) + (long)m * p.ldc + n) =
+            bf16x4_t{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+      }
+    }
+  }
+  FOD_STAMP(4);
+}
+
+// The short-launch kernel is used when its 64 x 64 tiles fit the chip in one wave of blocks.
+bool use_small_nt(int dtype, const NtParams& p) {
+  static const char* env = getenv("FOD_NT_SMALL");
+  if (env && env[0] == '0') return false;
+  if (dtype != FOD_BF16 || !p.vec_epi) return false;
+  const long blocks = (long)ceil_div(p.M, 64) * ceil_div(p.N, 64);
+  if (blocks > 256) return false;
+  // residual / mask are addressed with 31-bit byte offsets
+  if (p.res && ((long)(p.res_row_mod > 0 ? p.res_row_mod : p.M) * p.ldr + p.N) * 2 >= 0x7FFFFFF0L) return false;
+  if (p.mask && ((long)p.M * p.ldmask + p.N) * 2 >= 0x7FFFFFF0L) return false;
+  return true;
+}
+
 template <typename T, int MODE>
 int launch_nt(const NtParams& p, hipStream_t stream) {
   const bool narrow = p.N <= 64;
   const dim3 block(256);
   NtParams q = p;
   q.gy = ceil_div(p.M, BM);
+  static const char* env_glds = getenv("FOD_NT_GLDS");
+  const bool glds = env_glds && env_glds[0] == '1';   // measured: the register ring wins on this workload
   if (narrow) {
     q.gx = ceil_div(p.N, 64);
     const dim3 grid(q.gx * ((q.gy + 7) / 8 * 8));
     const size_t lds = 2 * (BM + 64) * ROW_BYTES;
-    hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 1>), grid, block, lds, stream, q);
+    if (glds) hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 1, true>), grid, block, lds, stream, q);
+    else hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 1, false>), grid, block, lds, stream, q);
   } else {
     q.gx = ceil_div(p.N, 128);
     const dim3 grid(q.gx * ((q.gy + 7) / 8 * 8));
     const size_t lds = 2 * (BM + 128) * ROW_BYTES;
-    hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 2>), grid, block, lds, stream, q);
+    if (glds) hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 2, true>), grid, block, lds, stream, q);
+    else hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 2, false>), grid, block, lds, stream, q);
   }
   FOD_LAUNCH_CHECK();
   return FOD_OK;
@@ -469,6 +695,11 @@ extern "C" int fod_gemm_nt(int dtype, const void* A, long lda, int a_row_mod, co
   FOD_REQUIRE(ab < 0xFFFFFFF0L - 16 && bb < 0xFFFFFFF0L - 16, "gemm_nt: operand larger than 4 GiB");
   p.a_bytes = (unsigned)ab;
   p.b_bytes = (unsigned)bb;
+  if (use_small_nt(dtype, p)) {
+    hipLaunchKernelGGL(gemm_nt_small_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, stream, p);
+    FOD_LAUNCH_CHECK();
+    return FOD_OK;
+  }
   return dispatch_nt<MODE_DENSE>(dtype, p, stream);
 }
 

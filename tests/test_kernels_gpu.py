@@ -247,3 +247,40 @@ def test_gemm_tn_fused_colsum(dtype):
     ops.gemm_tn_acc(g.to(DEV), x.to(DEV), dw, colsum=cs)
     check(dw, g.float().t() @ x.float(), torch.float32 if dtype == torch.float32 else dtype, math.sqrt(M), "tn")
     check(cs, g.float().sum(0), torch.float32, math.sqrt(M), "fused colsum")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mnk", [(256, 256, 256), (37, 72, 136), (300, 264, 64), (512, 8, 2048), (16, 64, 64),
+                                 (1, 8, 8), (260, 128, 104)])
+@pytest.mark.parametrize("zeroed", [False, True])
+def test_gemm_tn_short_reduction(dtype, mnk, zeroed):
+    """M <= 512 without row scale takes the one-shot short-reduction kernel (bf16); both write modes, fused
+    column sums, ragged tiles and a second 256-row chunk."""
+    M, N1, K2 = mnk
+    g, x = rnd((M, N1), dtype, 5), rnd((M, K2), dtype, 6)
+    dw0 = torch.zeros(N1, K2) if zeroed else torch.randn(N1, K2)
+    cs0 = torch.zeros(N1) if zeroed else torch.randn(N1)
+    dw, cs = dw0.clone().to(DEV), cs0.clone().to(DEV)
+    ops.gemm_tn_acc(g.to(DEV), x.to(DEV), dw, colsum=cs, zeroed=zeroed)
+    out_dt = torch.float32 if dtype == torch.float32 else dtype
+    check(dw, dw0 + g.float().t() @ x.float(), out_dt, math.sqrt(M), f"tn short {mnk}")
+    check(cs, cs0 + g.float().sum(0), torch.float32, math.sqrt(M), "tn short colsum")
+    dw2 = dw0.clone().to(DEV)
+    ops.gemm_tn_acc(g.to(DEV), x.to(DEV), dw2, zeroed=zeroed)
+    check(dw2, dw0 + g.float().t() @ x.float(), out_dt, math.sqrt(M), f"tn short {mnk} no colsum")
+
+
+@pytest.mark.parametrize("mnk", [(256, 256, 256), (256, 256, 2048), (100, 72, 40), (2900, 256, 256), (64, 2048, 256),
+                                 (65, 68, 72)])
+def test_gemm_nt_short_launch(mnk):
+    """bf16 problems of <= 256 64x64 tiles take the short-launch kernel (4-way in-block split of K)."""
+    M, N, K = mnk
+    dtype = torch.bfloat16
+    a, b = rnd((M, K), dtype, 7), rnd((N, K), dtype, 8)
+    shift = torch.randn(N)
+    res = rnd((M, N), dtype, 9)
+    ref = a.float() @ b.float().t() + shift + res.float()
+    out = ops.gemm_nt(a.to(DEV), b.to(DEV), shift=shift.to(DEV), residual=res.to(DEV))
+    check(out, ref, dtype, math.sqrt(K), f"nt short {mnk}")
+    out = ops.gemm_nt(a.to(DEV), b.to(DEV), relu=True, out_f32=True)
+    check(out, (a.float() @ b.float().t()).clamp(min=0), dtype, math.sqrt(K), f"nt short relu f32 {mnk}")

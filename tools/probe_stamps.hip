@@ -1,0 +1,68 @@
+// Standalone in-kernel timing probe: builds the GEMM kernels with -DFOD_STAMPS (block 0 / thread 0 writes
+// the 100 MHz wall clock at phase boundaries) and prints the phase times of the tiny decoder shapes.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DFOD_STAMPS tools/probe_stamps.hip -o gpurun_out/probe_stamps
+#include <stdarg.h>
+#include <stdio.h>
+#include <vector>
+#include "../future-object-detection_amd/csrc/common.h"
+void fod_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vfprintf(stderr, fmt, ap);
+  va_end(ap);
+  fputc('\n', stderr);
+}
+#define KIND_TN 1
+#define KIND_NT 2
+#if PROBE_KIND == KIND_TN
+#include "../future-object-detection_amd/csrc/gemm_tn.hip"
+#else
+#include "../future-object-detection_amd/csrc/gemm_nt.hip"
+#endif
+
+static void show(const char* what, int n) {
+  long long h[32];
+  hipMemcpyFromSymbol(h, HIP_SYMBOL(fod_stamps), sizeof(h));
+  printf("%-28s", what);
+  for (int i = 1; i < n; ++i) printf("  s%d-s%d %6.2f us", i - 1, i, (h[i] - h[i - 1]) * 0.01);
+  printf("   total %6.2f us\n", (h[n - 1] - h[0]) * 0.01);
+}
+
+int main() {
+  const size_t big = 64u << 20;
+  void *a, *b, *c;
+  float* bias;
+  hipMalloc(&a, big); hipMalloc(&b, big); hipMalloc(&c, big); hipMalloc((void**)&bias, 1 << 20);
+  hipMemset(a, 0, big); hipMemset(b, 0, big); hipMemset(c, 0, big); hipMemset(bias, 0, 1 << 20);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  char name[64];
+#if PROBE_KIND == KIND_TN
+  const int shapes[][3] = {{32, 256, 256}, {256, 256, 256}, {512, 256, 256}, {256, 2048, 256}};
+  for (auto& s : shapes)
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(e0, 0);
+      int rc = fod_gemm_tn_acc(FOD_BF16, a, s[1], b, s[2], (float*)c, s[2], s[0], s[1], s[2], nullptr, nullptr, 0, 0);
+      hipEventRecord(e1, 0);
+      hipDeviceSynchronize();
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      snprintf(name, sizeof name, "tn M%d N%d K%d rc%d ev %.1fus", s[0], s[1], s[2], rc, ms * 1e3);
+      show(name, 6);
+    }
+#else
+  const int shapes[][3] = {{256, 256, 64}, {256, 256, 256}, {256, 256, 2048}, {2900, 256, 256}};
+  fod_epilogue epi = {};
+  epi.shift = bias;
+  for (auto& s : shapes)
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(e0, 0);
+      int rc = fod_gemm_nt(FOD_BF16, a, s[2], 0, b, s[2], c, s[1], s[0], s[1], s[2], &epi, 0);
+      hipEventRecord(e1, 0);
+      hipDeviceSynchronize();
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      snprintf(name, sizeof name, "nt M%d N%d K%d rc%d ev %.1fus", s[0], s[1], s[2], rc, ms * 1e3);
+      show(name, 5);
+    }
+#endif
+  return 0;
+}
