@@ -63,12 +63,12 @@ constexpr int ROW_BYTES = 128;   // bytes of k per tile row
 
 FOD_DEVINL int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-// GLDS = true : operand tiles go global -> LDS directly (buffer_load_dwordx4 ... lds, one 1 KB piece = 8 rows x
-//               128 B per wave-instruction).  The DMA writes lane-linear, so the XOR swizzle is applied to the
-//               per-lane SOURCE chunk instead (read side unchanged).  No staging VGPRs, no ds_write_b128 (whose
-//               ~79 B/clk/CU was the busiest LDS port of the register-staged loop).
-// GLDS = false: register-staged ring (kept for A/B measurements, env FOD_NT_GLDS=0).
-template <typename T, int MODE, int NT, bool GLDS>
+// UTAP (conv modes): the source channel count is a multiple of BK, so a k-tile lies inside ONE tap and the tap
+// walk (r, s, c) is block-uniform: it lives in SGPRs and costs scalar instructions; a row's gather offset is
+// then one vector add.  UTAP = false keeps a per-thread tap walk (stem: 8 padded channels, ragged shapes).
+// (An LDS-DMA variant of the operand path -- buffer_load ... lds, swizzle applied to the source chunk -- was
+// measured 2-8 % slower than the register ring on this workload's shapes and removed; see DESIGN.md.)
+template <typename T, int MODE, int NT, bool UTAP>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int BK = ROW_BYTES / (int)sizeof(T);
@@ -104,6 +104,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
   const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
 
   // ---- per-row gather state (fixed over the k loop); offsets in BYTES
+  // dense: a_base = byte offset of the row.  conv modes: byte offset of the image; with UTAP of source pixel
+  // (img, a_h, a_w), channel = this thread's chunk (modulo 2^32 when a_h / a_w are negative: only used after the
+  // bounds check), so that a tap adds or subtracts one uniform byte delta (tap_off below)
   unsigned a_base[4];
   int a_h[4], a_w[4];
 #pragma unroll
@@ -131,6 +134,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
         a_h[i] = valid ? ph + p.pad : -(1 << 28);
         a_w[i] = pw + p.pad;
       }
+      if (UTAP)
+        a_base[i] += ((unsigned)a_h[i] * (unsigned)p.Ws + (unsigned)a_w[i]) * (unsigned)p.Cs * (unsigned)sizeof(T);
     }
   }
   unsigned b_base[BROWS];
@@ -146,17 +151,33 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
     __builtin_memcpy(&u, &v, 16);
     return u;
   };
-  // source chunk column of this thread: with LDS-DMA the lane's LDS slot is fixed (row r0 & 7, position cc of
-  // its 1 KB piece), so the swizzle (position = chunk ^ ((row>>1)&7), same for r0, r0+32, ...) picks the chunk
-  const int ccs = GLDS ? (cc ^ ((r0 >> 1) & 7)) : cc;
-  // running tap decode of this thread's chunk column (see tile_offsets)
-  int tap_r = 0, tap_s = 0, tap_c = ccs * VEC;
+  constexpr unsigned ESZ = sizeof(T);
+  constexpr unsigned BKB = BK * ESZ;
+  const int ccs = cc;
+  const unsigned cc_off = (unsigned)(ccs * VEC) * ESZ;
   const int tap_w = MODE == MODE_DGRAD_S2 ? p.n_s : p.kw;
+  const unsigned tap_row_skip = (unsigned)((p.Ws - tap_w) * p.Cs) * ESZ;
+  const unsigned kb_row_skip = (unsigned)((2 * p.kw - 2 * tap_w) * p.Cs) * ESZ;
+  const unsigned cs_b = (unsigned)p.Cs * ESZ;
+  // Tap walk (r, s, c) of the tile being requested (tiles come in increasing order).
+  //   UTAP : c = the tile's first channel, the state is block-uniform (SGPRs, scalar updates).
+  //          tap_off = ((r * Ws + s) * Cs +- c) * ESZ is the source-side byte delta of (tap (r, s), channel c):
+  //          added to the row's base in the forward conv, subtracted (taps walk backwards, the channel still
+  //          counts up) in both dgrad modes.  tap_kb (MODE_DGRAD_S2) = byte offset of (full-kernel tap, c) in a
+  //          weight row.  Everything advances by adds.
+  //   else : per-thread walk of this thread's chunk; offsets by multiplication (stem, ragged channel counts).
+  int tap_r = 0, tap_s = 0, tap_c = UTAP ? 0 : ccs * VEC;
+  unsigned tap_off = 0, tap_kb = 0;
   if (MODE != MODE_DENSE) {
     const int tap = tap_c / p.Cs;
     tap_c -= tap * p.Cs;
     tap_r = tap / tap_w;
     tap_s = tap - tap_r * tap_w;
+    if (UTAP) {
+      if (MODE == MODE_DGRAD_S2) tap_kb = (unsigned)((p.r_first * p.kw + p.s_first) * p.Cs) * ESZ;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a_base[i] += cc_off;
+    }
   }
   // Register staging ring: tile t lives in ring[t % 3]; two tiles are in flight while a third is consumed
   // from LDS, so a block that is alone on its CU (small problems) still overlaps global latency.
@@ -167,20 +188,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
   Stage st0, st1, st2;
   auto tile_offsets = [&](int kt, unsigned* offa, unsigned* offb) {
     const int k = kt * BK + ccs * VEC;
-    const bool kin = k < p.K;
-    // (r, s, c) of this thread's chunk: kept incrementally (tiles are requested in increasing order), the
-    // two integer divisions per tile were ~5 VALU instructions per MFMA
+    const bool kin = UTAP ? true : k < p.K;          // UTAP: K is a multiple of BK
     const int r = tap_r, s = tap_s, c = tap_c;
-    unsigned kb = (unsigned)k * (unsigned)sizeof(T);     // byte offset of this chunk inside a B row
+    const unsigned toff = tap_off;
+    unsigned kb = (unsigned)k * ESZ;                 // byte offset of this chunk inside a B row
     if (MODE == MODE_DGRAD_S2)
-      kb = (unsigned)(((p.r_first + 2 * r) * p.kw + p.s_first + 2 * s) * p.Cs + c) * (unsigned)sizeof(T);
-    if (MODE != MODE_DENSE) {
+      kb = UTAP ? tap_kb + cc_off
+                : (unsigned)(((p.r_first + 2 * r) * p.kw + p.s_first + 2 * s) * p.Cs + c) * ESZ;
+    if (MODE != MODE_DENSE) {                        // advance to the next tile's tap
       tap_c += BK;
-      while (tap_c >= p.Cs) {
+      if (UTAP) {
+        tap_off = MODE == MODE_CONV ? tap_off + BKB : tap_off - BKB;
+        tap_kb += BKB;
+      }
+      while (tap_c >= p.Cs) {                        // UTAP: at most once, uniform
         tap_c -= p.Cs;
+        if (UTAP) {
+          if (MODE != MODE_CONV) tap_off += 2 * cs_b;   // (s+1)*Cs - (c-Cs) vs s*Cs - c; forward: the sum is unchanged
+          tap_kb += cs_b;                               // the full kernel advances by two taps
+        }
         if (++tap_s == tap_w) {
           tap_s = 0;
           ++tap_r;
+          if (UTAP) {
+            tap_off += tap_row_skip;
+            tap_kb += kb_row_skip;
+          }
         }
       }
     }
@@ -189,20 +222,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
       unsigned off;
       if (MODE == MODE_DENSE) {
         off = (kin && a_base[i] != OOB) ? a_base[i] + kb : OOB;
-      } else if (MODE == MODE_CONV) {
-        const int hs = a_h[i] + r, ws = a_w[i] + s;
-        const bool ok = kin && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
-        off = ok ? a_base[i] + (unsigned)((hs * p.Ws + ws) * p.Cs + c) * (unsigned)sizeof(T) : OOB;
-      } else if (MODE == MODE_DGRAD_S2) {
-        const int hs = a_h[i] - r, ws = a_w[i] - s;
-        const bool ok = kin && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
-        off = ok ? a_base[i] + (unsigned)((hs * p.Ws + ws) * p.Cs + c) * (unsigned)sizeof(T) : OOB;
       } else {
-        const int th = a_h[i] - r, tw = a_w[i] - s;
-        const int sm = p.stride - 1;   // stride is 1 or 2
-        const int hs = th >> (p.stride >> 1), ws = tw >> (p.stride >> 1);
-        const bool ok = kin && th >= 0 && tw >= 0 && ((th | tw) & sm) == 0 && hs < p.Hs && ws < p.Ws;
-        off = ok ? a_base[i] + (unsigned)((hs * p.Ws + ws) * p.Cs + c) * (unsigned)sizeof(T) : OOB;
+        // forward: source = (a_h + r, a_w + s); both dgrad modes walk the taps backwards
+        const int hs = MODE == MODE_CONV ? a_h[i] + r : a_h[i] - r;
+        const int ws = MODE == MODE_CONV ? a_w[i] + s : a_w[i] - s;
+        const bool ok = kin && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
+        if (UTAP) off = ok ? (MODE == MODE_CONV ? a_base[i] + toff : a_base[i] - toff) : OOB;
+        else off = ok ? a_base[i] + (unsigned)((hs * p.Ws + ws) * p.Cs + c) * ESZ : OOB;
       }
       offa[i] = off;
     }
@@ -216,20 +242,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
     for (int i = 0; i < 4; ++i) st.a[i] = bload(rsA, offa[i]);
 #pragma unroll
     for (int i = 0; i < BROWS; ++i) st.b[i] = bload(rsB, offb[i]);
-  };
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-  auto issue_tile = [&](int kt, int buf) {     // LDS-DMA: lane l of the wave lands at piece base + 16*l
-    unsigned offa[4], offb[BROWS];
-    tile_offsets(kt, offa, offb);
-    const int piece_row = (r0 & ~7);           // 8 * wave
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsA, (lds_ptr)(sA + buf * BM * ROW_BYTES + (piece_row + 32 * i) * ROW_BYTES), 16, (int)offa[i], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < BROWS; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rsB, (lds_ptr)(sB + buf * BN * ROW_BYTES + (piece_row + 32 * i) * ROW_BYTES), 16, (int)offb[i], 0, 0, 0);
   };
   auto store_tile = [&](int buf, const Stage& st) {
 #pragma unroll
@@ -248,23 +260,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // per-column scale / shift of the vectorised epilogue, requested before the k-loop: loaded after it they are
-  // a cold dependent miss (~1-2 us) on the critical path of every short launch
-  f32x4 epi_sc = {1.f, 1.f, 1.f, 1.f}, epi_sh = {0.f, 0.f, 0.f, 0.f};
-  if (p.vec_epi) {
-    const int nce = min(n0 + (tid % (BN / 4)) * 4, p.N - 4);
-    if (p.scale) epi_sc = *reinterpret_cast<const f32x4*>(p.scale + nce);
-    if (p.shift) epi_sh = *reinterpret_cast<const f32x4*>(p.shift + nce);
-  }
   const int nkt = (p.K + BK - 1) / BK;
-  if (GLDS) {
-    issue_tile(0, 0);
-  } else {
-    load_tile(0, st0);
-    if (nkt > 1) load_tile(1, st1);
-    FOD_STAMP(1);
-    store_tile(0, st0);
-  }
+  load_tile(0, st0);
+  if (nkt > 1) load_tile(1, st1);
+  FOD_STAMP(1);
+  store_tile(0, st0);
   __syncthreads();
   FOD_STAMP(2);
 
@@ -315,20 +315,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
     if ((k) + 1 < nkt) store_tile(((k) + 1) & 1, ST); \
     __syncthreads();                                  \
   }
-  if (GLDS) {
-    // the DMA of tile kt+1 flies during the MFMAs of tile kt; __syncthreads() waits for it (hipcc emits
-    // vmcnt(0) ahead of the barrier while an LDS-DMA is outstanding) and orders the LDS reuse
-    for (int kt = 0; kt < nkt; ++kt) {
-      if (kt + 1 < nkt) issue_tile(kt + 1, (kt + 1) & 1);
-      compute(kt & 1);
-      __syncthreads();
-    }
-  } else {
-    for (int kt = 0; kt < nkt; kt += 3) {
-      FOD_NT_STEP(kt, st2, st1)
-      FOD_NT_STEP(kt + 1, st0, st2)
-      FOD_NT_STEP(kt + 2, st1, st0)
-    }
+  for (int kt = 0; kt < nkt; kt += 3) {
+    FOD_NT_STEP(kt, st2, st1)
+    FOD_NT_STEP(kt + 1, st0, st2)
+    FOD_NT_STEP(kt + 2, st1, st0)
   }
 #undef FOD_NT_STEP
   FOD_STAMP(3);
@@ -381,7 +371,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
         for (int r = 0; r < 16; ++r)
           sC[(wm * 64 + i * 32 + acc_row(r, lane)) * BN + wn * (32 * NT) + j * 32 + fr] = acc[i][j][r];
     __syncthreads();
-    const f32x4 sc = epi_sc, sh = epi_sh;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + nc);
+    if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + nc);
 #pragma unroll
     for (int base = 0; base < NPASS; base += PB) {
       if (base > 0) prefetch(base);
@@ -620,19 +612,19 @@ int launch_nt(const NtParams& p, hipStream_t stream) {
   const dim3 block(256);
   NtParams q = p;
   q.gy = ceil_div(p.M, BM);
-  static const char* env_glds = getenv("FOD_NT_GLDS");
-  const bool glds = env_glds && env_glds[0] == '1';   // measured: the register ring wins on this workload
+  constexpr int BK = ROW_BYTES / (int)sizeof(T);
+  const bool utap = MODE != MODE_DENSE && p.Cs % BK == 0;     // a k-tile never straddles two taps
   if (narrow) {
     q.gx = ceil_div(p.N, 64);
     const dim3 grid(q.gx * ((q.gy + 7) / 8 * 8));
     const size_t lds = 2 * (BM + 64) * ROW_BYTES;
-    if (glds) hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 1, true>), grid, block, lds, stream, q);
+    if (utap) hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 1, MODE != MODE_DENSE>), grid, block, lds, stream, q);
     else hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 1, false>), grid, block, lds, stream, q);
   } else {
     q.gx = ceil_div(p.N, 128);
     const dim3 grid(q.gx * ((q.gy + 7) / 8 * 8));
     const size_t lds = 2 * (BM + 128) * ROW_BYTES;
-    if (glds) hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 2, true>), grid, block, lds, stream, q);
+    if (utap) hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 2, MODE != MODE_DENSE>), grid, block, lds, stream, q);
     else hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 2, false>), grid, block, lds, stream, q);
   }
   FOD_LAUNCH_CHECK();

@@ -63,8 +63,9 @@ FOD_DEVINL void tn_frag(Frag<__bf16>& f, const unsigned char* tile, int ks, int 
       (lds_s4)(tile + row0 * TnCfg<__bf16>::PITCH + col * 2));
   const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (lds_s4)(tile + (row0 + 4) * TnCfg<__bf16>::PITCH + col * 2));
-  short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  __builtin_memcpy(&f, tmp, 16);
+  typedef __attribute__((ext_vector_type(8))) short short8_t;
+  const short8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);   // register pairing, no VALU
+  __builtin_memcpy(&f, &v, 16);
 }
 FOD_DEVINL void tn_frag(Frag<float>& f, const unsigned char* tile, int ks, int colbase, int lane) {
   const int h = lane >> 5;
@@ -137,43 +138,68 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     uint4 x[PASSES];
   };
   Stage st[RING];           // step t lives in st[t % RING]; RING-1 steps in flight
-  // pixel coordinates of this thread's rows, advanced by MSTEP per requested step (steps are requested in
-  // increasing order): replaces two integer divisions per row per step
-  int px_img[PASSES], px_h[PASSES], px_w[PASSES];
-  if (MODE == MODE_CONV) {
+  // Running addresses of this thread's rows, advanced by MSTEP per requested step (steps are requested in
+  // increasing order).  Everything is a 32-bit byte offset updated by adds: the straightforward form (two
+  // integer divisions, 64-bit multiply-adds and three v_mul_lo_u32 per row per step) made the loop
+  // VALU-bound -- ~100 VALU instructions, 12 of them quarter-rate, against 8 MFMAs per step.
+  constexpr unsigned ESZ = sizeof(T);
+  int row_m[PASSES];                 // global row (pixel) index of the next request
+  unsigned off_g[PASSES];            // byte offset of G(row, gi)
+  unsigned off_x[PASSES];            // dense: byte offset of X(row, xj); conv: of source pixel (img, hs, 0), channel xc
+  unsigned ws_b[PASSES];             // conv: ws * Cs * ESZ
+  int px_h[PASSES], px_w[PASSES], src_h[PASSES], src_w[PASSES];
+  const unsigned step_g = (unsigned)(MSTEP * p.ldg) * ESZ;
+  const unsigned step_x = MODE == MODE_DENSE ? (unsigned)(MSTEP * p.ldx) * ESZ : (unsigned)(MSTEP * p.stride * p.Cs) * ESZ;
+  const unsigned line_b = (unsigned)(p.Ws * p.Cs) * ESZ;          // one source row
 #pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-      const int m = mb + prow + ps * RPP;
+  for (int ps = 0; ps < PASSES; ++ps) {
+    const int m = mb + prow + ps * RPP;
+    row_m[ps] = m;
+    off_g[ps] = (unsigned)(((long)m * p.ldg + gi) * (long)ESZ);
+    if (MODE == MODE_DENSE) {
+      off_x[ps] = (unsigned)(((long)m * p.ldx + xj) * (long)ESZ);
+    } else {
       const int hw = p.Hd * p.Wd;
-      px_img[ps] = m / hw;
-      const int rem = m - px_img[ps] * hw;
+      const int img = m / hw;
+      const int rem = m - img * hw;
       px_h[ps] = rem / p.Wd;
       px_w[ps] = rem - px_h[ps] * p.Wd;
+      src_h[ps] = px_h[ps] * p.stride - p.pad + xr;
+      src_w[ps] = px_w[ps] * p.stride - p.pad + xs;
+      off_x[ps] = (unsigned)((((long)img * p.Hs + src_h[ps]) * p.Ws * p.Cs + xc) * (long)ESZ);
+      ws_b[ps] = (unsigned)(src_w[ps] * p.Cs) * ESZ;
     }
   }
-  auto load_step = [&](int m_start, Stage& st) {
+  auto load_step = [&](Stage& st) {
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
-      const int m = m_start + prow + ps * RPP;
-      const bool in = m < mend;
-      unsigned og = (in && g_ok) ? (unsigned)(((long)m * p.ldg + gi) * (long)sizeof(T)) : OOB;
+      const bool in = row_m[ps] < mend;
+      const unsigned og = (in && g_ok) ? off_g[ps] : OOB;
       unsigned ox;
       if (MODE == MODE_DENSE) {
-        ox = (in && x_ok) ? (unsigned)(((long)m * p.ldx + xj) * (long)sizeof(T)) : OOB;
+        ox = (in && x_ok) ? off_x[ps] : OOB;
       } else {
-        const int img = px_img[ps], ph = px_h[ps], pw = px_w[ps];
-        const int hs = ph * p.stride - p.pad + xr, ws = pw * p.stride - p.pad + xs;
-        const bool ok = in && x_ok && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
-        ox = ok ? (unsigned)(((((long)img * p.Hs + hs) * p.Ws + ws) * p.Cs + xc) * (long)sizeof(T)) : OOB;
+        const bool ok = in && x_ok && (unsigned)src_h[ps] < (unsigned)p.Hs && (unsigned)src_w[ps] < (unsigned)p.Ws;
+        ox = ok ? off_x[ps] + ws_b[ps] : OOB;
         px_w[ps] += MSTEP;
-        while (px_w[ps] >= p.Wd) {
+        src_w[ps] += MSTEP * p.stride;
+        ws_b[ps] += step_x;
+        while (px_w[ps] >= p.Wd) {                       // next output row (rare: once per Wd / MSTEP steps)
           px_w[ps] -= p.Wd;
-          if (++px_h[ps] == p.Hd) {
+          src_w[ps] -= p.Wd * p.stride;
+          ws_b[ps] -= (unsigned)(p.Wd * p.stride * p.Cs) * ESZ;
+          src_h[ps] += p.stride;
+          off_x[ps] += (unsigned)p.stride * line_b;
+          if (++px_h[ps] == p.Hd) {                      // next image: its row -pad+xr follows the last source row
             px_h[ps] = 0;
-            ++px_img[ps];
+            off_x[ps] += (unsigned)(p.Hs - p.Hd * p.stride) * line_b;
+            src_h[ps] -= p.Hd * p.stride;
           }
         }
       }
+      row_m[ps] += MSTEP;
+      off_g[ps] += step_g;
+      if (MODE == MODE_DENSE) off_x[ps] += step_x;
       st.g[ps] = bload(rsG, og);
       st.x[ps] = bload(rsX, ox);
     }
@@ -208,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
   const int nst = mb < mend ? (mend - mb + MSTEP - 1) / MSTEP : 0;
 #pragma unroll
   for (int r = 0; r < RING - 1; ++r)
-    if (r < nst) load_step(mb + r * MSTEP, st[r]);
+    if (r < nst) load_step(st[r]);
   FOD_STAMP(1);
   if (nst > 0) store_step(0, st[0]);
   __syncthreads();
@@ -229,16 +255,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
         for (int b = 0; b < 2; ++b) mma16(fa[a], fb[b], acc[a][b]);
     }
   };
-  for (int t = 0; t < nst; t += RING) {
+  // Whole groups of RING steps run without any guard: a request past the split's rows is all-OOB (zeros, no
+  // memory access), so the body is straight-line code and hipcc keeps counted vmcnt waits -- a guard around a
+  // load_step makes it drain to vmcnt(0) at the join, i.e. wait for the prefetch it has just issued.
+  int t = 0;
+  for (; t + RING <= nst; t += RING) {
 #pragma unroll
     for (int r = 0; r < RING; ++r) {       // fully unrolled: every ring index is a compile-time constant
-      const int k = t + r;
-      if (k < nst) {
-        if (k + RING - 1 < nst) load_step(mb + (k + RING - 1) * MSTEP, st[(r + RING - 1) % RING]);
-        compute(k & 1);
-        if (k + 1 < nst) store_step((k + 1) & 1, st[(r + 1) % RING]);
-        __syncthreads();
-      }
+      load_step(st[(r + RING - 1) % RING]);
+      compute((t + r) & 1);
+      store_step((t + r + 1) & 1, st[(r + 1) % RING]);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RING; ++r) {         // tail: fewer than RING steps left, nothing more to request
+    if (t + r < nst) {
+      compute((t + r) & 1);
+      if (t + r + 1 < nst) store_step((t + r + 1) & 1, st[(r + 1) % RING]);
+      __syncthreads();
     }
   }
   FOD_STAMP(3);
@@ -453,9 +488,10 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const TnParams p) {
       const int o1 = o0 + 4 * 128;                               // row + 4 has the same swizzle bit
       const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(tile + o0));
       const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(tile + o1));
+      typedef __attribute__((ext_vector_type(8))) short short8_t;
+      const short8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       Frag<T> f;
-      short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      __builtin_memcpy(&f, tmp, 16);
+      __builtin_memcpy(&f, &v, 16);
       return f;
     };
 #pragma unroll
