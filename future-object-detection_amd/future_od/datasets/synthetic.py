@@ -54,4 +54,7 @@ def make_batch(B, L, H, W, seed=1234, device="cpu", num_classes=8, max_boxes=40,
         active[b, :nb] = 1
     data.update(boxes=boxes, classes=classes, active=active,
                 ignore_boxes=torch.zeros(B, MAX_NUM_OBJECTS, 4))
-    return {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in data.items()}
+    out = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in data.items()}
+    # host copies of the annotations, as recursive_to() keeps them for a loader batch
+    out["_host_annotations"] = {"active": active, "boxes": boxes, "classes": classes}
+    return out

@@ -35,10 +35,16 @@ class HungarianMatcher(nn.Module):
         ld = max(max(sizes), 1)
         cost = ops.match_cost(logits, boxes, packed["labels"], packed["boxes"], packed["offset"], ld,
                               self.cost_class, self.cost_bbox, self.cost_giou)
-        local = ops.lap_solve_batch_host(cost.cpu().view(Lv * B, M, ld), sizes * Lv, threads).view(Lv, B, M)
+        if cost.device.type == "cuda":       # the one host sync of the step: D2H through pinned memory
+            cost_h = torch.empty(cost.shape, dtype=cost.dtype, pin_memory=True)
+            cost_h.copy_(cost, non_blocking=True)
+            torch.cuda.current_stream(cost.device).synchronize()
+        else:
+            cost_h = cost
+        local = ops.lap_solve_batch_host(cost_h.view(Lv * B, M, ld), sizes * Lv, threads).view(Lv, B, M)
         off = packed["offset_cpu"][:B].view(1, B, 1)
         glob = torch.where(local >= 0, local + off, local)
-        return glob.to(logits.device, non_blocking=True), local
+        return _to_device_async(glob, logits.device), local
 
     @torch.no_grad()
     def forward(self, outputs, targets):
@@ -59,20 +65,29 @@ def build_matcher(args):
                             cost_giou=args.set_cost_giou)
 
 
+def _to_device_async(t, device):
+    """Host tensor -> device through pinned memory, without blocking the host on the stream."""
+    if t.device.type != "cpu" or device.type == "cpu":
+        return t.to(device)
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def pack_targets(targets, device):
-    """list of {"labels","boxes"} -> concatenated device tensors + per-sample offsets (one host sync,
-    meant to run BEFORE the model forward is queued so it does not stall the stream)."""
+    """list of {"labels","boxes"} -> concatenated device tensors + per-sample offsets.  Host targets (the usual
+    case, see st_detr.forward) are packed on the host and uploaded asynchronously; device targets cost one sync."""
+    device = torch.device(device)
     sizes = [int(t["labels"].shape[0]) for t in targets]
-    labels = torch.cat([t["labels"] for t in targets]).to(device=device, dtype=torch.int64).contiguous()
-    boxes = torch.cat([t["boxes"] for t in targets]).to(device=device, dtype=torch.float32).contiguous()
+    labels = torch.cat([t["labels"] for t in targets]).to(dtype=torch.int64).contiguous()
+    boxes = torch.cat([t["boxes"] for t in targets]).to(dtype=torch.float32).contiguous()
     off = [0]
     for s in sizes:
         off.append(off[-1] + s)
     off_cpu = torch.tensor(off, dtype=torch.int32)
     if labels.numel() == 0:          # keep pointers valid for the kernels
-        labels = torch.zeros(1, dtype=torch.int64, device=device)
-        boxes = torch.zeros((1, 4), dtype=torch.float32, device=device)
-    return {"sizes": sizes, "labels": labels, "boxes": boxes, "offset": off_cpu.to(device), "offset_cpu": off_cpu}
+        labels = torch.zeros(1, dtype=torch.int64, device=labels.device)
+        boxes = torch.zeros((1, 4), dtype=torch.float32, device=boxes.device)
+    return {"sizes": sizes, "labels": _to_device_async(labels, device), "boxes": _to_device_async(boxes, device),
+            "offset": _to_device_async(off_cpu, device), "offset_cpu": off_cpu}
 
 
 class _SetLossFn(Function):
@@ -93,6 +108,14 @@ class _SetLossFn(Function):
         dl, db = ops.set_loss_bwd(logits, boxes, match, ctx.packed["labels"], ctx.packed["boxes"], g,
                                   ctx.num_boxes, ctx.alpha)
         return dl, db, None, None, None, None
+
+
+class _PendingNumBoxes:
+    def __init__(self, t, world):
+        self.t, self.world = t, world
+
+    def resolve(self):
+        return max(float(self.t.item()) / self.world, 1.0)
 
 
 class LossDict(dict):
@@ -116,14 +139,19 @@ class SetCriterion(nn.Module):
         for name in losses:
             assert name in ("labels", "boxes", "cardinality"), f"do you really want to compute {name} loss?"
 
-    def global_num_boxes(self, targets, device, distributed):
-        """set_criterion.py:185-193: mean number of boxes per rank, clamped to >= 1."""
+    def global_num_boxes(self, targets, device, distributed, lazy=False):
+        """set_criterion.py:185-193: mean number of boxes per rank, clamped to >= 1.
+
+        `lazy=True` (distributed only) queues the all-reduce now and returns a handle whose `resolve()` reads the
+        value back later: forward() resolves it right after the matcher's host sync, when the result has long
+        arrived, instead of stalling the host on the previous step's backward at the start of the step."""
         n = float(sum(int(t["labels"].shape[0]) for t in targets))
-        if distributed:
-            t = torch.tensor([n], dtype=torch.float, device=device)
-            dist.all_reduce(t)
-            n = float(t.item()) / dist.get_world_size()
-        return max(n, 1.0)
+        if not distributed:
+            return max(n, 1.0)
+        t = _to_device_async(torch.tensor([n], dtype=torch.float), torch.device(device))
+        dist.all_reduce(t)
+        pending = _PendingNumBoxes(t, dist.get_world_size())
+        return pending if lazy else pending.resolve()
 
     def forward(self, outputs, targets, distributed, packed=None, num_boxes=None):
         if "_stacked" in outputs:
@@ -143,6 +171,8 @@ class SetCriterion(nn.Module):
         else:
             match, _ = self.matcher.match_levels(logits.detach()[-1:], boxes.detach()[-1:], packed)
             match = match.expand(Lv, -1, -1).contiguous()
+        if isinstance(num_boxes, _PendingNumBoxes):
+            num_boxes = num_boxes.resolve()
         table = _SetLossFn.apply(logits, boxes, match, packed, num_boxes, self.focal_alpha)
         out = LossDict()
         out.table = table

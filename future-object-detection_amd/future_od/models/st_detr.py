@@ -83,11 +83,15 @@ class SpatioTemporalDETR(nn.Module):
     def forward(self, data=None, visualize=False, epoch=None, distributed=False):
         images = data["video"]
         B, L, _, H, W = images.shape
-        # --- host-side preparation first (target packing syncs; nothing is queued yet)
-        targets = to_detr_targets(H=H, W=W, anno_active=data["active"], anno_boxes=data["boxes"],
-                                  anno_classes=data["classes"])
+        # --- host-side preparation first.  With the loader's host copies of the annotations (recursive_to keeps
+        # them) this touches no device tensor: no wait on the previous step's queued backward, so the host
+        # queues this forward while the GPU is still draining it.  Without them the boolean indexing below reads
+        # the counts back from the device (one sync per sample, as in the reference).
+        anno = data.get("_host_annotations") or data
+        targets = to_detr_targets(H=H, W=W, anno_active=anno["active"], anno_boxes=anno["boxes"],
+                                  anno_classes=anno["classes"])
         packed = pack_targets(targets, images.device)
-        num_boxes = self._criterion.global_num_boxes(targets, images.device, distributed)
+        num_boxes = self._criterion.global_num_boxes(targets, images.device, distributed, lazy=True)
         kwargs = {}
         if data.get("translation") is not None:
             kwargs["imu"] = torch.cat([data[k] for k in self._imu_keys], dim=2)

@@ -46,9 +46,17 @@ class FusedAdamW(torch.optim.Optimizer):
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         return st
 
+    @staticmethod
+    def _upload(host, dev):
+        """Host table -> device without blocking the host on the stream (a pageable copy synchronises it, i.e.
+        waits for the whole queued backward; the optimizer is the last thing queued in a step, so that wait
+        would also keep the host from queueing the next forward while the GPU drains)."""
+        pinned = host.pin_memory()
+        return pinned.to(dev, non_blocking=True), pinned
+
     def _build_plan(self):
-        """Slow path: (re)build the device tables for the current set of (param, grad, moment) pointers."""
-        entries, params, keepalive = [], [], []
+        """(Re)build the device tables for the current set of (param, grad, moment) pointers."""
+        entries, params = [], []
         for grp in self.param_groups:
             for p in grp["params"]:
                 g = p.grad
@@ -65,6 +73,11 @@ class FusedAdamW(torch.optim.Optimizer):
         if not entries:
             return None
         dev = params[0].device
+        tab, ring = self._tables_for(entries, dev)
+        return {"params": params, "gptrs": [e[1] for e in entries], "tab": tab, "ring": ring, "turn": 0,
+                "lrs": [(g["lr"], g["weight_decay"]) for g in self.param_groups], "dev": dev}
+
+    def _tables_for(self, entries, dev):
         ptrs = torch.tensor([e[:4] for e in entries], dtype=torch.int64)
         numel = torch.tensor([e[4] for e in entries], dtype=torch.int64)
         lr_wd = torch.tensor([e[5:7] for e in entries], dtype=torch.float32)
@@ -73,10 +86,32 @@ class FusedAdamW(torch.optim.Optimizer):
             for c in range((e[4] + self._chunk - 1) // self._chunk):
                 bt.append(t)
                 bc.append(c)
-        tab = tuple(x.to(dev) for x in (ptrs, numel, lr_wd, torch.tensor(bt, dtype=torch.int32),
-                                        torch.tensor(bc, dtype=torch.int32)))
-        return {"params": params, "gptrs": [e[1] for e in entries], "tab": tab,
-                "lrs": [(g["lr"], g["weight_decay"]) for g in self.param_groups], "dev": dev}
+        up = [self._upload(x, dev) for x in (ptrs, numel, lr_wd, torch.tensor(bt, dtype=torch.int32),
+                                             torch.tensor(bc, dtype=torch.int32))]
+        # pinned copies of the pointer table, used in turn when only gradient addresses move between steps; the
+        # step's one host sync (the matcher) bounds how far the GPU lags, three buffers are never in flight at once
+        ring = [up[0][1], up[0][1].clone().pin_memory(), up[0][1].clone().pin_memory()]
+        self._keep = [u[1] for u in up]
+        return tuple(u[0] for u in up), ring
+
+    def _refresh_grad_pointers(self, plan):
+        """Same parameters as last step; returns False if the plan no longer applies."""
+        gptrs = []
+        for p, old in zip(plan["params"], plan["gptrs"]):
+            g = p.grad
+            if g is None:
+                return False
+            gp = g.data_ptr()
+            if gp != old and (g.dtype != torch.float32 or not _same_layout(g, p)):
+                return False
+            gptrs.append(gp)
+        if gptrs != plan["gptrs"]:
+            plan["turn"] = (plan["turn"] + 1) % len(plan["ring"])
+            host = plan["ring"][plan["turn"]]
+            host[:, 1] = torch.tensor(gptrs, dtype=torch.int64)
+            plan["tab"][0].copy_(host, non_blocking=True)
+            plan["gptrs"] = gptrs
+        return True
 
     def _launch(self, tab, dev, betas, eps):
         ptrs, numel, lr_wd, bt, bc = tab
@@ -101,17 +136,14 @@ class FusedAdamW(torch.optim.Optimizer):
         for grp in self.param_groups:
             assert grp["betas"] == betas and grp["eps"] == eps    # lr / weight decay are per tensor, these are shared
         self._step_no = getattr(self, "_step_no", 0) + 1
-        # fast path: the same tensors at the same addresses as last step (the gradient arena hands out the
-        # same slots every step) -> two launches, no per-parameter Python work beyond reading the pointers
+        # fast path: the same parameters as last step.  The gradient arena hands out the same slots every step, so
+        # usually nothing moved; gradients that autograd allocates itself (sums of slices) get fresh addresses,
+        # then only the pointer column is refreshed -- asynchronously, never a blocking copy
         plan = getattr(self, "_plan", None)
         if plan is not None:
-            ok = plan["lrs"] == [(g["lr"], g["weight_decay"]) for g in self.param_groups]
-            if ok:
-                for p, gp in zip(plan["params"], plan["gptrs"]):
-                    g = p.grad
-                    if g is None or g.data_ptr() != gp:
-                        ok = False
-                        break
+            n_with_grad = sum(1 for grp in self.param_groups for p in grp["params"] if p.grad is not None)
+            ok = (plan["lrs"] == [(g["lr"], g["weight_decay"]) for g in self.param_groups]
+                  and n_with_grad == len(plan["params"]) and self._refresh_grad_pointers(plan))
             if ok:
                 self._launch(plan["tab"], plan["dev"], betas, eps)
                 return None
@@ -138,16 +170,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if not entries:
             return None
         dev = self.param_groups[0]["params"][0].device
-        ptrs = torch.tensor([e[:4] for e in entries], dtype=torch.int64)
-        numel = torch.tensor([e[4] for e in entries], dtype=torch.int64)
-        lr_wd = torch.tensor([e[5:7] for e in entries], dtype=torch.float32)
-        bt, bc = [], []
-        for t, e in enumerate(entries):
-            for c in range((e[4] + self._chunk - 1) // self._chunk):
-                bt.append(t)
-                bc.append(c)
-        tab = tuple(x.to(dev) for x in (ptrs, numel, lr_wd, torch.tensor(bt, dtype=torch.int32),
-                                        torch.tensor(bc, dtype=torch.int32)))
+        tab, _ring = self._tables_for(entries, dev)
         self._launch(tab, dev, betas, eps)
         del keepalive
         return None

@@ -66,3 +66,23 @@ def test_lap_matches_scipy(shape):
         assert abs(c[mine_i, mine_j].sum() - c[i, j].sum()) < 1e-9          # same optimum always
         if p >= 2:                                                          # untied problems: same assignment
             assert np.array_equal(mine_i, i) and np.array_equal(mine_j, j)
+
+
+def test_recursive_to_keeps_host_annotations():
+    """The batch mover keeps the loader's host copies of the dense annotations (the step's target packing reads
+    them instead of syncing on the device copies) and leaves other batches alone."""
+    import torch
+    from future_od.datasets.synthetic import make_batch
+    from future_od.models.st_detr import to_detr_targets
+    from future_od.models.set_criterion import pack_targets
+    from future_od.utils.recursive_functions import recursive_to
+    batch = make_batch(2, 2, 16, 24, seed=3, max_boxes=5)
+    batch.pop("_host_annotations")
+    moved = recursive_to(batch, torch.device("cpu"))
+    host = moved["_host_annotations"]
+    assert set(host) == {"active", "boxes", "classes"} and host["active"] is batch["active"]
+    assert "_host_annotations" not in recursive_to({"video": batch["video"]}, torch.device("cpu"))
+    targets = to_detr_targets(16, 24, host["active"], host["boxes"], host["classes"])
+    packed = pack_targets(targets, "cpu")
+    assert packed["sizes"] == [int(batch["active"][b].sum()) for b in range(2)]
+    assert packed["labels"].shape[0] == sum(packed["sizes"]) and packed["offset_cpu"].tolist()[-1] == sum(packed["sizes"])

@@ -129,6 +129,23 @@ def test_fp32_parity_with_oracle_and_golden(golden, name):
         assert torch.equal(i.cpu(), ri) and torch.equal(j.cpu(), rj)
 
 
+def test_host_annotation_path_is_exact():
+    """Targets built from the loader's host copies of the annotations (no device read-back at the start of the
+    step) give bit-identical losses and matches to targets read back from the device tensors."""
+    cfg = Config(backbone="resnet18", enc_layers=1, dec_layers=2)
+    model, _ = build_product(cfg, torch.float32, 4)
+    data = make_batch(2, 3, 64, 96, seed=4, device=DEV, max_boxes=7)
+    assert "_host_annotations" in data
+    _, _, loss_a, stats_a, od_a = model(data=data, distributed=False)
+    no_host = {k: v for k, v in data.items() if k != "_host_annotations"}
+    _, _, loss_b, stats_b, od_b = model(data=no_host, distributed=False)
+    assert torch.equal(loss_a, loss_b)
+    for k in stats_a:
+        assert torch.equal(stats_a[k], stats_b[k]), k
+    for x, y in zip(od_a, od_b):
+        assert torch.equal(x, y)
+
+
 def test_dead_frame_skipping_is_exact():
     cfg = Config(backbone="resnet18", enc_layers=1, dec_layers=1)
     model, _ = build_product(cfg, torch.float32, 3)
