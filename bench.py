@@ -43,6 +43,18 @@ def build(args, device, distributed, num_images, dtype="bf16"):
     return build_model(a, detr), detr
 
 
+def pmc_traffic_per_launch(entry):
+    """HBM bytes per launch of `entry` from the committed PMC passes (profiles/pmc_traffic.json, written by
+    tools/pmc_traffic.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same workload; FETCH doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  PMC passes cannot run inside the timed bench; None if absent."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)[entry]["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(num_images, cores):
     """The oracle (plain-PyTorch fp32 restatement of the reference graph) on this box's host cores:
     ONE frame-sequence (B=1), forward + backward, same shapes.  Checker code used as the baseline leg
@@ -165,7 +177,8 @@ def main():
         achieved = rec["work"] / rec["seconds"] / 1e12
         result["device_ms_per_step_profiled"] = 1e3 * total / nprof
         result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
-                              "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                              "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+                              "traffic": pmc_traffic_per_launch(name),
                               "avg_launch_us": 1e6 * rec["seconds"] / rec["calls"], "launches_per_step": rec["calls"] / nprof,
                               "share_of_device_time": rec["seconds"] / total}
         result["kernel_breakdown"] = {k: {"ms_per_step": 1e3 * v["seconds"] / nprof, "calls_per_step": v["calls"] / nprof,

@@ -69,7 +69,7 @@ FOD_DEVINL int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ 
 // (An LDS-DMA variant of the operand path -- buffer_load ... lds, swizzle applied to the source chunk -- was
 // measured 2-8 % slower than the register ring on this workload's shapes and removed; see DESIGN.md.)
 template <typename T, int MODE, int NT, bool UTAP>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
+FOD_DEVINL void gemm_nt_body(const NtParams& p) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int BK = ROW_BYTES / (int)sizeof(T);
   constexpr int BN = 64 * NT;
@@ -439,6 +439,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
   }
 }
 
+// One named kernel per C-ABI entry point, so that a rocprofv3 summary reads like include/fod.h.
+template <typename T, int NT>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
+  gemm_nt_body<T, MODE_DENSE, NT, false>(p);
+}
+template <typename T, int NT, bool UTAP>
+__global__ __launch_bounds__(256, 2) void conv2d_fwd_kernel(const NtParams p) {
+  gemm_nt_body<T, MODE_CONV, NT, UTAP>(p);
+}
+template <typename T, int NT, bool UTAP>
+__global__ __launch_bounds__(256, 2) void conv2d_dgrad_kernel(const NtParams p) {
+  gemm_nt_body<T, MODE_DGRAD, NT, UTAP>(p);
+}
+template <typename T, int NT, bool UTAP>
+__global__ __launch_bounds__(256, 2) void conv2d_dgrad_s2_kernel(const NtParams p) {
+  gemm_nt_body<T, MODE_DGRAD_S2, NT, UTAP>(p);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Short-launch variant for the decoder's query-side GEMMs (M = batch x queries = a few hundred rows, 300+
 // launches per step).  At that size the tiled kernel above runs one block per CU with nothing to overlap:
@@ -614,19 +632,27 @@ int launch_nt(const NtParams& p, hipStream_t stream) {
   q.gy = ceil_div(p.M, BM);
   constexpr int BK = ROW_BYTES / (int)sizeof(T);
   const bool utap = MODE != MODE_DENSE && p.Cs % BK == 0;     // a k-tile never straddles two taps
-  if (narrow) {
-    q.gx = ceil_div(p.N, 64);
-    const dim3 grid(q.gx * ((q.gy + 7) / 8 * 8));
-    const size_t lds = 2 * (BM + 64) * ROW_BYTES;
-    if (utap) hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 1, MODE != MODE_DENSE>), grid, block, lds, stream, q);
-    else hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 1, false>), grid, block, lds, stream, q);
+  q.gx = ceil_div(p.N, narrow ? 64 : 128);
+  const dim3 grid(q.gx * ((q.gy + 7) / 8 * 8));
+  const size_t lds = 2 * (BM + (narrow ? 64 : 128)) * ROW_BYTES;
+#define FOD_NT_LAUNCH(KERNEL_NT1, KERNEL_NT2)                                        \
+  do {                                                                               \
+    if (narrow) hipLaunchKernelGGL((KERNEL_NT1), grid, block, lds, stream, q);       \
+    else hipLaunchKernelGGL((KERNEL_NT2), grid, block, lds, stream, q);              \
+  } while (0)
+  if constexpr (MODE == MODE_DENSE) {
+    FOD_NT_LAUNCH((gemm_nt_kernel<T, 1>), (gemm_nt_kernel<T, 2>));
+  } else if constexpr (MODE == MODE_CONV) {
+    if (utap) FOD_NT_LAUNCH((conv2d_fwd_kernel<T, 1, true>), (conv2d_fwd_kernel<T, 2, true>));
+    else FOD_NT_LAUNCH((conv2d_fwd_kernel<T, 1, false>), (conv2d_fwd_kernel<T, 2, false>));
+  } else if constexpr (MODE == MODE_DGRAD) {
+    if (utap) FOD_NT_LAUNCH((conv2d_dgrad_kernel<T, 1, true>), (conv2d_dgrad_kernel<T, 2, true>));
+    else FOD_NT_LAUNCH((conv2d_dgrad_kernel<T, 1, false>), (conv2d_dgrad_kernel<T, 2, false>));
   } else {
-    q.gx = ceil_div(p.N, 128);
-    const dim3 grid(q.gx * ((q.gy + 7) / 8 * 8));
-    const size_t lds = 2 * (BM + 128) * ROW_BYTES;
-    if (utap) hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 2, MODE != MODE_DENSE>), grid, block, lds, stream, q);
-    else hipLaunchKernelGGL((gemm_nt_kernel<T, MODE, 2, false>), grid, block, lds, stream, q);
+    if (utap) FOD_NT_LAUNCH((conv2d_dgrad_s2_kernel<T, 1, true>), (conv2d_dgrad_s2_kernel<T, 2, true>));
+    else FOD_NT_LAUNCH((conv2d_dgrad_s2_kernel<T, 1, false>), (conv2d_dgrad_s2_kernel<T, 2, false>));
   }
+#undef FOD_NT_LAUNCH
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }

@@ -77,7 +77,7 @@ FOD_DEVINL void tn_frag(Frag<float>& f, const unsigned char* tile, int ks, int c
 
 // RING = depth of the register staging ring: RING-1 steps of global loads are in flight while one is computed.
 template <typename T, int MODE, int RING>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
+FOD_DEVINL void gemm_tn_body(const TnParams& p) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int PITCH = TnCfg<T>::PITCH;
   constexpr int CHR = 128 / VEC;          // 16-byte chunks per tile row
@@ -378,6 +378,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
   FOD_STAMP(5);
 }
 
+// One named kernel per C-ABI entry point (rocprofv3 summaries then read like include/fod.h).
+// RING = 3: deeper rings (4, 6) measured within 1 % on every shape of the workload and cost an occupancy step.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
+  gemm_tn_body<T, MODE_DENSE, 3>(p);
+}
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const TnParams p) {
+  gemm_tn_body<T, MODE_CONV, 3>(p);
+}
+
 template <typename T>
 __global__ void colsum_kernel(const T* __restrict__ G, long ldg, int M, int N, int rows_per_block,
                               int group_rows, float* __restrict__ out) {
@@ -586,11 +597,13 @@ int launch_tn(int dtype, TnParams& p, hipStream_t stream) {
   p.nsplit = ceil_div(p.M, p.m_per_split);
   p.xcd_order = (env_xcd && atoi(env_xcd) > 0 && p.nsplit >= 8) ? 1 : 0;
   const dim3 grid = p.xcd_order ? dim3(ti * tj * ((p.nsplit + 7) / 8 * 8)) : dim3(tj, ti, p.nsplit);
-  // RING = 3: deeper rings (4, 6) measured within 1 % on every shape of the workload and cost an occupancy step
-  if (dtype == FOD_BF16)
-    hipLaunchKernelGGL((gemm_tn_kernel<__bf16, MODE, 3>), grid, dim3(256), 0, stream, p);
-  else if (dtype == FOD_F32)
-    hipLaunchKernelGGL((gemm_tn_kernel<float, MODE, 3>), grid, dim3(256), 0, stream, p);
+  if (dtype == FOD_BF16) {
+    if (MODE == MODE_DENSE) hipLaunchKernelGGL((gemm_tn_kernel<__bf16>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv2d_wgrad_kernel<__bf16>), grid, dim3(256), 0, stream, p);
+  } else if (dtype == FOD_F32) {
+    if (MODE == MODE_DENSE) hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((conv2d_wgrad_kernel<float>), grid, dim3(256), 0, stream, p);
+  }
   else {
     fod_set_error("gemm_tn: bad dtype %d", dtype);
     return FOD_ERR_ARG;
