@@ -48,6 +48,10 @@ struct NtParams {
   int vec_epi;   // host-checked: N, ldc, ldr, ldmask multiples of 4 and 16-byte aligned bases
   unsigned a_bytes, b_bytes;   // extents of A and B for the buffer descriptors (< 4 GiB, host-checked)
   int gx, gy;                  // tile grid (n-tiles, m-tiles); launched as a 1-D grid of gx * roundup(gy, 8)
+  // grouped form (short-launch kernel only): A's k range and C's columns are cut into segments that live
+  // a_seg_stride / c_seg_stride elements apart -- P same-shaped tensors side by side without a concatenation
+  int a_seg_len, c_seg_cols;   // elements per segment; 0 = not segmented
+  long a_seg_stride, c_seg_stride;
   // MODE_DGRAD_S2: class geometry.  m indexes (img, hi', wi') of the class grid Hd x Wd; hi = 2*hi' + par_h
   int par_h, par_w, out_H, out_W;   // parity of the class, full input dims (rows of C / residual / mask)
   int r_first, s_first, n_s;        // first valid tap per axis, taps per row of the compact list
@@ -531,6 +535,12 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const NtParams p) {
   struct Unit {
     Frag<T> a[2][2], b[2][2];   // [k-step][32-row fragment]
   };
+  // segmented A: units are requested in increasing order, so the segment walk is two scalar adds per unit
+  const int seg_len = p.a_seg_len > 0 ? p.a_seg_len : 0x7fffffff;
+  const int seg0 = (ub * 32) / seg_len;
+  int seg_k = ub * 32 - seg0 * seg_len;                                   // k offset inside the segment
+  unsigned seg_extra = (unsigned)((long)seg0 * (p.a_seg_stride - seg_len) * 2);   // bytes added to k * 2
+  const unsigned seg_jump = (unsigned)((p.a_seg_stride - seg_len) * 2);
   auto load_unit = [&](int u, Unit& f) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -538,9 +548,14 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const NtParams p) {
       const bool kin = u < ue && k < p.K;        // K % 8 == 0: a 16-byte chunk is all in or all out
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        f.a[ks][i] = bload(rsA, (kin && a_off[i] != OOB) ? a_off[i] + k * 2 : OOB);
+        f.a[ks][i] = bload(rsA, (kin && a_off[i] != OOB) ? a_off[i] + k * 2 + seg_extra : OOB);
         f.b[ks][i] = bload(rsB, (kin && b_off[i] != OOB) ? b_off[i] + k * 2 : OOB);
       }
+    }
+    seg_k += 32;
+    if (seg_k >= seg_len) {
+      seg_k = 0;
+      seg_extra += seg_jump;
     }
   };
   f32x16 acc[2][2];
@@ -580,6 +595,13 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const NtParams p) {
   __syncthreads();
   FOD_STAMP(3);
   const bool has_scale = p.scale != nullptr, has_mask = p.mask != nullptr;
+  long c_base = 0;             // segmented C: this block's columns lie in one segment (c_seg_cols % 64 == 0)
+  int n_c = n;
+  if (p.c_seg_cols > 0) {
+    const int cseg = n0 / p.c_seg_cols;
+    c_base = (long)cseg * p.c_seg_stride;
+    n_c = n - cseg * p.c_seg_cols;
+  }
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
     const int row = rq + 16 * ps;
@@ -601,9 +623,9 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const NtParams p) {
     }
     if (m < p.M && n_ok) {
       if (p.c_is_f32) {
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = v;
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + c_base + (long)m * p.ldc + n_c) = v;
       } else {
-        *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(p.C) + (long)m * p.ldc + n) =
+        *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(p.C) + c_base + (long)m * p.ldc + n_c) =
             bf16x4_t{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
       }
     }
@@ -719,6 +741,45 @@ extern "C" int fod_gemm_nt(int dtype, const void* A, long lda, int a_row_mod, co
     return FOD_OK;
   }
   return dispatch_nt<MODE_DENSE>(dtype, p, stream);
+}
+
+extern "C" int fod_gemm_nt_grouped(int dtype, const void* A, long lda, int a_seg_len, long a_seg_stride,
+                                   const void* B, long ldb, void* C, long ldc, int c_seg_cols, long c_seg_stride,
+                                   int M, int N, int K, const fod_epilogue* epi, hipStream_t stream) {
+  FOD_REQUIRE(dtype == FOD_BF16, "gemm_nt_grouped: bf16 only (dtype %d)", dtype);
+  FOD_REQUIRE(A && B && C, "gemm_nt_grouped: null operand");
+  FOD_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt_grouped: empty problem %d %d %d", M, N, K);
+  FOD_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "gemm_nt_grouped: K=%d lda=%ld ldb=%ld must be multiples of 8",
+              K, lda, ldb);
+  FOD_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm_nt_grouped: operands must be 16-byte aligned");
+  FOD_REQUIRE(a_seg_len >= 0 && c_seg_cols >= 0, "gemm_nt_grouped: negative segment size");
+  FOD_REQUIRE(a_seg_len == 0 || (a_seg_len % 32 == 0 && K % a_seg_len == 0 && a_seg_stride % 8 == 0),
+              "gemm_nt_grouped: A segments of %d (stride %ld) must be multiples of 32 dividing K=%d", a_seg_len,
+              a_seg_stride, K);
+  FOD_REQUIRE(c_seg_cols == 0 || (c_seg_cols % 64 == 0 && c_seg_stride % 4 == 0),
+              "gemm_nt_grouped: C segments of %d columns (stride %ld) must be multiples of 64 / 4", c_seg_cols,
+              c_seg_stride);
+  NtParams p{};
+  p.A = A; p.B = B; p.C = C;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K;
+  p.a_seg_len = a_seg_len; p.a_seg_stride = a_seg_stride;
+  p.c_seg_cols = c_seg_cols; p.c_seg_stride = c_seg_stride;
+  fill_epilogue(p, epi);
+  decide_vec_epilogue(p);
+  FOD_REQUIRE(p.vec_epi, "gemm_nt_grouped: N, ldc and the epilogue operands must be 4-element / 16-byte aligned");
+  FOD_REQUIRE(!p.res || ((long)(p.res_row_mod > 0 ? p.res_row_mod : M) * p.ldr + N) * 2 < 0x7FFFFFF0L,
+              "gemm_nt_grouped: residual larger than 2 GiB");
+  FOD_REQUIRE(!p.mask || ((long)M * p.ldmask + N) * 2 < 0x7FFFFFF0L, "gemm_nt_grouped: mask larger than 2 GiB");
+  const long nseg = a_seg_len > 0 ? K / a_seg_len : 1;
+  const long seg_k = a_seg_len > 0 ? a_seg_len : K;
+  const long ab = ((nseg - 1) * a_seg_stride + (long)(M - 1) * lda + seg_k) * 2, bb = ((long)(N - 1) * ldb + K) * 2;
+  FOD_REQUIRE(ab < 0xFFFFFFF0L - 16 && bb < 0xFFFFFFF0L - 16, "gemm_nt_grouped: operand larger than 4 GiB");
+  p.a_bytes = (unsigned)ab;
+  p.b_bytes = (unsigned)bb;
+  hipLaunchKernelGGL(gemm_nt_small_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, stream, p);
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
 }
 
 static int conv_common(int dtype, bool dgrad, const void* src, const void* w, void* dst,

@@ -35,6 +35,8 @@ struct TnParams {
   int m_per_split;
   int tj, ti, nsplit, xcd_order;   // tile grid, number of M-splits, 1 = XCD-grouped 1-D launch
   unsigned g_bytes, x_bytes;       // operand extents for the buffer descriptors (< 4 GiB, host-checked)
+  int g_seg_cols;                  // short-reduction kernel: G's columns in segments g_seg_stride elements apart
+  long g_seg_stride;               //   (P same-shaped gradient tensors side by side); 0 = plain [M, N1]
   int Hs, Ws, Cs, Hd, Wd, kh, kw, stride, pad;
 };
 
@@ -446,6 +448,11 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const TnParams p) {
   const int cc = tid & 7, r0 = tid >> 3;     // 16-byte chunk column / first row (then +32 ...) of the staging pass
   const int gi = i0 + cc * 8, xj = j0 + cc * 8;
   const bool g_ok = gi < p.N1, x_ok = xj < p.K2;
+  long g_col = gi;                 // element offset of column gi inside a row of G (segmented: the tile's 64 columns
+  if (p.g_seg_cols > 0) {          // lie in one segment, g_seg_cols % 64 == 0)
+    const int seg = i0 / p.g_seg_cols;
+    g_col = (long)seg * p.g_seg_stride + (gi - seg * p.g_seg_cols);
+  }
   const bool do_colsum = p.colsum != nullptr && blockIdx.x == 0;
   float csum[8];
 #pragma unroll
@@ -465,7 +472,7 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const TnParams p) {
       const int m = mb + r0 + 32 * i;
       const bool in = m < p.M;
       const auto a = __builtin_amdgcn_raw_buffer_load_b128(
-          rsG, (in && g_ok) ? (int)(unsigned)(((long)m * p.ldg + gi) * 2) : (int)OOB, 0, 0);
+          rsG, (in && g_ok) ? (int)(unsigned)(((long)m * p.ldg + g_col) * 2) : (int)OOB, 0, 0);
       const auto b = __builtin_amdgcn_raw_buffer_load_b128(
           rsX, (in && x_ok) ? (int)(unsigned)(((long)m * p.ldx + xj) * 2) : (int)OOB, 0, 0);
       __builtin_memcpy(&vg[i], &a, 16);
@@ -619,6 +626,37 @@ int launch_tn(int dtype, TnParams& p, hipStream_t stream) {
 }
 
 }  // namespace
+
+extern "C" int fod_gemm_tn_grouped(int dtype, const void* G, long ldg, int g_seg_cols, long g_seg_stride,
+                                   const void* X, long ldx, float* dW, long ldw, int M, int N1, int K2,
+                                   float* colsum, int accumulate, hipStream_t stream) {
+  FOD_REQUIRE(dtype == FOD_BF16, "gemm_tn_grouped: bf16 only (dtype %d)", dtype);
+  FOD_REQUIRE(G && X && dW, "gemm_tn_grouped: null operand");
+  FOD_REQUIRE(M > 0 && N1 > 0 && K2 > 0, "gemm_tn_grouped: empty problem");
+  FOD_REQUIRE(N1 % 8 == 0 && K2 % 8 == 0 && ldg % 8 == 0 && ldx % 8 == 0,
+              "gemm_tn_grouped: N1=%d K2=%d ldg=%ld ldx=%ld must be multiples of 8", N1, K2, ldg, ldx);
+  FOD_REQUIRE(((uintptr_t)G % 16) == 0 && ((uintptr_t)X % 16) == 0 && ((uintptr_t)dW % 16) == 0 && ldw % 4 == 0,
+              "gemm_tn_grouped: operands must be 16-byte aligned");
+  FOD_REQUIRE(g_seg_cols == 0 || (g_seg_cols % 64 == 0 && g_seg_stride % 8 == 0),
+              "gemm_tn_grouped: G segments of %d columns (stride %ld) must be multiples of 64 / 8", g_seg_cols, g_seg_stride);
+  TnParams p{};
+  p.G = G; p.X = X; p.dW = dW;
+  p.ldg = ldg; p.ldx = ldx; p.ldw = ldw;
+  p.M = M; p.N1 = N1; p.K2 = K2;
+  p.colsum = colsum;
+  p.accumulate = accumulate;
+  p.g_seg_cols = g_seg_cols; p.g_seg_stride = g_seg_stride;
+  const long nseg = g_seg_cols > 0 ? ceil_div(N1, g_seg_cols) : 1;
+  const long seg_c = g_seg_cols > 0 ? g_seg_cols : N1;
+  const long gb = ((nseg - 1) * g_seg_stride + (long)(M - 1) * ldg + seg_c) * 2, xb = ((long)(M - 1) * ldx + K2) * 2;
+  FOD_REQUIRE(gb < 0xFFFFFFF0L - 16 && xb < 0xFFFFFFF0L - 16, "gemm_tn_grouped: operand larger than 4 GiB");
+  FOD_REQUIRE(((long)N1 * ldw + K2) * 4 < 0x7FFFFFF0L, "gemm_tn_grouped: output larger than 2 GiB");
+  p.g_bytes = (unsigned)gb;
+  p.x_bytes = (unsigned)xb;
+  hipLaunchKernelGGL(gemm_tn_small_kernel, dim3(ceil_div(K2, 64), ceil_div(N1, 64)), dim3(256), 0, stream, p);
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
+}
 
 extern "C" int fod_gemm_tn_acc(int dtype, const void* G, long ldg, const void* X, long ldx, float* dW,
                                long ldw, int M, int N1, int K2, const float* row_scale, float* colsum,

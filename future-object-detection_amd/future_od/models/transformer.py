@@ -78,11 +78,14 @@ class SlotToSlotAttention(Attention):
         self.fun = OutProj(D)
         self.Nhead, self.D = Nhead, D
 
-    def forward(self, x, qpos):
+    def forward(self, x, qpos, pos_proj=None):
+        """`pos_proj` = (query_pos(qpos), key_pos(qpos)) when the decoder has projected the (layer-independent)
+        query positions for all layers at once."""
         M = qpos.shape[0]
-        q = Fn.add(_lin(x, self.query_content), _lin(qpos, self.query_pos), b_row_mod=M)
-        k = Fn.add(_lin(x, self.key_content), _lin(qpos, self.key_pos), b_row_mod=M)
-        v = _lin(x, self.value)
+        qp, kp = pos_proj if pos_proj is not None else (_lin(qpos, self.query_pos), _lin(qpos, self.key_pos))
+        qc, kc, v = Fn.group_linear(x, [self.query_content, self.key_content, self.value])
+        q = Fn.add(qc, qp, b_row_mod=M)
+        k = Fn.add(kc, kp, b_row_mod=M)
         a = Fn.attention(q, k, v, 1.0 / math.sqrt(self.D // self.Nhead))
         return _lin(a, self.fun.out_proj)
 
@@ -134,14 +137,16 @@ class SlotToImageAttention(Attention):
         self.D, self.Nhead = D, Nhead
         self.store_attention = False
 
-    def forward(self, x, qpos, query_sine, side, layer, image, is_first):
+    def forward(self, x, qpos, query_sine, side, layer, image, is_first, qs=None, qpos_proj=None):
         """`side` (functional.MemorySide) holds this image's value / key_content projections for ALL layers
-        and the projected positional table; this call uses the (layer, image) slots."""
+        and the projected positional table; this call uses the (layer, image) slots.  `qs` = query_sine(query_sine)
+        and `qpos_proj` = query_pos(qpos) when the caller has projected them for all images at once."""
         B, M, D = x.shape
         qc = _lin(x, self.query_content)
         if is_first:
-            qc = Fn.add(qc, _lin(qpos, self.query_pos), b_row_mod=M)
-        qs = _lin(query_sine, self.query_sine)
+            qc = Fn.add(qc, qpos_proj if qpos_proj is not None else _lin(qpos, self.query_pos), b_row_mod=M)
+        if qs is None:
+            qs = _lin(query_sine, self.query_sine)
         if qs.dim() == 2:
             qs = Fn.expand_rows(qs, B).view(B, M, D)
         if is_first:
@@ -187,11 +192,15 @@ class TransformerDecoderLayer(nn.Module):
         self.norm_out = nn.LayerNorm(D)
         self.Nhead, self.D = Nhead, D
 
-    def forward(self, x, qpos, query_sine, side, layer, is_first=False):
-        o = self.self_attend(x, qpos)
+    def forward(self, x, qpos, query_sine, side, layer, is_first=False, pos_proj=None):
+        """`pos_proj` (from TransformerDecoder): {"sa": (query_pos(qpos), key_pos(qpos)), "ca": [query_pos_i(qpos)]}."""
+        o = self.self_attend(x, qpos, pos_proj["sa"] if pos_proj else None)
         x = Fn.layer_norm(x, self.norm_sa.weight, self.norm_sa.bias, residual=o)
+        # the sine embedding is the same for every image of the layer: all their query_sine projections at once
+        qs_all = Fn.group_linear(query_sine, [self.image_attend[i].query_sine for i in range(side.K)])
         for i in range(side.K):
-            o = self.image_attend[i](x, qpos, query_sine, side, layer, i, is_first)
+            o = self.image_attend[i](x, qpos, query_sine, side, layer, i, is_first, qs=qs_all[i],
+                                     qpos_proj=pos_proj["ca"][i] if (pos_proj and is_first) else None)
             x = Fn.layer_norm(x, self.norm_ia[i].weight, self.norm_ia[i].bias, residual=o)
         h = _lin(x, self.feedforward[0], relu=True)
         return Fn.layer_norm(x, self.norm_out.weight, self.norm_out.bias, residual=_lin(h, self.feedforward[3]))
@@ -226,14 +235,22 @@ class TransformerDecoder(nn.Module):
                for j in range(K)]
         ks_all = Fn.wide_linear(mem_poss[0], [layer.image_attend[j].key_pos for layer in self.layers for j in range(K)])
         side = Fn.MemorySide(big, ks_all, len(self.layers), K, D)
+        # query side: every projection of the learned query positions (2 per layer for the self-attention, one
+        # per image for the first layer's cross-attention) in one grouped launch
+        pos_lin = [m for layer in self.layers for m in (layer.self_attend.query_pos, layer.self_attend.key_pos)]
+        if first_layer_special:
+            pos_lin += [self.layers[0].image_attend[j].query_pos for j in range(K)]
+        pos_all = Fn.group_linear(qpos, pos_lin)
         inter = []
         for lid, layer in enumerate(self.layers):
             special = lid == 0 and first_layer_special
+            pos_proj = {"sa": (pos_all[2 * lid], pos_all[2 * lid + 1]),
+                        "ca": pos_all[2 * len(self.layers):] if special else None}
             if special:
                 q_sine = sine0
             else:
                 q_sine = Fn.mul(self.query_scale(x).view(B * M, D), sine0, b_row_mod=M).view(B, M, D)
-            x = layer(x, qpos, q_sine, side, lid, is_first=special)
+            x = layer(x, qpos, q_sine, side, lid, is_first=special, pos_proj=pos_proj)
             if self.return_intermediate:
                 inter.append(Fn.layer_norm(x, self.norm.weight, self.norm.bias))
         if not self.return_intermediate:

@@ -323,7 +323,13 @@ class AttentionFn(Function):
     @staticmethod
     def backward(ctx, do):
         q1, k1, v, q2, k2, o, lse2 = ctx.saved_tensors
-        dq1, dk1, dq2, dk2, dv = ops.attn_bwd(q1, k1, v, o, do.contiguous(), lse2, ctx.scale, q2, k2)
+        slots = {}
+        if q1.shape == k1.shape == v.shape and k1.is_contiguous() and v.is_contiguous():
+            # self-attention: dq | dk | dv as consecutive blocks of one buffer, the layout a GroupLinearFn that
+            # produced q, k, v takes as it is (no gather copies)
+            buf = torch.empty((3,) + tuple(q1.shape), dtype=q1.dtype, device=q1.device)
+            slots = dict(dq1_out=buf[0], dk1_out=buf[1], dv_out=buf[2])
+        dq1, dk1, dq2, dk2, dv = ops.attn_bwd(q1, k1, v, o, do.contiguous(), lse2, ctx.scale, q2, k2, **slots)
         return dq1, dk1, dv, dq2, dk2, None
 
 
@@ -484,6 +490,72 @@ class WideLinearFn(Function):
         return (dx, None) + tuple(gw) + tuple(gb)
 
 
+class GroupLinearFn(Function):
+    """P same-shaped Linear layers applied to ONE input, returned as P separate contiguous tensors (blocks of one
+    [P, rows, D] buffer): one launch forward, one for the input gradient (the P output gradients are the k-segments
+    of its A operand), one for all weight / bias gradients.  The decoder's query side is made of these: the
+    self-attention's query_content / key_content / value, the per-image query_sine projections of a layer, and
+    the per-layer projections of the learned query positions (reference transformer.py:66-70,139-141)."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        P = len(params) // 2
+        weights, biases = params[:P], params[P:]
+        wcat, bcat, _ = CAT.get(weights, biases, x.dtype)
+        D = weights[0].shape[0]
+        y = ops.group_linear_fwd(x.view(-1, x.shape[-1]), wcat, bcat, P)
+        ctx.save_for_backward(x)
+        ctx.params = params
+        return tuple(y[p].view(*x.shape[:-1], D) for p in range(P))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        (x,) = ctx.saved_tensors
+        P = len(ctx.params) // 2
+        weights, biases = ctx.params[:P], ctx.params[P:]
+        D, K = weights[0].shape
+        _, _, wcat_t = CAT.get(weights, biases, x.dtype)
+        rows = x.numel() // K
+        g = _as_segments(gs, rows, D)
+        if g is None:                                # gather the P gradients into the segment layout
+            g = torch.empty((P, rows, D), dtype=x.dtype, device=x.device)
+            for p_, gp in enumerate(gs):
+                if gp is None:
+                    g[p_].zero_()
+                else:
+                    g[p_].copy_(gp.reshape(rows, D))
+        dx = ops.group_linear_dgrad(g, wcat_t, P).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = zeros_f32((P * D, K), x.device)
+        db = zeros_f32((P * D,), x.device)
+        ops.group_linear_wgrad(g, x.view(rows, K), dw, db, zeroed=True)
+        return (dx,) + tuple(dw[i * D:(i + 1) * D] for i in range(P)) + tuple(db[i * D:(i + 1) * D] for i in range(P))
+
+
+def _as_segments(gs, rows, D):
+    """The tensors of `gs` as one [P, rows, D] tensor if they already are consecutive contiguous blocks of one
+    allocation (producers that know about the grouping write their gradients that way), else None."""
+    g0 = gs[0]
+    if g0 is None or not g0.is_contiguous() or g0.numel() != rows * D:
+        return None
+    st, step = g0.untyped_storage(), rows * D
+    for p_, gp in enumerate(gs):
+        if (gp is None or gp.dtype != g0.dtype or not gp.is_contiguous() or gp.numel() != step
+                or gp.untyped_storage().data_ptr() != st.data_ptr()
+                or gp.storage_offset() != g0.storage_offset() + p_ * step):
+            return None
+    return torch.as_strided(g0, (len(gs), rows, D), (step, D, 1))
+
+
+def group_linear(x, linears):
+    """[m(x) for m in linears] for nn.Linear-like holders of equal shape; grouped launches in bf16, plain
+    per-layer launches otherwise (fp32 parity mode, odd widths)."""
+    D, K = linears[0].weight.shape
+    same = all(tuple(m.weight.shape) == (D, K) and m.bias is not None for m in linears)
+    if x.dtype != torch.bfloat16 or not same or D % 64 or K % 32 or len(linears) < 2:
+        return [linear(x, m.weight, m.bias) for m in linears]
+    return list(GroupLinearFn.apply(x.contiguous(), *[m.weight for m in linears], *[m.bias for m in linears]))
+
+
 def _sum_leading(t, n):
     """[n, ...] -> [...] : sum over the (tiny) leading dim."""
     acc = t[0]
@@ -507,6 +579,7 @@ class MemorySide:
         self.L, self.K, self.D = n_layers, n_images, D
         self.dbig = [None] * n_images
         self.dks = None
+        self.dq2 = {}
 
     def slots(self, layer, image):
         D = self.D
@@ -547,8 +620,12 @@ class HoistedCrossAttnFn(Function):
         dkc = db[..., (2 * layer + 1) * D:(2 * layer + 2) * D]
         qi = layer * side.K + image
         dks = side.dks[..., qi * D:(qi + 1) * D]
+        # dq2 of the K images of a layer as consecutive blocks (their query_sine projections are one GroupLinearFn)
+        key = (layer, tuple(q2.shape))
+        if key not in side.dq2:
+            side.dq2[key] = torch.empty((side.K,) + tuple(q2.shape), dtype=q2.dtype, device=q2.device)
         dq1, _, dq2, _, _ = ops.attn_bwd(q1, kc, v, o, do.contiguous(), lse2, ctx.scale, q2, ks,
-                                         dk1_out=dkc, dv_out=dv, dk2_out=dks)
+                                         dk1_out=dkc, dv_out=dv, dk2_out=dks, dq2_out=side.dq2[key][image])
         g_big = side.dbig[image] if layer == 0 else None
         # ks_all is shared by the batch: its gradient is the sum of the per-batch slots
         g_ks = _sum_leading(side.dks, side.dks.shape[0]) if (layer == 0 and image == 0) else None

@@ -48,6 +48,8 @@ _EP, _CG, _AS = C.POINTER(Epilogue), C.POINTER(ConvGeom), C.POINTER(AttnShape)
 SIGNATURES = {
     "fod_gemm_nt": [_i, _p, _l, _i, _p, _l, _p, _l, _i, _i, _i, _EP, _p],
     "fod_gemm_tn_acc": [_i, _p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p],
+    "fod_gemm_nt_grouped": [_i, _p, _l, _i, _l, _p, _l, _p, _l, _i, _l, _i, _i, _i, _EP, _p],
+    "fod_gemm_tn_grouped": [_i, _p, _l, _i, _l, _p, _l, _p, _l, _i, _i, _i, _p, _i, _p],
     "fod_colsum_acc": [_i, _p, _l, _i, _i, _i, _p, _p],
     "fod_conv2d_fwd": [_i, _p, _p, _p, _CG, _EP, _p],
     "fod_conv2d_dgrad": [_i, _p, _p, _p, _CG, _EP, _p],

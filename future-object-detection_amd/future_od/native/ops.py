@@ -109,6 +109,49 @@ def gemm_tn_acc(g, x, dw, row_scale=None, colsum=None, zeroed=False):
     return dw
 
 
+def group_linear_fwd(x, wcat, bcat, P, relu=False):
+    """P Linear layers sharing the input x [rows, K]: wcat [P*D, K], bcat f32 [P*D] -> y [P, rows, D] (each
+    [rows, D] block contiguous) in one launch."""
+    _chk(x, "x", torch.bfloat16); _chk(wcat, "wcat", torch.bfloat16)
+    K = x.shape[-1]
+    rows = x.numel() // K
+    N = wcat.shape[0]
+    D = N // P
+    assert wcat.shape[1] == K and N == P * D and D % 64 == 0, (x.shape, wcat.shape, P)
+    if bcat is not None:
+        _chk(bcat, "bcat", torch.float32); assert bcat.numel() == N
+    y = torch.empty((P, rows, D), dtype=x.dtype, device=x.device)
+    call("fod_gemm_nt_grouped", dt(x), ptr(x), K, 0, 0, ptr(wcat), K, ptr(y), D, D, rows * D, rows, N, K,
+         _epi(None, bcat, None, N, 0, None, N, relu, False), stream(), work=2.0 * rows * N * K,
+         tag="fod_gemm_nt")
+    return y
+
+
+def group_linear_dgrad(g, wcat_t, P):
+    """g [P, rows, D] (output gradients of the P layers), wcat_t [K, P*D] -> dx [rows, K] = sum_p g_p W_p."""
+    _chk(g, "g", torch.bfloat16); _chk(wcat_t, "wcat_t", torch.bfloat16)
+    _, rows, D = g.shape
+    K = wcat_t.shape[0]
+    assert g.shape[0] == P and wcat_t.shape[1] == P * D and D % 32 == 0
+    dx = torch.empty((rows, K), dtype=g.dtype, device=g.device)
+    call("fod_gemm_nt_grouped", dt(g), ptr(g), D, D, rows * D, ptr(wcat_t), P * D, ptr(dx), K, 0, 0, rows, K, P * D,
+         None, stream(), work=2.0 * rows * K * P * D, tag="fod_gemm_nt")
+    return dx
+
+
+def group_linear_wgrad(g, x, dw, db, zeroed=False):
+    """g [P, rows, D], x [rows, K] -> dw f32 [P*D, K] (+)= g_p^T x per block, db f32 [P*D] (+)= column sums."""
+    _chk(g, "g", torch.bfloat16); _chk(x, "x", torch.bfloat16); _chk(dw, "dw", torch.float32)
+    P, rows, D = g.shape
+    K = x.shape[-1]
+    assert x.numel() // K == rows and dw.numel() == P * D * K and D % 64 == 0
+    if db is not None:
+        _chk(db, "db", torch.float32); assert db.numel() == P * D
+    call("fod_gemm_tn_grouped", dt(g), ptr(g), D, D, rows * D, ptr(x), K, ptr(dw), K, rows, P * D, K, ptr(db),
+         0 if zeroed else 1, stream(), work=2.0 * rows * P * D * K, tag="fod_gemm_tn_acc")
+    return dw
+
+
 def colsum_acc(g, out, group_rows=0):
     _chk(g, "g"); _chk(out, "out", torch.float32)
     N = g.shape[-1]
@@ -277,13 +320,14 @@ def attn_fwd(q1, k1, v, scale, q2=None, k2=None):
     return o, lse2
 
 
-def attn_bwd(q1, k1, v, o, dout, lse2, scale, q2=None, k2=None, dk1_out=None, dv_out=None, dk2_out=None):
+def attn_bwd(q1, k1, v, o, dout, lse2, scale, q2=None, k2=None, dk1_out=None, dv_out=None, dk2_out=None,
+             dq1_out=None, dq2_out=None):
     """Gradients (dq1, dk1, dq2, dk2, dv).  dk1_out / dv_out / dk2_out: optional destinations (e.g. slots of a
     larger gradient buffer); dk1_out / dv_out must have k1's / v's strides, dk2_out is always per batch element."""
     _chk(lse2, "lse2", torch.float32)
     _chk(o, "o", q1.dtype); _chk(dout, "dout", q1.dtype)
     assert dout.shape == q1.shape
-    dq1 = torch.empty(q1.shape, dtype=q1.dtype, device=q1.device)
+    dq1 = dq1_out if dq1_out is not None else torch.empty(q1.shape, dtype=q1.dtype, device=q1.device)
     _same_bt(dq1, q1, "q1 (must be contiguous)")
     dk1 = dk1_out if dk1_out is not None else torch.empty_strided(k1.shape, k1.stride(), dtype=k1.dtype, device=k1.device)
     dv = dv_out if dv_out is not None else torch.empty_strided(v.shape, v.stride(), dtype=v.dtype, device=v.device)
@@ -291,7 +335,8 @@ def attn_bwd(q1, k1, v, o, dout, lse2, scale, q2=None, k2=None, dk1_out=None, dv
     dq2 = dk2 = None
     if q2 is not None:
         _same_bt(q1, q2, "q2")
-        dq2 = torch.empty_like(dq1)
+        dq2 = dq2_out if dq2_out is not None else torch.empty_like(dq1)
+        _same_bt(dq2, q1, "dq2")
         B, S, E = k1.shape
         dk2 = dk2_out if dk2_out is not None else torch.empty((B, S, E), dtype=k1.dtype, device=k1.device)
     shp, H = _attn_shape(q1, k1, v, o, scale, k2, dk2)

@@ -71,6 +71,22 @@ int fod_gemm_tn_acc(int dtype, const void* G, long ldg, const void* X, long ldx,
                     int M, int N1, int K2, const float* row_scale, float* colsum, int accumulate,
                     fod_stream_t stream);
 
+/* Grouped forms for P same-shaped Linear layers that share their input (the decoder's query-side projections:
+ * query_content / key_content / value of future_od/models/transformer.py:66-70, the per-image query_sine
+ * projections :139-141, the per-layer query_pos / key_pos projections :67,69).  The P tensors stay separate,
+ * contiguous [M, D] blocks `seg_stride` elements apart -- no concatenation or slicing kernels:
+ *   fod_gemm_nt_grouped : C's columns [p*c_seg_cols, (p+1)*c_seg_cols) go to block p (forward: B = the P weights
+ *                         stacked [P*D, K]); A's k range [p*a_seg_len, ...) comes from block p (input gradient:
+ *                         A = the P output gradients, B = stacked weights transposed [K, P*D]).
+ *   fod_gemm_tn_grouped : G's columns come from P blocks (weight / bias gradients of all P layers in one pass).
+ * A segment size of 0 means "not segmented".  bf16 only; always the short-launch kernels (64 x 64 tiles). */
+int fod_gemm_nt_grouped(int dtype, const void* A, long lda, int a_seg_len, long a_seg_stride, const void* B,
+                        long ldb, void* C, long ldc, int c_seg_cols, long c_seg_stride, int M, int N, int K,
+                        const fod_epilogue* epi, fod_stream_t stream);
+int fod_gemm_tn_grouped(int dtype, const void* G, long ldg, int g_seg_cols, long g_seg_stride, const void* X,
+                        long ldx, float* dW, long ldw, int M, int N1, int K2, float* colsum, int accumulate,
+                        fod_stream_t stream);
+
 /* out[g, n] += sum over rows m of group g of G[m, n];  group g = m / group_rows (group_rows <= 0:
  * one group).  Bias gradients and sums over a broadcast dimension. */
 int fod_colsum_acc(int dtype, const void* G, long ldg, int M, int N, int group_rows, float* out,

@@ -141,3 +141,34 @@ def test_post_proc_and_od_map(golden):
     close(s, torch.cat([sr, sr.max(3, keepdim=True)[0]], 3), atol=1e-6)
     bb = boxes * torch.tensor([800.0, 448.0, 800.0, 448.0])
     close(bp, torch.cat([bb[..., :2] - 0.5 * bb[..., 2:], bb[..., :2] + 0.5 * bb[..., 2:]], -1), atol=1e-4)
+
+
+def test_group_linear_function_matches_separate_linears():
+    """GroupLinearFn (one launch for P Linear layers of one input, bf16) against P LinearFn calls: same outputs
+    and gradients up to bf16 rounding of the differently ordered sums; unused outputs get zero gradient."""
+    import torch.nn as nn
+    from future_od.native import functional as Fn
+    torch.manual_seed(0)
+    P, D, K, rows = 4, 256, 256, 200
+    lins = [nn.Linear(K, D).to("cuda:0") for _ in range(P)]
+    x0 = torch.randn(2, rows // 2, K, device="cuda:0").to(torch.bfloat16)
+    outs = {}
+    for mode in ("group", "separate"):
+        for m in lins:
+            m.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        ys = Fn.group_linear(x, lins) if mode == "group" else [Fn.linear(x, m.weight, m.bias) for m in lins]
+        assert all(y.shape == (2, rows // 2, D) for y in ys)
+        loss = sum((i + 1.0) * (y.float() ** 2).mean() for i, y in enumerate(ys[:-1]))      # last output unused
+        loss.backward()
+        outs[mode] = ([y.detach().float() for y in ys], x.grad.float(),
+                      [m.weight.grad.clone() if m.weight.grad is not None else None for m in lins],
+                      [m.bias.grad.clone() if m.bias.grad is not None else None for m in lins])
+    a, b = outs["group"], outs["separate"]
+    for ya, yb in zip(a[0], b[0]):
+        assert torch.allclose(ya, yb, rtol=2e-2, atol=2e-2)
+    assert torch.allclose(a[1], b[1], rtol=3e-2, atol=1e-4)
+    for i in range(P - 1):
+        assert torch.allclose(a[2][i], b[2][i], rtol=3e-2, atol=1e-5), i
+        assert torch.allclose(a[3][i], b[3][i], rtol=3e-2, atol=1e-5), i
+    assert float(a[2][P - 1].abs().max()) == 0.0 and b[2][P - 1] is None

@@ -284,3 +284,26 @@ def test_gemm_nt_short_launch(mnk):
     check(out, ref, dtype, math.sqrt(K), f"nt short {mnk}")
     out = ops.gemm_nt(a.to(DEV), b.to(DEV), relu=True, out_f32=True)
     check(out, (a.float() @ b.float().t()).clamp(min=0), dtype, math.sqrt(K), f"nt short relu f32 {mnk}")
+
+
+@pytest.mark.parametrize("shape", [(256, 256, 256, 3), (128, 256, 256, 17), (300, 64, 96, 2), (256, 256, 256, 5)])
+def test_group_linear_kernels(shape):
+    """Grouped forms of the short-launch kernels: P Linear layers sharing one input, outputs / output gradients as
+    P separate contiguous blocks (segmented C columns, segmented A k-range, segmented G columns)."""
+    rows, D, K, P = shape
+    dtype = torch.bfloat16
+    x = rnd((rows, K), dtype, 11)
+    w = rnd((P * D, K), dtype, 12, 0.2)
+    b = torch.randn(P * D)
+    y = ops.group_linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), P)
+    ref = (x.float() @ w.float().t() + b).view(rows, P, D).permute(1, 0, 2)
+    check(y, ref, dtype, math.sqrt(K), f"group fwd {shape}")
+    g = rnd((P, rows, D), dtype, 13)
+    wt = w.t().contiguous()                                        # [K, P*D]
+    dx = ops.group_linear_dgrad(g.to(DEV), wt.to(DEV), P)
+    gcat = g.permute(1, 0, 2).reshape(rows, P * D).float()
+    check(dx, gcat @ w.float(), dtype, math.sqrt(P * D), f"group dgrad {shape}")
+    dw, db = torch.zeros(P * D, K, device=DEV), torch.zeros(P * D, device=DEV)
+    ops.group_linear_wgrad(g.to(DEV), x.to(DEV), dw, db, zeroed=True)
+    check(dw, gcat.t() @ x.float(), dtype, math.sqrt(rows), f"group wgrad {shape}")
+    check(db, gcat.sum(0), torch.float32, math.sqrt(rows), f"group bias grad {shape}")
