@@ -374,7 +374,12 @@ FOD_DEVINL void gemm_nt_body(const NtParams& p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           sC[(wm * 64 + i * 32 + acc_row(r, lane)) * BN + wn * (32 * NT) + j * 32 + fr] = acc[i][j][r];
+    FOD_STAMP(5);
     __syncthreads();
+    FOD_STAMP(6);
+    // (A branch-free form of the row loop below -- absent operands read through empty buffer descriptors, relu as
+    // a max against -inf, edge rows stored out of range -- was measured slower: the loop is VALU-bound, ~10
+    // instructions per output, and the uniform branches are what skips the unused ones.)
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + nc);
     if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + nc);
@@ -648,10 +653,14 @@ bool use_small_nt(int dtype, const NtParams& p) {
 
 template <typename T, int MODE>
 int launch_nt(const NtParams& p, hipStream_t stream) {
-  const bool narrow = p.N <= 64;
-  const dim3 block(256);
   NtParams q = p;
   q.gy = ceil_div(p.M, BM);
+  // 64-wide tiles also when 128-wide ones would leave CUs with a single block (or none): a block's prologue and
+  // epilogue (~4.5 us) then overlap nothing; two narrower blocks per CU overlap each other
+  static const char* env_narrow = getenv("FOD_NT_NARROW");
+  const int narrow_below = env_narrow ? atoi(env_narrow) : 320;
+  const bool narrow = p.N <= 64 || (long)q.gy * ceil_div(p.N, 128) < narrow_below;
+  const dim3 block(256);
   constexpr int BK = ROW_BYTES / (int)sizeof(T);
   const bool utap = MODE != MODE_DENSE && p.Cs % BK == 0;     // a k-tile never straddles two taps
   q.gx = ceil_div(p.N, narrow ? 64 : 128);

@@ -50,7 +50,7 @@ int main() {
       show(name, 6);
     }
 #else
-  const int shapes[][3] = {{256, 256, 64}, {256, 256, 256}, {256, 256, 2048}, {2900, 256, 256}};
+  const int shapes[][3] = {{256, 256, 64}, {256, 256, 256}, {256, 256, 2048}, {2900, 256, 256}, {14500, 256, 256}, {14500, 2048, 256}};
   fod_epilogue epi = {};
   epi.shift = bias;
   for (auto& s : shapes)
@@ -62,6 +62,12 @@ int main() {
       float ms; hipEventElapsedTime(&ms, e0, e1);
       snprintf(name, sizeof name, "nt M%d N%d K%d rc%d ev %.1fus", s[0], s[1], s[2], rc, ms * 1e3);
       show(name, 5);
+      {
+        long long h[32];
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(fod_stamps), sizeof(h));
+        if (s[0] > 3000) printf("      epilogue: s3->s5 (acc to LDS) %.2f us, s5->s6 (barrier) %.2f us, s6->s4 (rows out) %.2f us\n",
+                                (h[5] - h[3]) * 0.01, (h[6] - h[5]) * 0.01, (h[4] - h[6]) * 0.01);
+      }
     }
 #endif
   return 0;
