@@ -287,11 +287,8 @@ class EncoderAttention(nn.Module):
         """src [F,N,D]; pos table [N,D].  q = k = src + pos, v = src."""
         D = self.D
         N = pos.shape[0]
-        w, b = self.attn.in_proj_weight, self.attn.in_proj_bias
         xp = Fn.add(src, pos, b_row_mod=N)
-        q = Fn.linear(xp, w[:D], b[:D])
-        k = Fn.linear(xp, w[D:2 * D], b[D:2 * D])
-        v = Fn.linear(src, w[2 * D:], b[2 * D:])
+        q, k, v = Fn.in_proj(xp, src, self.attn.in_proj_weight, self.attn.in_proj_bias)
         a = Fn.attention(q, k, v, 1.0 / math.sqrt(D // self.H))
         src = Fn.layer_norm(src, self.norm1.weight, self.norm1.bias, residual=_lin(a, self.attn.out_proj))
         h = _lin(src, self.mlp[0], relu=True)

@@ -324,7 +324,13 @@ class AttentionFn(Function):
     def backward(ctx, do):
         q1, k1, v, q2, k2, o, lse2 = ctx.saved_tensors
         slots = {}
-        if q1.shape == k1.shape == v.shape and k1.is_contiguous() and v.is_contiguous():
+        qk = _column_siblings(q1, k1)
+        if qk is not None:
+            # q | k are the column halves of one buffer (InProjFn): dq | dk go out the same way
+            D = q1.shape[-1]
+            dqk = torch.empty_strided(qk.shape, qk.stride(), dtype=qk.dtype, device=qk.device)
+            slots = dict(dq1_out=dqk[..., :D], dk1_out=dqk[..., D:])
+        elif q1.shape == k1.shape == v.shape and q1.is_contiguous() and k1.is_contiguous() and v.is_contiguous():
             # self-attention: dq | dk | dv as consecutive blocks of one buffer, the layout a GroupLinearFn that
             # produced q, k, v takes as it is (no gather copies)
             buf = torch.empty((3,) + tuple(q1.shape), dtype=q1.dtype, device=q1.device)
@@ -333,9 +339,74 @@ class AttentionFn(Function):
         return dq1, dk1, dv, dq2, dk2, None
 
 
+def _strided_ok(t):
+    """A [B, T, E] operand the attention kernels take as it is: channel-contiguous, 16-byte strides / pointer."""
+    v = _VEC[t.dtype]
+    return (t.dim() == 3 and t.stride(-1) == 1 and t.stride(0) % v == 0 and t.stride(1) % v == 0
+            and t.data_ptr() % 16 == 0)
+
+
 def attention(q1, k1, v, scale, q2=None, k2=None):
-    c = lambda t: None if t is None else t.contiguous()
+    c = lambda t: None if t is None else (t if _strided_ok(t) else t.contiguous())
     return AttentionFn.apply(c(q1), c(k1), c(v), c(q2), c(k2), scale)
+
+
+def _column_siblings(a, b):
+    """a = buf[..., :D], b = buf[..., D:2D] of one [..., 2D] buffer?  Returns that buffer (a view) or None."""
+    D = a.shape[-1]
+    if (b is None or a.shape != b.shape or a.stride() != b.stride() or a.stride(-1) != 1 or a.stride(-2) != 2 * D
+            or a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr()
+            or b.storage_offset() != a.storage_offset() + D):
+        return None
+    outer = 2 * D
+    for n, st in zip(reversed(a.shape[:-1]), reversed(a.stride()[:-1])):      # dense apart from the column split
+        if st != outer:
+            return None
+        outer *= n
+    return torch.as_strided(a, tuple(a.shape[:-1]) + (2 * D,), a.stride())
+
+
+class InProjFn(Function):
+    """torch.nn.MultiheadAttention's packed input projection as the encoder uses it (reference
+    transformer.py:401-411: q = k-input = src + pos, v-input = src): q | k from ONE GEMM over xp (N = 2D), v from
+    one over src; the packed weight / bias get ONE gradient tensor each (no slice-and-accumulate kernels, and the
+    same address every step).  q and k come back as the two column halves of one [.., 2D] buffer; the attention
+    kernels read them strided and write dq | dk the same way."""
+
+    @staticmethod
+    def forward(ctx, xp, src, w, b):
+        D = w.shape[1]
+        dtype = xp.dtype
+        wqk, wv = prep_linear(w[:2 * D], dtype, False), prep_linear(w[2 * D:], dtype, False)
+        qk = ops.gemm_nt(xp, wqk, shift=b[:2 * D]).view(*xp.shape[:-1], 2 * D)
+        v = ops.gemm_nt(src, wv, shift=b[2 * D:]).view(src.shape)
+        ctx.save_for_backward(xp, src)
+        ctx.w, ctx.b = w, b
+        return qk[..., :D], qk[..., D:], v
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        xp, src = ctx.saved_tensors
+        w, b = ctx.w, ctx.b
+        D = w.shape[1]
+        dtype = xp.dtype
+        rows = xp.numel() // D
+        dqk = _column_siblings(dq, dk)
+        if dqk is None:
+            dqk = torch.cat([dq, dk], dim=-1)
+        dqk = dqk.reshape(rows, 2 * D)
+        dv = dv.contiguous().view(rows, D)
+        dxp = ops.gemm_nt(dqk, prep_linear(w[:2 * D], dtype, True)).view(xp.shape) if ctx.needs_input_grad[0] else None
+        dsrc = ops.gemm_nt(dv, prep_linear(w[2 * D:], dtype, True)).view(src.shape) if ctx.needs_input_grad[1] else None
+        dw = zeros_f32((3 * D, D), xp.device)
+        db = zeros_f32((3 * D,), xp.device)
+        ops.gemm_tn_acc(dqk, xp.view(rows, D), dw[:2 * D], colsum=db[:2 * D], zeroed=True)
+        ops.gemm_tn_acc(dv, src.view(rows, D), dw[2 * D:], colsum=db[2 * D:], zeroed=True)
+        return dxp, dsrc, dw, db
+
+
+def in_proj(xp, src, weight, bias):
+    return InProjFn.apply(xp.contiguous(), src.contiguous(), weight, bias)
 
 
 class RefPointSineFn(Function):

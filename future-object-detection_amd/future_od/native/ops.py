@@ -327,15 +327,17 @@ def attn_bwd(q1, k1, v, o, dout, lse2, scale, q2=None, k2=None, dk1_out=None, dv
     _chk(lse2, "lse2", torch.float32)
     _chk(o, "o", q1.dtype); _chk(dout, "dout", q1.dtype)
     assert dout.shape == q1.shape
-    dq1 = dq1_out if dq1_out is not None else torch.empty(q1.shape, dtype=q1.dtype, device=q1.device)
-    _same_bt(dq1, q1, "q1 (must be contiguous)")
+    dq1 = dq1_out if dq1_out is not None else torch.empty_strided(q1.shape, q1.stride(), dtype=q1.dtype,
+                                                                  device=q1.device)
+    _same_bt(dq1, q1, "dq1")
     dk1 = dk1_out if dk1_out is not None else torch.empty_strided(k1.shape, k1.stride(), dtype=k1.dtype, device=k1.device)
     dv = dv_out if dv_out is not None else torch.empty_strided(v.shape, v.stride(), dtype=v.dtype, device=v.device)
     _same_bt(dk1, k1, "dk1"); _same_bt(dv, v, "dv")
     dq2 = dk2 = None
     if q2 is not None:
         _same_bt(q1, q2, "q2")
-        dq2 = dq2_out if dq2_out is not None else torch.empty_like(dq1)
+        dq2 = dq2_out if dq2_out is not None else torch.empty_strided(q1.shape, q1.stride(), dtype=q1.dtype,
+                                                                      device=q1.device)
         _same_bt(dq2, q1, "dq2")
         B, S, E = k1.shape
         dk2 = dk2_out if dk2_out is not None else torch.empty((B, S, E), dtype=k1.dtype, device=k1.device)
