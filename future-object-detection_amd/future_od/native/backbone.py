@@ -159,6 +159,11 @@ class BackboneFn(Function):
         dev = dfeat.device
         g = dfeat.contiguous()
         grads = {}
+        sync = Fn.GRAD_SYNC
+        if sync is not None:
+            # data parallel: the backbone is the first node of the graph, so it runs last in backward and every
+            # transformer gradient is final by now -- their average over ranks travels during the whole sweep below
+            sync.flush(Fn.ARENA)
 
         def wgrad(gy, xin, cw, geom, scale):
             co, ci, kh, kw = cw.weight.shape
@@ -201,6 +206,8 @@ class BackboneFn(Function):
                 sc = bn.scale_shift()[0]
                 g = ops.conv2d_dgrad(gcur, Fn.prep_conv(cw.weight, dtype, sc, True), geoms[0],
                                      residual=d_idt, relu_mask=acts[0])
+            if sync is not None:
+                sync.maybe_flush(Fn.ARENA)        # this block's weight gradients are final (weights are used once)
         ctx.tape = None
         out = [None, None, None, None]
         for w in ctx.train_weights:

@@ -80,6 +80,15 @@ class _ZeroArena:
 
 ARENA = _ZeroArena()
 
+# Data-parallel runs: the object that averages finished arena regions across ranks (parallel.GradientReducer),
+# installed by FodDataParallel.forward for the coming backward pass; None otherwise.
+GRAD_SYNC = None
+
+
+def set_grad_sync(reducer):
+    global GRAD_SYNC
+    GRAD_SYNC = reducer
+
 
 def zeros_f32(shape, device):
     return ARENA.zeros(tuple(shape), device)

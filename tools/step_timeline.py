@@ -13,7 +13,16 @@ from types import SimpleNamespace
 
 a = SimpleNamespace(dtype="bf16")
 dev = torch.device("cuda", 0)
-model, detr = bench.build(a, dev, False, 5, "bf16")
+DDP = os.environ.get("FORCE_DDP") == "1"
+if DDP:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", init_method="env://", rank=0, world_size=1)
+model, detr = bench.build(a, dev, DDP, 5, "bf16")
+if DDP and os.environ.get("NOOP_COMM") == "1":
+    from torch.distributed.algorithms.ddp_comm_hooks.debugging_hooks import noop_hook
+    model.register_comm_hook(None, noop_hook)
 model.train()
 opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, max_norm=0.1)
 data = make_batch(2, 6, 900, 1600, seed=1234, device=dev)
@@ -43,7 +52,7 @@ SC.HungarianMatcher.match_levels = match_levels
 def step():
     mark("step start")
     opt.zero_grad()
-    out, _s, loss, stats, od = model(data=data, distributed=False)
+    out, _s, loss, stats, od = model(data=data, distributed=DDP)
     mark("forward queued")
     loss.backward()
     mark("backward queued")
