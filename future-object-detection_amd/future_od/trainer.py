@@ -102,11 +102,41 @@ class Trainer:
                     self._model_no_ddp._model.drop_mode = name
                 self._run_epoch(name, loader)
 
+    @staticmethod
+    def _fetch_async(tensors):
+        """Device tensors -> pinned host copies queued on the stream, plus the event that says when they are there.
+        The bookkeeping below consumes an iteration's numbers one iteration LATER, after the next step has been
+        queued: reading them back at once (as the reference does) stalls the host on the whole backward, and the
+        GPU then idles while the next forward is being queued (~10 % of the step)."""
+        if not tensors or not tensors[0].is_cuda:
+            return [t.detach().cpu() for t in tensors], None
+        host = []
+        for t in tensors:
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t.detach(), non_blocking=True)
+            host.append(h)
+        ev = torch.cuda.Event()
+        ev.record()
+        return host, ev
+
     def _run_epoch(self, mode, data_loader):
         od_lists = [[], [], [], []]
         world = distrib.get_world_size() if self._distributed else 1
         batch_size = getattr(data_loader, "batch_size", 1) or 1
         stat_keys = []
+        pending = None                     # (keys, host stats, host od tensors or None, event) of the previous iteration
+
+        def consume(item):
+            keys, (hstats, hod, ev) = item
+            if ev is not None:
+                ev.synchronize()
+            for k, v in zip(keys, hstats[0].tolist()):
+                self._stats[f"{mode} {k} loss"].update(v, 1)
+            if hod is not None:
+                n = len(hod) // 4
+                for j in range(4):
+                    od_lists[j].extend(hod[j * n:(j + 1) * n])
+
         for i, data in enumerate(data_loader):
             if EXIT.is_set():
                 return
@@ -129,17 +159,25 @@ class Trainer:
             if self._distributed:
                 stats = reduce_distrib_loss(stats, average=True)
             keys = list(stats.keys())
-            vals = torch.stack([stats[k].detach().float().reshape(()) for k in keys]).cpu().tolist()   # one sync
-            for k, v in zip(keys, vals):
-                self._stats[f"{mode} {k} loss"].update(v, 1)
-            stat_keys = keys
+            fetch = [torch.stack([stats[k].detach().float().reshape(()) for k in keys])]
+            n_od = 0
             if i * batch_size * world < 10000:          # cap the AP bookkeeping at ~10k images
                 od = gather_distrib_od_map_stuffs(od) if self._distributed else [[t] for t in od]
+                n_od = len(od[0])
                 for j in range(4):
-                    od_lists[j].extend(t.detach().cpu() for t in od[j])
+                    fetch.extend(od[j])
+            host, ev = self._fetch_async(fetch)
+            if pending is not None:
+                consume(pending)
+            pending = (keys, (host[:1], host[1:] if n_od else None, ev))
+            stat_keys = keys
             if (i + 1) % self._print_interval == 0:
+                consume(pending)
+                pending = None
                 msg = "  ".join(f"{self._stats[f'{mode} {k} loss'].avg:.5f} ({k})" for k in keys)
                 print(f"[{mode}: {self._epoch}, {i + 1:4d}/{len(data_loader)}] Loss: {msg}.")
+        if pending is not None:
+            consume(pending)
         msg = "  ".join(f"{self._stats[f'{mode} {k} loss'].avg:.5f} ({k})" for k in stat_keys)
         print(f"[{mode}: {self._epoch}] Loss: {msg}")
         if not od_lists[0]:
