@@ -8,99 +8,201 @@ namespace {
 constexpr int MAX_BLOCKS = 2048;
 
 FOD_DEVINL long res_row(long m, int div, int mod) {
-  long r = div > 0 ? m / div : m;
-  return mod > 0 ? r % mod : r;
+  // row counts are < 2^31 (host-checked): 32-bit division (the 64-bit one is ~100 instructions of emulation)
+  unsigned r = (unsigned)m;
+  if (div > 0) r /= (unsigned)div;
+  if (mod > 0) r %= (unsigned)mod;
+  return (long)r;
 }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm: one wave per row, D/64 elements per lane at stride 64 (coalesced).
-template <typename T, int NPL>
+// LayerNorm.  A row is spread over LPR = 16 (D % 128 == 0) or 8 lanes, so a wave works on 4 or 8 rows at once and
+// every lane moves EPL = D / LPR consecutive channels in 16-byte accesses (D = 256 bf16: two per tensor).  One wave
+// per row with two-byte accesses (the first version) was a latency chain of two 6-step wave reductions per row.
+template <int LPR>
+FOD_DEVINL float row_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// alignment of a lane's slice: the largest power of two dividing its byte size, at most 16 (16-byte-aligned rows)
+template <typename T, int EPL>
+struct SliceAlign {
+  static constexpr unsigned B = EPL * sizeof(T);
+  static constexpr unsigned VALUE = (B & (~B + 1)) > 16 ? 16 : (B & (~B + 1));
+};
+template <typename T, int EPL>
+FOD_DEVINL void ln_load(float* v, const T* p) {
+  T t[EPL];
+  __builtin_memcpy(t, __builtin_assume_aligned(p, SliceAlign<T, EPL>::VALUE), EPL * sizeof(T));
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) v[i] = to_f32(t[i]);
+}
+template <typename T, int EPL>
+FOD_DEVINL void ln_store(T* p, const float* v) {
+  T t[EPL];
+#pragma unroll
+  for (int i = 0; i < EPL; ++i) t[i] = from_f32<T>(v[i]);
+  __builtin_memcpy(__builtin_assume_aligned(p, SliceAlign<T, EPL>::VALUE), t, EPL * sizeof(T));
+}
+
+template <typename T, int D, int LPR>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                      int rdiv, int rmod, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      T* __restrict__ sum_out, float* __restrict__ mean,
                                                      float* __restrict__ rstd, int rows, float eps) {
-  constexpr int D = NPL * 64;
+  constexpr int EPL = D / LPR, RPW = 64 / LPR;      // channels per lane, rows per wave
   const int lane = threadIdx.x & 63;
-  const int wpb = blockDim.x >> 6;
-  for (long row = (long)blockIdx.x * wpb + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * wpb) {
-    float v[NPL];
-    float s = 0.f;
-    const T* xr = x + row * D;
-    const T* rr = res ? res + res_row(row, rdiv, rmod) * D : nullptr;
+  const int sub = lane % LPR, rsel = lane / LPR;
+  const int c0 = sub * EPL;
+  const long rows_per_block = (long)(blockDim.x >> 6) * RPW;
+  float ga[EPL], be[EPL];
+  __builtin_memcpy(ga, __builtin_assume_aligned(gamma + c0, SliceAlign<float, EPL>::VALUE), EPL * sizeof(float));
+  __builtin_memcpy(be, __builtin_assume_aligned(beta + c0, SliceAlign<float, EPL>::VALUE), EPL * sizeof(float));
+  for (long base = (long)blockIdx.x * rows_per_block + (threadIdx.x >> 6) * RPW; base < rows;
+       base += (long)gridDim.x * rows_per_block) {
+    const long row = base + rsel;
+    const bool live = row < rows;
+    const long r = live ? row : rows - 1;             // idle lane groups shadow the last row, nothing is stored
+    float v[EPL];
+    ln_load<T, EPL>(v, x + r * D + c0);
+    if (res) {
+      float t[EPL];
+      ln_load<T, EPL>(t, res + res_row(r, rdiv, rmod) * D + c0);
 #pragma unroll
-    for (int t = 0; t < NPL; ++t) {
-      v[t] = to_f32(xr[lane + 64 * t]);
-      if (rr) v[t] += to_f32(rr[lane + 64 * t]);
-      if (sum_out) {
-        // keep the rounding the backward will see: normalise what was stored
-        const T st = from_f32<T>(v[t]);
-        sum_out[row * D + lane + 64 * t] = st;
-        v[t] = to_f32(st);
-      }
-      s += v[t];
+      for (int i = 0; i < EPL; ++i) v[i] += t[i];
     }
-    const float mu = wave_sum(s) * (1.f / D);
+    if (sum_out) {
+      // keep the rounding the backward will see: normalise what was stored
+      T st[EPL];
+#pragma unroll
+      for (int i = 0; i < EPL; ++i) {
+        st[i] = from_f32<T>(v[i]);
+        v[i] = to_f32(st[i]);
+      }
+      if (live) __builtin_memcpy(__builtin_assume_aligned(sum_out + r * D + c0, SliceAlign<T, EPL>::VALUE), st, EPL * sizeof(T));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) s += v[i];
+    const float mu = row_sum<LPR>(s) * (1.f / D);
     float q = 0.f;
 #pragma unroll
-    for (int t = 0; t < NPL; ++t) q += (v[t] - mu) * (v[t] - mu);
-    const float rs = rsqrtf(wave_sum(q) * (1.f / D) + eps);
+    for (int i = 0; i < EPL; ++i) q += (v[i] - mu) * (v[i] - mu);
+    const float rs = rsqrtf(row_sum<LPR>(q) * (1.f / D) + eps);
+    float o[EPL];
 #pragma unroll
-    for (int t = 0; t < NPL; ++t) {
-      const int c = lane + 64 * t;
-      y[row * D + c] = from_f32<T>((v[t] - mu) * rs * gamma[c] + beta[c]);
-    }
-    if (lane == 0) {
-      mean[row] = mu;
-      rstd[row] = rs;
+    for (int i = 0; i < EPL; ++i) o[i] = (v[i] - mu) * rs * ga[i] + be[i];
+    if (live) {
+      ln_store<T, EPL>(y + r * D + c0, o);
+      if (sub == 0) {
+        mean[r] = mu;
+        rstd[r] = rs;
+      }
     }
   }
 }
 
-template <typename T, int NPL>
+template <typename T, int D, int LPR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ xs,
                                                      const float* __restrict__ mean,
                                                      const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, T* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      int rows) {
-  constexpr int D = NPL * 64;
+  constexpr int EPL = D / LPR, RPW = 64 / LPR;
   __shared__ float sg[4][D];
   __shared__ float sb[4][D];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float ag[NPL], ab[NPL];
+  const int sub = lane % LPR, rsel = lane / LPR;
+  const int c0 = sub * EPL;
+  float ga[EPL];
+  __builtin_memcpy(ga, __builtin_assume_aligned(gamma + c0, SliceAlign<float, EPL>::VALUE), EPL * sizeof(float));
+  float ag[EPL], ab[EPL];
 #pragma unroll
-  for (int t = 0; t < NPL; ++t) ag[t] = ab[t] = 0.f;
-  for (long row = (long)blockIdx.x * 4 + w; row < rows; row += (long)gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
-    float g[NPL], xh[NPL];
+  for (int i = 0; i < EPL; ++i) ag[i] = ab[i] = 0.f;
+  for (long base = (long)blockIdx.x * (4 * RPW) + w * RPW; base < rows; base += (long)gridDim.x * (4 * RPW)) {
+    const long row = base + rsel;
+    const bool live = row < rows;
+    const long r = live ? row : rows - 1;
+    const float mu = mean[r], rs = rstd[r];
+    float d[EPL], g[EPL], xh[EPL];
+    ln_load<T, EPL>(d, dy + r * D + c0);
+    ln_load<T, EPL>(xh, xs + r * D + c0);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int t = 0; t < NPL; ++t) {
-      const int c = lane + 64 * t;
-      const float d = to_f32(dy[row * D + c]);
-      xh[t] = (to_f32(xs[row * D + c]) - mu) * rs;
-      g[t] = d * gamma[c];
-      s1 += g[t];
-      s2 += g[t] * xh[t];
-      ag[t] += d * xh[t];
-      ab[t] += d;
+    for (int i = 0; i < EPL; ++i) {
+      if (!live) d[i] = 0.f;
+      xh[i] = (xh[i] - mu) * rs;
+      g[i] = d[i] * ga[i];
+      s1 += g[i];
+      s2 += g[i] * xh[i];
+      ag[i] += d[i] * xh[i];
+      ab[i] += d[i];
     }
-    s1 = wave_sum(s1) * (1.f / D);
-    s2 = wave_sum(s2) * (1.f / D);
+    s1 = row_sum<LPR>(s1) * (1.f / D);
+    s2 = row_sum<LPR>(s2) * (1.f / D);
+    float o[EPL];
 #pragma unroll
-    for (int t = 0; t < NPL; ++t)
-      dx[row * D + lane + 64 * t] = from_f32<T>(rs * (g[t] - s1 - xh[t] * s2));
+    for (int i = 0; i < EPL; ++i) o[i] = rs * (g[i] - s1 - xh[i] * s2);
+    if (live) ln_store<T, EPL>(dx + r * D + c0, o);
   }
+  // the RPW row groups of a wave hold partial sums for the same channels: fold them, then the 4 waves through LDS
 #pragma unroll
-  for (int t = 0; t < NPL; ++t) {
-    sg[w][lane + 64 * t] = ag[t];
-    sb[w][lane + 64 * t] = ab[t];
+  for (int i = 0; i < EPL; ++i) {
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+      ag[i] += __shfl_xor(ag[i], o);
+      ab[i] += __shfl_xor(ab[i], o);
+    }
+  }
+  if (rsel == 0) {
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      sg[w][c0 + i] = ag[i];
+      sb[w][c0 + i] = ab[i];
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < D; c += 256) {
     atomicAdd(dgamma + c, sg[0][c] + sg[1][c] + sg[2][c] + sg[3][c]);
     atomicAdd(dbeta + c, sb[0][c] + sb[1][c] + sb[2][c] + sb[3][c]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 16 bytes per thread when the row length allows it (every call on the path): no per-element 64-bit division,
+// 8 bf16 per load.  `cpr` = 16-byte chunks per row.
+template <typename T>
+__global__ void eltwise_vec_kernel(int op, T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b,
+                                   const T* __restrict__ c, unsigned nchunks, int cpr, int bdiv, int bmod,
+                                   float alpha) {
+  constexpr int VEC = Elem<T>::VEC;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += gridDim.x * blockDim.x) {
+    const unsigned m = i / (unsigned)cpr;
+    const unsigned col = (i - m * (unsigned)cpr) * VEC;
+    T ta[VEC], tb[VEC], tc[VEC], to[VEC];
+    __builtin_memcpy(ta, __builtin_assume_aligned(a + (long)i * VEC, 16), 16);
+    if (b) __builtin_memcpy(tb, __builtin_assume_aligned(b + res_row(m, bdiv, bmod) * ((long)cpr * VEC) + col, 16), 16);
+    if (op == FOD_EW_ADD3) __builtin_memcpy(tc, __builtin_assume_aligned(c + (long)i * VEC, 16), 16);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float av = to_f32(ta[e]);
+      const float bv = b ? to_f32(tb[e]) : 0.f;
+      float r;
+      switch (op) {
+        case FOD_EW_ADD: r = av + bv; break;
+        case FOD_EW_MUL: r = av * bv; break;
+        case FOD_EW_RELU_MASK: r = bv > 0.f ? av : 0.f; break;
+        case FOD_EW_SCALE: r = alpha * av; break;
+        case FOD_EW_ADD3: r = av + bv + to_f32(tc[e]); break;
+        case FOD_EW_COPY_B: r = bv; break;
+        default: r = fmaxf(av, 0.f); break;
+      }
+      to[e] = from_f32<T>(r);
+    }
+    __builtin_memcpy(__builtin_assume_aligned(out + (long)i * VEC, 16), to, 16);
   }
 }
 
@@ -185,6 +287,48 @@ __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N
       }
     }
     y[i] = from_f32<T>(m);
+  }
+}
+
+// 16 bytes of channels per thread (8 bf16 / 4 f32): nine 16-byte loads, one 16-byte store, 32-bit index math.
+// The scalar kernel above moved the stem's 553 MB at 1.2 TB/s (0.59 ms per step); this one is the HBM stream.
+template <typename T>
+__global__ void maxpool_vec_kernel(const T* __restrict__ x, T* __restrict__ y, int Nimg, int H, int W, int C, int Ho,
+                                   int Wo) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int cv = C / VEC;                                   // 16-byte chunks per pixel
+  const unsigned n = (unsigned)Nimg * Ho * Wo * cv;         // host-checked < 2^31
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const unsigned pix = i / cv;
+    const int c = (int)(i - pix * cv) * VEC;
+    const unsigned row = pix / Wo;
+    const int wo = (int)(pix - row * Wo);
+    const unsigned img = row / Ho;
+    const int ho = (int)(row - img * Ho);
+    float m[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) m[e] = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int hi = 2 * ho - 1 + r;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int wi = 2 * wo - 1 + s;
+        if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
+          const uint4 v = *reinterpret_cast<const uint4*>(x + (((long)img * H + hi) * W + wi) * C + c);
+          T t[VEC];
+          __builtin_memcpy(t, &v, 16);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) m[e] = fmaxf(m[e], to_f32(t[e]));
+        }
+      }
+    }
+    T o[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] = from_f32<T>(m[e]);
+    uint4 w;
+    __builtin_memcpy(&w, o, 16);
+    *reinterpret_cast<uint4*>(y + (long)pix * C + c) = w;
   }
 }
 
@@ -337,13 +481,26 @@ extern "C" int fod_layernorm_fwd(int dtype, const void* x, const void* residual,
                                  float* rstd, int rows, int D, float eps, hipStream_t stream) {
   FOD_REQUIRE(x && gamma && beta && y && mean && rstd && rows > 0, "layernorm_fwd: bad args");
   FOD_REQUIRE(D % 64 == 0 && D >= 64 && D <= 512, "layernorm_fwd: D=%d must be a multiple of 64, <= 512", D);
-  const int grid = grid_for(rows, 4);
-#define LN_FWD(NPL)                                                                                        \
-  hipLaunchKernelGGL((ln_fwd_kernel<T, NPL>), dim3(grid), dim3(256), 0, stream, (const T*)x, (const T*)residual, \
-                     res_row_div, res_row_mod, gamma, beta, (T*)y, (T*)sum_out, mean, rstd, rows, eps)
+  FOD_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)residual % 16) == 0 &&
+              ((uintptr_t)sum_out % 16) == 0 && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0,
+              "layernorm_fwd: operands must be 16-byte aligned");
+  // few rows (the decoder's 256): one row per wave so that the launch still covers many CUs
+#define LN_FWD(DD)                                                                                            \
+  do {                                                                                                        \
+    constexpr int LPR = (DD % 128 == 0) ? 16 : 8;                                                             \
+    if (rows < 8192) {                                                                                        \
+      hipLaunchKernelGGL((ln_fwd_kernel<T, DD, 64>), dim3(grid_for(rows, 4)), dim3(256), 0, stream,           \
+                         (const T*)x, (const T*)residual, res_row_div, res_row_mod, gamma, beta, (T*)y,       \
+                         (T*)sum_out, mean, rstd, rows, eps);                                                 \
+    } else {                                                                                                  \
+      hipLaunchKernelGGL((ln_fwd_kernel<T, DD, LPR>), dim3(grid_for(rows, 4 * (64 / LPR))), dim3(256), 0,     \
+                         stream, (const T*)x, (const T*)residual, res_row_div, res_row_mod, gamma, beta,      \
+                         (T*)y, (T*)sum_out, mean, rstd, rows, eps);                                          \
+    }                                                                                                         \
+  } while (0)
   FOD_DISPATCH_T(dtype, "layernorm_fwd", switch (D / 64) {
-    case 1: LN_FWD(1); break; case 2: LN_FWD(2); break; case 3: LN_FWD(3); break; case 4: LN_FWD(4); break;
-    case 5: LN_FWD(5); break; case 6: LN_FWD(6); break; case 7: LN_FWD(7); break; default: LN_FWD(8); break; })
+    case 1: LN_FWD(64); break; case 2: LN_FWD(128); break; case 3: LN_FWD(192); break; case 4: LN_FWD(256); break;
+    case 5: LN_FWD(320); break; case 6: LN_FWD(384); break; case 7: LN_FWD(448); break; default: LN_FWD(512); break; })
 #undef LN_FWD
   FOD_LAUNCH_CHECK();
   return FOD_OK;
@@ -354,14 +511,26 @@ extern "C" int fod_layernorm_bwd(int dtype, const void* dy, const void* xsum, co
                                  hipStream_t stream) {
   FOD_REQUIRE(dy && xsum && mean && rstd && gamma && dx && dgamma && dbeta && rows > 0, "layernorm_bwd: bad args");
   FOD_REQUIRE(D % 64 == 0 && D >= 64 && D <= 512, "layernorm_bwd: D=%d must be a multiple of 64, <= 512", D);
-  int grid = grid_for(rows, 16);
-  if (grid > 512) grid = 512;
-#define LN_BWD(NPL)                                                                                         \
-  hipLaunchKernelGGL((ln_bwd_kernel<T, NPL>), dim3(grid), dim3(256), 0, stream, (const T*)dy, (const T*)xsum, mean, \
-                     rstd, gamma, (T*)dx, dgamma, dbeta, rows)
+  FOD_REQUIRE(((uintptr_t)dy % 16) == 0 && ((uintptr_t)xsum % 16) == 0 && ((uintptr_t)dx % 16) == 0 &&
+              ((uintptr_t)gamma % 16) == 0, "layernorm_bwd: operands must be 16-byte aligned");
+#define LN_BWD(DD)                                                                                            \
+  do {                                                                                                        \
+    constexpr int LPR = (DD % 128 == 0) ? 16 : 8;                                                             \
+    if (rows < 8192) {                                                                                        \
+      int grid = grid_for(rows, 16);                                                                          \
+      if (grid > 512) grid = 512;                                                                             \
+      hipLaunchKernelGGL((ln_bwd_kernel<T, DD, 64>), dim3(grid), dim3(256), 0, stream, (const T*)dy,          \
+                         (const T*)xsum, mean, rstd, gamma, (T*)dx, dgamma, dbeta, rows);                     \
+    } else {                                                                                                  \
+      int grid = grid_for(rows, 4 * (64 / LPR) * 4);    /* ~4 row groups per wave: fewer atomics on dgamma */  \
+      if (grid > 512) grid = 512;                                                                             \
+      hipLaunchKernelGGL((ln_bwd_kernel<T, DD, LPR>), dim3(grid), dim3(256), 0, stream, (const T*)dy,         \
+                         (const T*)xsum, mean, rstd, gamma, (T*)dx, dgamma, dbeta, rows);                     \
+    }                                                                                                         \
+  } while (0)
   FOD_DISPATCH_T(dtype, "layernorm_bwd", switch (D / 64) {
-    case 1: LN_BWD(1); break; case 2: LN_BWD(2); break; case 3: LN_BWD(3); break; case 4: LN_BWD(4); break;
-    case 5: LN_BWD(5); break; case 6: LN_BWD(6); break; case 7: LN_BWD(7); break; default: LN_BWD(8); break; })
+    case 1: LN_BWD(64); break; case 2: LN_BWD(128); break; case 3: LN_BWD(192); break; case 4: LN_BWD(256); break;
+    case 5: LN_BWD(320); break; case 6: LN_BWD(384); break; case 7: LN_BWD(448); break; default: LN_BWD(512); break; })
 #undef LN_BWD
   FOD_LAUNCH_CHECK();
   return FOD_OK;
@@ -369,11 +538,21 @@ extern "C" int fod_layernorm_bwd(int dtype, const void* dy, const void* xsum, co
 
 extern "C" int fod_eltwise(int op, int dtype, void* out, const void* a, const void* b, const void* c, long rows,
                            int cols, int b_row_div, int b_row_mod, float alpha, hipStream_t stream) {
-  FOD_REQUIRE(out && a && rows > 0 && cols > 0, "eltwise: bad args");
+  FOD_REQUIRE(out && a && rows > 0 && cols > 0 && rows < (1L << 31), "eltwise: bad args");
   FOD_REQUIRE(op >= FOD_EW_ADD && op <= FOD_EW_COPY_B, "eltwise: bad op %d", op);
   FOD_REQUIRE(b || op == FOD_EW_SCALE || op == FOD_EW_RELU, "eltwise: op %d needs b", op);
   FOD_REQUIRE(c || op != FOD_EW_ADD3, "eltwise: ADD3 needs c");
   const long n = rows * cols;
+  const int vec = dtype == FOD_BF16 ? 8 : 4;
+  auto al = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
+  if (cols % vec == 0 && n / vec < (1L << 32) - 1 && al(out) && al(a) && (!b || al(b)) && (!c || al(c))) {
+    FOD_DISPATCH_T(dtype, "eltwise",
+                   hipLaunchKernelGGL((eltwise_vec_kernel<T>), dim3(grid_for(n / vec)), dim3(256), 0, stream, op,
+                                      (T*)out, (const T*)a, (const T*)b, (const T*)c, (unsigned)(n / vec), cols / vec,
+                                      b_row_div, b_row_mod, alpha))
+    FOD_LAUNCH_CHECK();
+    return FOD_OK;
+  }
   FOD_DISPATCH_T(dtype, "eltwise",
                  hipLaunchKernelGGL((eltwise_kernel<T>), dim3(grid_for(n)), dim3(256), 0, stream, op, (T*)out,
                                     (const T*)a, (const T*)b, (const T*)c, n, cols, b_row_div, b_row_mod, alpha))
@@ -415,6 +594,14 @@ extern "C" int fod_maxpool3x3s2(int dtype, const void* x, void* y, int Nimg, int
   FOD_REQUIRE(x && y && Nimg > 0, "maxpool: bad args");
   FOD_REQUIRE(Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1, "maxpool: geometry mismatch");
   const long n = (long)Nimg * Ho * Wo * C;
+  const int vec = dtype == FOD_BF16 ? 8 : 4;
+  if (C % vec == 0 && n / vec < (1L << 31) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0) {
+    FOD_DISPATCH_T(dtype, "maxpool",
+                   hipLaunchKernelGGL((maxpool_vec_kernel<T>), dim3(grid_for(n / vec)), dim3(256), 0, stream,
+                                      (const T*)x, (T*)y, Nimg, H, W, C, Ho, Wo))
+    FOD_LAUNCH_CHECK();
+    return FOD_OK;
+  }
   FOD_DISPATCH_T(dtype, "maxpool",
                  hipLaunchKernelGGL((maxpool_kernel<T>), dim3(grid_for(n)), dim3(256), 0, stream, (const T*)x, (T*)y,
                                     Nimg, H, W, C, Ho, Wo))
