@@ -15,6 +15,8 @@
 // kappa, common.h).  No LDS, no barriers.  Operand rows come straight from global/L2.
 //
 // lse is kept in log2 units: lse2[q] = max2 + log2(sum exp2(x - max2)), x = score*scale*log2(e).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -72,6 +74,8 @@ struct TransTile<float> {
   FOD_DEVINL void stage(const float* b, long st, int nr, unsigned char*, int) {
     base = b; stride = st; nrows = nr;
   }
+  FOD_DEVINL void prefetch(const float* b, long st, int nr, int) { base = b; stride = st; nrows = nr; }
+  FOD_DEVINL void commit(unsigned char*, int) {}
   FOD_DEVINL void frag(Frag<float>& f, int s, int lane) const {
     frag_gather_accorder(f, base + (lane & 31), stride, s, lane >> 5, nrows);
   }
@@ -79,6 +83,31 @@ struct TransTile<float> {
 template <>
 struct TransTile<__bf16> {
   const unsigned char* lds;
+  uint4 pre[2];
+  // prefetch() requests the tile's rows into registers, commit() moves them into the slab one loop trip later
+  FOD_DEVINL void prefetch(const __bf16* b, long st, int nr, int lane) {
+    const int chunk = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (lane >> 2) + 16 * i;
+      pre[i] = *reinterpret_cast<const uint4*>(b + (long)min(row, max(nr, 1) - 1) * st + chunk * 8);
+    }
+  }
+  FOD_DEVINL void commit(unsigned char* slab, int lane) {
+    const int chunk = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(slab + ((lane >> 2) + 16 * i) * 64 + chunk * 16) = pre[i];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lds = slab;
+  }
+  // the tile is already in registers as the two natural fragments of row (lane & 31): write those
+  FOD_DEVINL void from_frags(const Frag<__bf16>& f0, const Frag<__bf16>& f1, unsigned char* slab, int lane) {
+    unsigned char* q = slab + (lane & 31) * 64 + 16 * (lane >> 5);
+    *reinterpret_cast<Frag<__bf16>*>(q) = f0;
+    *reinterpret_cast<Frag<__bf16>*>(q + 32) = f1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lds = slab;
+  }
   FOD_DEVINL void stage(const __bf16* b, long st, int nr, unsigned char* slab, int lane) {
     const int chunk = lane & 3;
 #pragma unroll
@@ -142,6 +171,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char slab_v[4][2048];
   TransTile<T> tv;
 
+  // (Requesting the next key tile one trip ahead, as the two backward passes do, was measured SLOWER here: at 4
+  // waves per SIMD the other waves already cover the L2 round trip, the extra register copies and waits do not.)
   for (int k0 = SPLIT ? wave * 32 : 0; k0 < p.S; k0 += SPLIT ? 128 : 32) {
     const int kr = min(k0 + fr, p.S - 1);
     f32x16 sacc;
@@ -261,22 +292,38 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char slab_k[4][PARTS][2048];
   TransTile<T> tk[PARTS];
 
-  for (int k0 = SPLIT ? wave * 32 : 0; k0 < p.S; k0 += SPLIT ? 128 : 32) {
+  // next key tile one trip ahead (see attn_fwd_kernel); the transposed K operand is made from the same registers
+  constexpr int KSTEP = SPLIT ? 128 : 32;
+  const int kfirst = SPLIT ? wave * 32 : 0;
+  Frag<T> fk_next[PARTS][2], fv_next[2];
+  auto request = [&](int k0) {
     const int kr = min(k0 + fr, p.S - 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt)
+        frag_load_contig(fk_next[pt][s], Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)kr * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
+      frag_load_contig(fv_next[s], Vp + (long)kr * p.v_ts + 16 * s + 8 * fh);
+    }
+  };
+  if (kfirst < p.S) request(kfirst);
+  for (int k0 = kfirst; k0 < p.S; k0 += KSTEP) {
+    Frag<T> fk[PARTS][2], fv[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      fv[s] = fv_next[s];
+#pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt) fk[pt][s] = fk_next[pt][s];
+    }
+    request(k0 + KSTEP);
     f32x16 sacc, dpacc;
     zero_acc<T>(sacc);
     zero_acc<T>(dpacc);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
-      for (int pt = 0; pt < PARTS; ++pt) {
-        Frag<T> fk;
-        frag_load_contig(fk, Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)kr * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
-        mma16(fk, fq[pt][s], sacc);
-      }
-      Frag<T> fv;
-      frag_load_contig(fv, Vp + (long)kr * p.v_ts + 16 * s + 8 * fh);
-      mma16(fv, fdo[s], dpacc);             // dP^T[k, q] = sum_d V[k,d] dO[q,d]
+      for (int pt = 0; pt < PARTS; ++pt) mma16(fk[pt][s], fq[pt][s], sacc);
+      mma16(fv[s], fdo[s], dpacc);          // dP^T[k, q] = sum_d V[k,d] dO[q,d]
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -285,9 +332,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
       sacc[r] = pr * (dpacc[r] - dl) * p.scale;      // dS^T
     }
 #pragma unroll
-    for (int pt = 0; pt < PARTS; ++pt)
-      tk[pt].stage(Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)k0 * (pt ? p.k2_ts : p.k_ts) + h * 32,
-                   (pt ? p.k2_ts : p.k_ts), p.S - k0, slab_k[wave][pt], lane);
+    for (int pt = 0; pt < PARTS; ++pt) {
+      if constexpr (sizeof(T) == 2)
+        tk[pt].from_frags(fk[pt][0], fk[pt][1], slab_k[wave][pt], lane);
+      else
+        tk[pt].stage(Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)k0 * (pt ? p.k2_ts : p.k_ts) + h * 32,
+                     (pt ? p.k2_ts : p.k_ts), p.S - k0, slab_k[wave][pt], lane);
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       Frag<T> fds;
@@ -299,6 +350,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
         mma16(fkt, fds, dq[pt]);             // dQ^T[d, q] += sum_k K[k,d] dS^T[k,q]
       }
     }
+    if (sizeof(T) == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next tile
   }
   if (SPLIT) {   // the four partial dQ^T tiles just add
     __shared__ float s_dq[3][PARTS][32][33];
@@ -417,6 +469,133 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
   }
 }
 
+// bf16 dk/dv pass with the next query tile in flight.  The loop above consumes its global loads at once (two
+// exposed L2 round trips per 32 queries, plus 32 scalar loads of lse / delta per lane): at 2 waves per SIMD that
+// latency was the kernel -- 111 TFLOP/s against 226 for the dq pass on the same problem.  Here
+//   * the Q / dO fragments of tile t+1 (exactly the [32 x 32] tiles, 16 bytes per lane each) and its lse / delta
+//     are requested before tile t is touched;
+//   * the transposed operands are made from those same registers (ds_write_b128 into the wave's slab, then
+//     transposing reads) instead of loading the tiles a second time;
+//   * lse / delta reach the accumulator layout through LDS: one coalesced load per lane, four ds_read_b128 each
+//     (accumulator rows 8g + 4h .. +3 are consecutive queries).
+// Rows past Tq are clamped duplicates; their P and dS are zeroed, so they add nothing.
+template <int PARTS>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_pf_kernel(const AttnParams p) {
+  typedef __bf16 T;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int k0 = (blockIdx.x * 4 + wave) * 32;
+  if (k0 >= p.S) return;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int key = min(k0 + fr, p.S - 1);
+  const T* Qb[2] = {reinterpret_cast<const T*>(p.q1) + (long)b * p.q_bs + h * 32 + 8 * fh,
+                    p.q2 ? reinterpret_cast<const T*>(p.q2) + (long)b * p.q_bs + h * 32 + 8 * fh : nullptr};
+  const T* Kp[2] = {reinterpret_cast<const T*>(p.k1), reinterpret_cast<const T*>(p.k2)};
+  const T* Vp = reinterpret_cast<const T*>(p.v) + (long)b * p.v_bs + (long)key * p.v_ts + h * 32;
+  const T* dOb = reinterpret_cast<const T*>(p.dout) + (long)b * p.o_bs + h * 32 + 8 * fh;
+
+  Frag<T> fk[PARTS][2], fv[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    frag_load_contig(fv[s], Vp + 16 * s + 8 * fh);
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt)
+      frag_load_contig(fk[pt][s], Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)key * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
+  }
+  const float c = p.scale * LOG2E;
+  f32x16 dk[PARTS], dv;
+  zero_acc<T>(dv);
+#pragma unroll
+  for (int pt = 0; pt < PARTS; ++pt) zero_acc<T>(dk[pt]);
+  const float* lse_b = p.lse2 + ((long)b * p.H + h) * p.Tq;
+  const float* del_b = p.delta + ((long)b * p.H + h) * p.Tq;
+  __shared__ __attribute__((aligned(16))) unsigned char slab_q[4][PARTS + 1][2048];
+  __shared__ __attribute__((aligned(16))) float stat[4][2][32];
+
+  struct Tile {
+    Frag<T> q[PARTS][2], d[2];
+    float st;                       // lanes 0-31: lse of query q0 + lane, lanes 32-63: delta of query q0 + lane - 32
+  };
+  auto request = [&](int q0, Tile& t) {
+    const int qr = min(q0 + fr, p.Tq - 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt) frag_load_contig(t.q[pt][s], Qb[pt] + (long)qr * p.q_ts + 16 * s);
+      frag_load_contig(t.d[s], dOb + (long)qr * p.o_ts + 16 * s);
+    }
+    t.st = (fh ? del_b : lse_b)[qr];
+  };
+  TransTile<T> tdo, tq[PARTS];
+  tdo.lds = slab_q[wave][PARTS];
+#pragma unroll
+  for (int pt = 0; pt < PARTS; ++pt) tq[pt].lds = slab_q[wave][pt];
+  const int slab_off = fr * 64 + 16 * fh;                // this lane's two 16-byte pieces of a row-major [32][32] tile
+
+  Tile cur, nxt;
+  request(0, cur);
+  for (int q0 = 0; q0 < p.Tq; q0 += 32) {
+    request(q0 + 32, nxt);                               // past the end: clamped re-reads of the last row, unused
+    // tile t -> the wave's slabs (transposed operands) and its row statistics -> LDS
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      *reinterpret_cast<Frag<T>*>(slab_q[wave][PARTS] + slab_off + 32 * s) = cur.d[s];
+#pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt) *reinterpret_cast<Frag<T>*>(slab_q[wave][pt] + slab_off + 32 * s) = cur.q[pt][s];
+    }
+    stat[wave][fh][fr] = cur.st;
+    f32x16 sacc, dpacc;
+    zero_acc<T>(sacc);
+    zero_acc<T>(dpacc);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt) mma16(cur.q[pt][s], fk[pt][s], sacc);      // S[q, key]
+      mma16(cur.d[s], fv[s], dpacc);                                                // dP[q, key]
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private LDS: the writes above are visible to the reads
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 ls = *reinterpret_cast<const f32x4*>(&stat[wave][0][8 * g + 4 * fh]);
+      const f32x4 de = *reinterpret_cast<const f32x4*>(&stat[wave][1][8 * g + 4 * fh]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        const bool ok = q0 + 8 * g + 4 * fh + e < p.Tq;
+        const float pr = ok ? exp2f(sacc[r] * c - ls[e]) : 0.f;
+        dpacc[r] = pr * (dpacc[r] - de[e]) * p.scale;   // dS
+        sacc[r] = pr;                                   // P
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      Frag<T> fp, fds, fdot;
+      frag_from_acc(fp, sacc, s);
+      frag_from_acc(fds, dpacc, s);
+      tdo.frag(fdot, s, lane);
+      mma16(fdot, fp, dv);                    // dV^T[d, key] += sum_q dO[q,d] P[q,key]
+#pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt) {
+        Frag<T> fqt;
+        tq[pt].frag(fqt, s, lane);
+        mma16(fqt, fds, dk[pt]);              // dK^T[d, key] += sum_q Q[q,d] dS[q,key]
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slab reads are done before the next tile overwrites them
+    cur = nxt;
+  }
+  if (k0 + fr < p.S) {
+    T* o = reinterpret_cast<T*>(p.dv) + (long)b * p.v_bs + (long)key * p.v_ts + h * 32;
+    store_acc_t<T>(o, dv, fh, 1.f);
+    T* d1 = reinterpret_cast<T*>(p.dk1) + (long)b * p.k_bs + (long)key * p.k_ts + h * 32;
+    store_acc_t<T>(d1, dk[0], fh, 1.f);
+    if (PARTS == 2) {
+      T* d2 = reinterpret_cast<T*>(p.dk2) + (long)b * p.dk2_bs + (long)key * p.dk2_ts + h * 32;
+      store_acc_t<T>(d2, dk[PARTS - 1], fh, 1.f);
+    }
+  }
+}
+
 template <typename T, int PARTS>
 int launch_all(int which, const AttnParams& p, hipStream_t stream) {
   const dim3 block(256);
@@ -434,7 +613,11 @@ int launch_all(int which, const AttnParams& p, hipStream_t stream) {
       hipLaunchKernelGGL((attn_bwd_dq_kernel<T, PARTS, false>), dim3(ceil_div(p.Tq, 128), p.H, p.B), block, 0, stream, p);
   } else {
     const dim3 grid(ceil_div(p.S, 128), p.H, p.B);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, PARTS>), grid, block, 0, stream, p);
+    static const char* env_pf = getenv("FOD_ATTN_PF");
+    if (sizeof(T) == 2 && !(env_pf && env_pf[0] == '0'))
+      hipLaunchKernelGGL((attn_bwd_dkv_pf_kernel<PARTS>), grid, block, 0, stream, p);
+    else
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, PARTS>), grid, block, 0, stream, p);
   }
   FOD_LAUNCH_CHECK();
   return FOD_OK;
