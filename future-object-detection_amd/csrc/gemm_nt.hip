@@ -383,6 +383,45 @@ FOD_DEVINL void gemm_nt_body(const NtParams& p) {
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + nc);
     if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + nc);
+    // Full tiles with bf16 output (all but the last m-tile of a launch) take a row loop specialised at compile
+    // time for the epilogue options in use: straight-line code, so the 16 LDS reads are issued together and no
+    // option costs instructions when it is off.  The generic loop below (a uniform branch per option and an edge
+    // test per row) ran each pass as its own read -> wait -> arithmetic -> store chain, 2.4 us per tile.
+    if (sizeof(T) == 2 && !p.c_is_f32 && PB == NPASS && m0 + BM <= p.M && n0 + BN <= p.N) {
+      auto rows_out = [&](auto has_res, auto do_relu, auto has_mask) {
+        f32x4 v[NPASS];
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) v[ps] = *reinterpret_cast<const f32x4*>(sC + (rq + ps * RPP) * BN + cq * 4);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+          f32x4 w = v[ps] * sc + sh;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (decltype(has_res)::value) w[e] += (float)rres[ps][e];
+            if constexpr (decltype(do_relu)::value) w[e] = fmaxf(w[e], 0.f);
+            if constexpr (decltype(has_mask)::value) w[e] = ((float)rmsk[ps][e] > 0.f) ? w[e] : 0.f;
+          }
+          const long mo = out_row(m0 + rq + ps * RPP);
+          *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(p.C) + mo * p.ldc + n) =
+              bf16x4_t{(__bf16)w[0], (__bf16)w[1], (__bf16)w[2], (__bf16)w[3]};
+        }
+      };
+      typedef std::true_type Y;
+      typedef std::false_type N_;
+      const bool R = Rp != nullptr, L = p.relu != 0, K = Mp != nullptr;
+      bool done = true;
+      if (!R && !L && !K) rows_out(N_{}, N_{}, N_{});
+      else if (!R && L && !K) rows_out(N_{}, Y{}, N_{});
+      else if (R && L && !K) rows_out(Y{}, Y{}, N_{});
+      else if (R && !L && !K) rows_out(Y{}, N_{}, N_{});
+      else if (!R && !L && K) rows_out(N_{}, N_{}, Y{});
+      else if (R && !L && K) rows_out(Y{}, N_{}, Y{});
+      else done = false;
+      if (done) {
+        FOD_STAMP(4);
+        return;
+      }
+    }
 #pragma unroll
     for (int base = 0; base < NPASS; base += PB) {
       if (base > 0) prefetch(base);
