@@ -107,6 +107,20 @@ class ResNetBody(nn.Module):
             for blk in getattr(self, f"layer{s + 1}"):
                 yield s + 1, blk
 
+    # the dataset's pixel pipeline (reference nu_scenes.py:97-101), applied inside the layout kernel when the clip
+    # arrives as raw uint8 frames; plain attributes, not buffers, so the state-dict schema stays the reference's
+    PIXEL_MEAN, PIXEL_STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+    def pixel_norm(self, video):
+        if video.dtype != torch.uint8:
+            return ()
+        c = getattr(self, "_pixel_norm", None)
+        if c is None or c[0].device != video.device:
+            c = (torch.tensor(self.PIXEL_MEAN, dtype=torch.float32, device=video.device),
+                 torch.tensor(self.PIXEL_STD, dtype=torch.float32, device=video.device))
+            object.__setattr__(self, "_pixel_norm", c)
+        return c
+
 
 STEM_CIN_PAD = 8   # 3 input channels padded to one 16-byte bf16 chunk
 
@@ -124,7 +138,7 @@ class BackboneFn(Function):
         """video f32 [B,L,3,H,W] (a strided view is fine) -> features NHWC [(l b), h, w, hidden];
         train_weights = trainable conv weights in body.blocks() order, then proj.weight, proj.bias
         (listed only so autograd routes their gradients)."""
-        x = ops.clip_to_nhwc_frame_major(video, dtype, STEM_CIN_PAD)
+        x = ops.clip_to_nhwc_frame_major(video, dtype, STEM_CIN_PAD, *body.pixel_norm(video))
         x, _ = _conv_fwd(x, body.conv1, body.bn1, dtype, relu=True, cin_pad=STEM_CIN_PAD)
         x = ops.maxpool3x3s2(x)
         tape = []

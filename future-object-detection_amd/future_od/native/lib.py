@@ -56,6 +56,7 @@ SIGNATURES = {
     "fod_conv2d_wgrad_acc": [_i, _p, _p, _p, _CG, _p, _i, _p],
     "fod_maxpool3x3s2": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "fod_nchw_to_nhwc": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _p],
+    "fod_u8_nchw_to_nhwc": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _p, _p, _p],
     "fod_permute3_cast": [_i, _i, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _i, _p],
     "fod_attn_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _AS, _p],
     "fod_attn_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _AS, _p],

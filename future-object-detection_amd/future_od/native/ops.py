@@ -236,15 +236,23 @@ def nchw_to_nhwc(video, dtype, cpad):
     return out
 
 
-def clip_to_nhwc_frame_major(video, dtype, cpad):
-    """f32 [B,L,C,H,W] (a view whose frame planes are contiguous) -> dtype [L*B,H,W,cpad] ordered (l, b)."""
-    if not video.is_cuda or video.dtype != torch.float32:
-        raise L.FodError("video must be a float32 device tensor")
+def clip_to_nhwc_frame_major(video, dtype, cpad, mean=None, std=None):
+    """[B,L,C,H,W] (a view whose frame planes are contiguous) -> dtype [L*B,H,W,cpad] ordered (l, b).
+    f32 video: already normalised pixels.  uint8 video: raw frames, normalised on the fly with f32 `mean` / `std`
+    ([C] device tensors): ((x / 255) - mean) / std."""
+    if not video.is_cuda or video.dtype not in (torch.float32, torch.uint8):
+        raise L.FodError("video must be a float32 or uint8 device tensor")
     b, l, c, h, w = video.shape
     sb, sl, sc, sh, sw = video.stride()
     assert (sc, sh, sw) == (h * w, w, 1), f"frame planes must be contiguous, got strides {video.stride()}"
     out = torch.empty((l * b, h, w, cpad), dtype=dtype, device=video.device)
-    call("fod_nchw_to_nhwc", _DT[dtype], ptr(video), ptr(out), l * b, c, h, w, cpad, b, sl, sb, stream())
+    if video.dtype == torch.uint8:
+        _chk(mean, "mean", torch.float32); _chk(std, "std", torch.float32)
+        assert mean.numel() == c and std.numel() == c
+        call("fod_u8_nchw_to_nhwc", _DT[dtype], ptr(video), ptr(out), l * b, c, h, w, cpad, b, sl, sb, ptr(mean),
+             ptr(std), stream())
+    else:
+        call("fod_nchw_to_nhwc", _DT[dtype], ptr(video), ptr(out), l * b, c, h, w, cpad, b, sl, sb, stream())
     return out
 
 

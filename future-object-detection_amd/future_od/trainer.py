@@ -8,6 +8,7 @@ import torch.distributed as distrib
 
 from future_od.utils.distributed import EXIT, gather_distrib_od_map_stuffs, reduce_distrib_loss
 from future_od.utils.od_map import aggregate_mean_average_precision
+from future_od.utils.prefetch import DevicePrefetcher
 from future_od.utils.recursive_functions import recursive_detach_cpu, recursive_to
 from future_od.utils.stats import AverageMeter
 from future_od.utils.wandb import WandBConfig
@@ -137,10 +138,9 @@ class Trainer:
                 for j in range(4):
                     od_lists[j].extend(hod[j * n:(j + 1) * n])
 
-        for i, data in enumerate(data_loader):
+        for i, data in enumerate(DevicePrefetcher(data_loader, self._device)):      # next batch staged on a side stream
             if EXIT.is_set():
                 return
-            data = recursive_to(data, self._device)
             if mode == "train":
                 self._optimizer.zero_grad()
             out, _state, loss, stats, od = self._model(data=data, visualize=False, epoch=self._epoch,

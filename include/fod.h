@@ -120,6 +120,13 @@ int fod_maxpool3x3s2(int dtype, const void* x, void* y, int Nimg, int H, int W, 
 int fod_nchw_to_nhwc(int dtype, const float* src, void* dst, int F, int C, int H, int W, int Cp, int inner,
                      long stride_outer, long stride_inner, fod_stream_t stream);
 
+/* The same fold for raw uint8 frames with the dataset's pixel pipeline applied on the fly in fp32:
+ * x.float() / 255 (future_od/datasets/transforms.py:12-15) then (x - mean[c]) / std[c]
+ * (future_od/datasets/nu_scenes.py:97-101); strides in bytes (= elements). */
+int fod_u8_nchw_to_nhwc(int dtype, const unsigned char* src, void* dst, int F, int C, int H, int W, int Cp,
+                        int inner, long stride_outer, long stride_inner, const float* mean, const float* std,
+                        fod_stream_t stream);
+
 /* dst[i0][i1][i2] = src[i0*s0 + i1*s1 + i2*s2] * scale[index on scale_axis]   (i2 >= valid2 -> 0)
  * src_dtype/dst_dtype independent.  Weight preparation (cast, transpose, BN-scale fold, channel pad)
  * and activation casts. */

@@ -86,3 +86,19 @@ def test_recursive_to_keeps_host_annotations():
     packed = pack_targets(targets, "cpu")
     assert packed["sizes"] == [int(batch["active"][b].sum()) for b in range(2)]
     assert packed["labels"].shape[0] == sum(packed["sizes"]) and packed["offset_cpu"].tolist()[-1] == sum(packed["sizes"])
+
+
+def test_device_prefetcher_cpu_passthrough():
+    """On a CPU device the prefetcher is a plain batch mover that keeps the host annotation copies."""
+    import torch
+    from future_od.datasets.synthetic import make_batch
+    from future_od.utils.prefetch import DevicePrefetcher
+    batches = []
+    for s in range(3):
+        b = make_batch(1, 2, 16, 24, seed=s, max_boxes=4)
+        b.pop("_host_annotations")
+        batches.append(b)
+    out = list(DevicePrefetcher(batches, "cpu"))
+    assert len(out) == 3 and len(DevicePrefetcher(batches, "cpu")) == 3
+    for src, dst in zip(batches, out):
+        assert torch.equal(src["video"], dst["video"]) and dst["_host_annotations"]["active"] is src["active"]

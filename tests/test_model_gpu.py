@@ -146,6 +146,24 @@ def test_host_annotation_path_is_exact():
         assert torch.equal(x, y)
 
 
+def test_uint8_frames_match_host_normalisation():
+    """Raw uint8 frames, normalised inside the layout kernel ((x / 255 - mean) / std in fp32, the reference
+    dataset's transform), give bit-identical fp32 outputs to the same frames normalised on the host."""
+    cfg = Config(backbone="resnet18", enc_layers=1, dec_layers=1)
+    model, _ = build_product(cfg, torch.float32, 5)
+    data = make_batch(2, 3, 64, 96, seed=5, device=DEV, max_boxes=6)
+    g = torch.Generator().manual_seed(5)
+    raw = torch.randint(0, 256, (2, 3, 3, 64, 96), generator=g, dtype=torch.uint8)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 1, 3, 1, 1)
+    host = ((raw.float() / 255) - mean) / std
+    imu = torch.cat([data[k] for k in model._imu_keys], dim=2)
+    with torch.no_grad():
+        a, _ = model._model(host.to(DEV), imu=imu)
+        b, _ = model._model(raw.to(DEV), imu=imu)
+    assert torch.equal(a["pred_logits"], b["pred_logits"]) and torch.equal(a["pred_boxes"], b["pred_boxes"])
+
+
 def test_dead_frame_skipping_is_exact():
     cfg = Config(backbone="resnet18", enc_layers=1, dec_layers=1)
     model, _ = build_product(cfg, torch.float32, 3)

@@ -85,3 +85,25 @@ def test_trainer_short_run(tmp_path):
     for k, v in model.state_dict().items():
         assert torch.equal(v, model2.state_dict()[k]), k
     assert hasattr(tr, "last_ap") and tr.last_ap["all"].shape[0] == 10
+
+
+def test_device_prefetcher_stages_next_batch():
+    """Batches staged through pinned memory on a side stream arrive intact, keep their host annotation copies, and
+    the model consumes them (uint8 and float clips alike)."""
+    import torch
+    from future_od.datasets.synthetic import make_batch
+    from future_od.utils.prefetch import DevicePrefetcher
+    host_batches = []
+    for s in range(3):
+        b = make_batch(1, 2, 32, 48, seed=s, max_boxes=4)
+        b.pop("_host_annotations")
+        if s == 1:
+            b["video"] = torch.randint(0, 256, b["video"].shape, dtype=torch.uint8)
+        host_batches.append(b)
+    got = list(DevicePrefetcher(host_batches, "cuda:0"))
+    torch.cuda.synchronize()
+    assert len(got) == 3
+    for src, dst in zip(host_batches, got):
+        assert dst["video"].is_cuda and dst["video"].dtype == src["video"].dtype
+        assert torch.equal(dst["video"].cpu(), src["video"]) and torch.equal(dst["boxes"].cpu(), src["boxes"])
+        assert dst["_host_annotations"]["classes"] is src["classes"]
