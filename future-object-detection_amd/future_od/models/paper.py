@@ -179,23 +179,29 @@ class CDetrDetectorSpatioTemporal(nn.Module):
         assert first_layer_special_when in ("first frame", "always", "never")
         self._first_layer_special_when = first_layer_special_when
         assert image_memory_mode in ("attend one at a time", "attend all at once")
-        if image_memory_mode != "attend one at a time":
-            raise NotImplementedError("'attend all at once' is not used by the reference's runs/ (SURVEY.md 8f-2)")
         self.image_memory_mode = image_memory_mode
         self.num_images = len(self.decoder.layers[0].image_attend)
         assert all(self.num_images == len(layer.image_attend) for layer in self.decoder.layers)
         self.use_slotstates = False
 
     def frames_needed(self, L):
-        return min(self.num_images, L)
+        """Past frames that can reach the output: all of them when they form one memory, else the last num_images."""
+        return L if self.image_memory_mode == "attend all at once" else min(self.num_images, L)
 
-    def forward(self, frame_tokens: List[Tensor], pos_table: Tensor, num_frames_total: int):
-        """frame_tokens: the LAST frames of the clip, oldest first, each [B,N,D]; pos_table [N,D].
-        Equivalent to the reference's sweep over all frames keeping the last result (paper.py:347-350)."""
+    def forward(self, frame_tokens: List[Tensor], pos, num_frames_total: int):
+        """frame_tokens: the LAST frames of the clip, oldest first, each [B,N,D].
+        'attend one at a time' (reference paper.py:340-350): `pos` = encoding of the current (last) frame, [N,D]
+        or [B,N,D]; equivalent to the reference's sweep over all frames keeping the last result.
+        'attend all at once' (paper.py:334-339): ONE memory of all frames, (l h w)-ordered; `pos` = its encoding,
+        [L*N,D] or [B,L*N,D]."""
         K = len(frame_tokens)
+        if self.image_memory_mode == "attend all at once":
+            assert K == num_frames_total, "every past frame is part of the memory"
+            mem = torch.cat(frame_tokens, dim=1) if K > 1 else frame_tokens[0]
+            return self.detect([mem], pos, True)
         first_frame = num_frames_total == 1
         mems = [frame_tokens[K - 1 - j] for j in range(min(K, self.num_images))]   # current, then previous
-        return self.detect(mems, pos_table, first_frame)
+        return self.detect(mems, pos, first_frame)
 
     def detect(self, mems, pos_table, first_frame=True):
         B, N, D = mems[0].shape
@@ -224,7 +230,8 @@ class FuturePredCore(nn.Module):
                  pos_encoder: PositionalEncoder):
         super().__init__()
         if joint_encoder is not None:
-            raise NotImplementedError("joint encoders are not instantiated by the reference's runs/ (SURVEY.md 8f-2)")
+            raise NotImplementedError("joint encoders (JointEncoder / JointEncoderSequential / F2F) are not instantiated "
+                                      "by the reference's runs/ (SURVEY.md 8f-2): next")
         self.separate_encoder = separate_encoder
         self.joint_encoder = None
         self.detector = detector
@@ -234,18 +241,27 @@ class FuturePredCore(nn.Module):
 
     def forward(self, images: Tensor, imu: Tensor = None, temporal_offsets: Tensor = None):
         B, L = images.shape[:2]
-        if not self.pos_encoder._no_temporal:
-            raise NotImplementedError("temporal positional encoding is disabled in the shipped model "
-                                      "(runs/_model.py:70-72); kernel exists (fod_posenc_temporal), wiring is next")
         past = L - 1
         assert past > 0
-        keep = self.detector.frames_needed(past) if self.skip_dead_frames else past
+        all_at_once = self.detector.image_memory_mode == "attend all at once"
+        keep = self.detector.frames_needed(past) if (self.skip_dead_frames or all_at_once) else past
         clip = images[:, past - keep:past]
         imu_k = imu[:, past - keep:past] if imu is not None else None
         tokens, (h, w), _ego = self.separate_encoder(clip, self.pos_encoder, imu_k, dtype=self.compute_dtype)
         F_, N, D = tokens.shape
         frames = list(tokens.view(keep, B, N, D).unbind(0))
-        pos = self.pos_encoder.spatial_table(h, w, D, self.compute_dtype, tokens.device)
+        pos = self.pos_encoder.spatial_table(h, w, D, self.compute_dtype, tokens.device)          # [N, D]
+        if not self.pos_encoder._no_temporal:
+            # + the per-(batch, frame) temporal term (reference paper.py:50-55,66-73), computed over ALL past
+            # frames (it is normalised by the last one) and cut to the frames that are kept
+            offs = temporal_offsets[:, :past] if temporal_offsets is not None else None
+            tt = self.pos_encoder.temporal_table(B, past, D, torch.float32, tokens.device, offs)[:, past - keep:]
+            if all_at_once:
+                pos = (pos.float()[None, None] + tt[:, :, None]).reshape(B, keep * N, D).to(self.compute_dtype)
+            else:
+                pos = (pos.float()[None] + tt[:, -1, None]).to(self.compute_dtype).contiguous()   # [B, N, D]
+        elif all_at_once:
+            pos = pos.repeat(keep, 1)                                                             # [keep*N, D]
         out = self.detector(frames, pos, num_frames_total=past)
         moods = [["model happy" for _ in range(L)] for _ in range(B)]
         return out, moods

@@ -667,7 +667,7 @@ class MemorySide:
         v = b[..., (2 * layer) * D:(2 * layer + 1) * D]
         kc = b[..., (2 * layer + 1) * D:(2 * layer + 2) * D]
         q = layer * self.K + image
-        ks = self.ks_all[:, q * D:(q + 1) * D]
+        ks = self.ks_all[..., q * D:(q + 1) * D]      # [N, D] table shared by the batch, or [B, N, D] (temporal term)
         return kc, ks, v
 
 
@@ -692,9 +692,11 @@ class HoistedCrossAttnFn(Function):
         kc, ks, v = side.slots(layer, image)
         if side.dbig[image] is None:
             side.dbig[image] = torch.empty_like(side.big[image])
+        per_batch_pos = side.ks_all.dim() == 3
         if side.dks is None:
             B = q1.shape[0]
-            side.dks = torch.empty((B,) + tuple(side.ks_all.shape), dtype=side.ks_all.dtype, device=q1.device)
+            shape = tuple(side.ks_all.shape) if per_batch_pos else (B,) + tuple(side.ks_all.shape)
+            side.dks = torch.empty(shape, dtype=side.ks_all.dtype, device=q1.device)
         db = side.dbig[image]
         dv = db[..., (2 * layer) * D:(2 * layer + 1) * D]
         dkc = db[..., (2 * layer + 1) * D:(2 * layer + 2) * D]
@@ -707,8 +709,10 @@ class HoistedCrossAttnFn(Function):
         dq1, _, dq2, _, _ = ops.attn_bwd(q1, kc, v, o, do.contiguous(), lse2, ctx.scale, q2, ks,
                                          dk1_out=dkc, dv_out=dv, dk2_out=dks, dq2_out=side.dq2[key][image])
         g_big = side.dbig[image] if layer == 0 else None
-        # ks_all is shared by the batch: its gradient is the sum of the per-batch slots
-        g_ks = _sum_leading(side.dks, side.dks.shape[0]) if (layer == 0 and image == 0) else None
+        # a batch-shared ks_all gets the sum of the per-batch slots
+        g_ks = None
+        if layer == 0 and image == 0:
+            g_ks = side.dks if per_batch_pos else _sum_leading(side.dks, side.dks.shape[0])
         return dq1, dq2, g_big, g_ks, None, None, None, None
 
 

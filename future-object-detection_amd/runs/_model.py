@@ -47,8 +47,8 @@ def build_model(args, detr_args: SpatioTemporalDETRArgs):
                 norm=nn.LayerNorm(detr_args.hidden_dim), return_intermediate=True, D=detr_args.hidden_dim),
             num_classes=detr_args.num_classes, hidden_dim=detr_args.hidden_dim,
             first_layer_special_when="always", num_queries=detr_args.num_queries, aux_loss=True,
-            image_memory_mode="attend one at a time"),
-        pos_encoder=PositionalEncoder(no_temporal=True))
+            image_memory_mode=getattr(args, "image_memory_mode", "attend one at a time")),
+        pos_encoder=PositionalEncoder(no_temporal=getattr(args, "no_temporal", True)))
     core.compute_dtype = _DTYPES[getattr(args, "compute_dtype", "bf16")]
     core.skip_dead_frames = bool(getattr(args, "skip_dead_frames", True))
     model = SpatioTemporalDETR(args=detr_args, model=core)

@@ -500,6 +500,11 @@ def core_forward(sd, cfg, images, imu=None, temporal_offsets=None, skip_dead=Fal
         keep = min(cfg.num_images, images.shape[1])
         images = images[:, -keep:]
         imu = imu[:, -keep:] if imu is not None else None
+        # the temporal term is normalised by the LAST frame's offset (paper.py:72), so trimming from the front is
+        # exact when offsets are given (with frame indices instead -- offsets None -- it would not be)
+        assert cfg.no_temporal or temporal_offsets is not None, "skip_dead needs explicit temporal offsets"
+        if temporal_offsets is not None:
+            temporal_offsets = temporal_offsets[:, -keep:]
     feat, _ego = separate_encoder(sd, cfg, images, imu, taps)
     B, L, D, h, w = feat.shape
     pos = spatial_pos_table(h, w, D, feat.device)[None, None].expand(B, L, -1, -1, -1)

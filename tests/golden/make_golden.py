@@ -58,7 +58,7 @@ def build_reference(cfg: Config, paper, transformer, st_detr):
         num_classes=cfg.num_classes, num_queries=cfg.num_queries, lr_backbone=1e-4,
         enc_layers=cfg.enc_layers, dec_layers=cfg.dec_layers, dim_feedforward=cfg.dim_feedforward,
         hidden_dim=cfg.hidden_dim, enc_nheads=cfg.nheads, nheads=cfg.nheads,
-        pretrained_backbone=False)
+        pretrained_backbone=False, encode_offset=not cfg.no_temporal)
     enc = transformer.TransformerEncoder(layers=nn.ModuleList(
         transformer.TransformerEncoderLayer(D=cfg.hidden_dim, Nhead=cfg.nheads, Dff=cfg.dim_feedforward,
                                             use_egodeep=cfg.use_imu)
@@ -96,7 +96,12 @@ def load_weights(model, cfg, seed):
     return sd
 
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]     # fixture names to (re)generate; default: all
+
+
 def save(name, **arrays):
+    if ONLY and name not in ONLY:
+        return
     out = {}
     for k, v in arrays.items():
         if isinstance(v, torch.Tensor):
@@ -155,8 +160,16 @@ def main():
         "g5_r50_2x2": (Config(backbone="resnet50", enc_layers=2, dec_layers=2), 2, 4, 96, 160, 12),
         "g5_r18_k3_noimu": (Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=3,
                                    use_imu=False), 2, 5, 64, 96, 13),
+        # one memory of all past frames + temporal encoding; temporal encoding alone
+        "g11_all_at_once_temporal": (Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=1,
+                                            image_memory_mode="attend all at once", no_temporal=False),
+                                     2, 4, 64, 96, 14),
+        "g12_one_at_a_time_temporal": (Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2,
+                                              no_temporal=False), 2, 4, 64, 96, 15),
     }
     for name, (cfg, B, L, H, W, seed) in cases.items():
+        if ONLY and name not in ONLY:
+            continue
         model = build_reference(cfg, paper, transformer, st_detr)
         sd = load_weights(model, cfg, seed)
         data = make_batch(B, L, H, W, seed=seed, device="cpu", max_boxes=12)
@@ -172,6 +185,8 @@ def main():
             kw = {}
             if cfg.use_imu:
                 kw["imu"] = torch.cat([data[k] for k in model._imu_keys], dim=2)
+            if not cfg.no_temporal:                       # as st_detr.py:115-118 does with encode_offset
+                kw["temporal_offsets"] = data["temporal_offsets"]
             core_out, _ = model._model(data["video"], **kw)
             # dead-work equivalence (G10): feed only the last K past frames (+ future frame)
             keep = min(cfg.num_images, L - 1)

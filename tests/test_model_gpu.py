@@ -30,7 +30,8 @@ def build_product(cfg: Config, dtype, seed):
     args = SpatioTemporalDETRArgs(num_classes=cfg.num_classes, num_queries=cfg.num_queries, lr_backbone=1e-4,
                                   enc_layers=cfg.enc_layers, dec_layers=cfg.dec_layers,
                                   dim_feedforward=cfg.dim_feedforward, hidden_dim=cfg.hidden_dim,
-                                  enc_nheads=cfg.nheads, nheads=cfg.nheads, pretrained_backbone=False)
+                                  enc_nheads=cfg.nheads, nheads=cfg.nheads, pretrained_backbone=False,
+                                  encode_offset=not cfg.no_temporal)
     core = FuturePredCore(
         separate_encoder=SeparateEncoder(
             backbone=CDetrBackbone(cfg.backbone, True, False, cfg.hidden_dim, pretrained=False),
@@ -46,8 +47,9 @@ def build_product(cfg: Config, dtype, seed):
                  for _ in range(cfg.dec_layers)]), norm=nn.LayerNorm(cfg.hidden_dim), return_intermediate=True,
                 D=cfg.hidden_dim),
             num_classes=cfg.num_classes, hidden_dim=cfg.hidden_dim,
-            first_layer_special_when=cfg.first_layer_special_when, num_queries=cfg.num_queries, aux_loss=True),
-        pos_encoder=PositionalEncoder(no_temporal=True))
+            first_layer_special_when=cfg.first_layer_special_when, num_queries=cfg.num_queries, aux_loss=True,
+            image_memory_mode=cfg.image_memory_mode),
+        pos_encoder=PositionalEncoder(no_temporal=cfg.no_temporal))
     core.compute_dtype = dtype
     model = SpatioTemporalDETR(args, core)
     sd = O.make_state_dict(cfg, seed)
@@ -61,6 +63,11 @@ CASES = {
     "g5_cfg1_r18": Config(backbone="resnet18", enc_layers=1, dec_layers=1),
     "g5_r50_2x2": Config(backbone="resnet50", enc_layers=2, dec_layers=2),
     "g5_r18_k3_noimu": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=3, use_imu=False),
+    # SURVEY 8(f)-2 variants the reference's paper.py holds but its runs/ never build
+    "g11_all_at_once_temporal": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=1,
+                                       image_memory_mode="attend all at once", no_temporal=False),
+    "g12_one_at_a_time_temporal": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2,
+                                         no_temporal=False),
 }
 
 
@@ -91,6 +98,8 @@ def test_fp32_parity_with_oracle_and_golden(golden, name):
         kw = {}
         if cfg.use_imu:
             kw["imu"] = torch.cat([data[k] for k in model._imu_keys], dim=2)
+        if not cfg.no_temporal:
+            kw["temporal_offsets"] = data["temporal_offsets"]
         raw, _ = model._model(data["video"], **kw)
     rel_close(raw["pred_logits"], g["pred_logits"], 1e-3, "pred_logits vs golden")
     rel_close(raw["pred_boxes"], g["pred_boxes"], 1e-3, "pred_boxes vs golden")

@@ -67,6 +67,11 @@ CASES = {
     "g5_cfg1_r18": Config(backbone="resnet18", enc_layers=1, dec_layers=1),
     "g5_r50_2x2": Config(backbone="resnet50", enc_layers=2, dec_layers=2),
     "g5_r18_k3_noimu": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=3, use_imu=False),
+    # SURVEY 8(f)-2 variants (paper.py:66-73 temporal encoding, :334-339 one memory of all past frames)
+    "g11_all_at_once_temporal": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=1,
+                                       image_memory_mode="attend all at once", no_temporal=False),
+    "g12_one_at_a_time_temporal": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2,
+                                         no_temporal=False),
 }
 
 
@@ -82,7 +87,8 @@ def test_g5_full_model_loss_and_grads(golden, name):
             sd[k].requires_grad_(True)
     data = make_batch(B, L, H, W, seed=seed, max_boxes=12)
     imu = O.imu_from_data(data) if cfg.use_imu else None
-    out = O.core_forward(sd, cfg, data["video"], imu)
+    offs = None if cfg.no_temporal else data["temporal_offsets"]          # st_detr.py passes them with encode_offset
+    out = O.core_forward(sd, cfg, data["video"], imu, offs)
     close(out["pred_logits"], g["pred_logits"])
     close(out["pred_boxes"], g["pred_boxes"])
     for i, aux in enumerate(out["aux_outputs"]):
@@ -105,10 +111,14 @@ def test_g5_full_model_loss_and_grads(golden, name):
         if k.startswith("gidx:"):
             n = k[5:]
             close(sd[n].grad.reshape(-1)[g[k]], g["gval:" + n], atol=1e-5, rtol=2e-4)
-    # G10: dead-work equivalence -- both in the reference (fixture) and in the oracle
+    # G10: dead-work equivalence -- both in the reference (fixture) and in the oracle.  With one memory of all past
+    # frames nothing is dead (the fixture's truncated run then differs, as it must).
+    if cfg.image_memory_mode == "attend all at once":
+        assert float(np.abs(g["dead_pred_logits"] - g["pred_logits"]).max()) > 1e-3
+        return
     close(g["dead_pred_logits"], g["pred_logits"])   # different frame count => different conv blocking => fp32 rounding only
     with torch.no_grad():
-        out2 = O.core_forward(sd, cfg, data["video"], imu, skip_dead=True)
+        out2 = O.core_forward(sd, cfg, data["video"], imu, offs, skip_dead=True)
     close(out2["pred_logits"], g["pred_logits"]); close(out2["pred_boxes"], g["pred_boxes"])
 
 
