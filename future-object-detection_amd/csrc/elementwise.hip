@@ -249,6 +249,40 @@ __global__ void permute3_kernel(const TS* __restrict__ src, TD* __restrict__ dst
   }
 }
 
+// Many permute3 jobs in one launch (the per-step refresh of every prepared weight copy: ~75 small launches
+// otherwise).  Block b works on chunk blk_chunk[b] (MP_CHUNK elements) of job blk_job[b].
+constexpr int MP_CHUNK = 8192;
+
+template <typename TS, typename TD>
+FOD_DEVINL void multi_permute_body(const fod_permute_job& j, long first) {
+  const TS* __restrict__ src = reinterpret_cast<const TS*>(j.src);
+  TD* __restrict__ dst = reinterpret_cast<TD*>(j.dst);
+  const long n = (long)j.d0 * j.d1 * j.d2;
+  const long last = min(n, first + MP_CHUNK);
+  for (long i = first + threadIdx.x; i < last; i += blockDim.x) {
+    const int i2 = (int)(i % j.d2);
+    const long t = i / j.d2;
+    const int i1 = (int)(t % j.d1);
+    const int i0 = (int)(t / j.d1);
+    float v = 0.f;
+    if (i1 < j.valid1 && i2 < j.valid2) {
+      v = to_f32(src[i0 * j.s0 + i1 * j.s1 + i2 * j.s2]);
+      if (j.scale) v *= j.scale[j.scale_axis == 0 ? i0 : (j.scale_axis == 1 ? i1 : i2)];
+    }
+    dst[i0 * j.t0 + i1 * j.t1 + i2] = from_f32<TD>(v);
+  }
+}
+
+__global__ void multi_permute3_kernel(const fod_permute_job* __restrict__ jobs, const int* __restrict__ blk_job,
+                                      const int* __restrict__ blk_chunk) {
+  const fod_permute_job j = jobs[blk_job[blockIdx.x]];
+  const long first = (long)blk_chunk[blockIdx.x] * MP_CHUNK;
+  if (j.src_dtype == FOD_F32 && j.dst_dtype == FOD_BF16) multi_permute_body<float, __bf16>(j, first);
+  else if (j.src_dtype == FOD_F32) multi_permute_body<float, float>(j, first);
+  else if (j.dst_dtype == FOD_BF16) multi_permute_body<__bf16, __bf16>(j, first);
+  else multi_permute_body<__bf16, float>(j, first);
+}
+
 template <typename T>
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int F, int C, int H, int W,
                                     int Cp, int inner, long stride_outer, long stride_inner) {
@@ -602,6 +636,16 @@ extern "C" int fod_permute3_cast(int src_dtype, int dst_dtype, const void* src, 
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }
+
+extern "C" int fod_multi_permute3(const fod_permute_job* jobs, const int* blk_job, const int* blk_chunk, int nblocks,
+                                  hipStream_t stream) {
+  FOD_REQUIRE(jobs && blk_job && blk_chunk && nblocks > 0, "multi_permute3: bad args");
+  hipLaunchKernelGGL(multi_permute3_kernel, dim3(nblocks), dim3(256), 0, stream, jobs, blk_job, blk_chunk);
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
+}
+
+extern "C" int fod_multi_permute_chunk(void) { return MP_CHUNK; }
 
 extern "C" int fod_nchw_to_nhwc(int dtype, const float* src, void* dst, int F, int C, int H, int W, int Cp,
                                 int inner, long stride_outer, long stride_inner, hipStream_t stream) {

@@ -137,8 +137,12 @@ class _PaddedInLinear(torch.autograd.Function):
     def forward(ctx, x, weight, bias, I, relu):
         N = weight.shape[0]
         Ip = x.shape[-1]
-        wp = Fn.PREP.get(weight, f"lin_pad{Ip}", x.dtype, lambda: ops.permute3_cast(
-            weight.detach(), x.dtype, (1, N, Ip), (0, I, 1), valid2=I).view(N, Ip))
+        wd = weight.detach()
+
+        def build():
+            out = torch.empty((N, Ip), dtype=x.dtype, device=wd.device)          # columns >= I zero
+            return out, [Fn._Job(wd, out, (1, N, Ip), (0, wd.stride(0), wd.stride(1)), valid2=I)]
+        wp = Fn.PREP.get(Fn._wkey(weight, f"lin_pad{Ip}", x.dtype), [weight], build)
         y = ops.gemm_nt(x, wp, shift=bias, relu=relu)
         ctx.save_for_backward(x, y)
         ctx.meta = (I, relu, N, Ip)

@@ -16,24 +16,92 @@ _VEC = {torch.float32: 4, torch.bfloat16: 8}
 
 
 # ------------------------------------------------------------------------------------------------
-# prepared-weight cache
+# prepared-weight registry
+#
+# Every kernel operand derived from a parameter (compute-dtype copy, transposed copy for input gradients, BN
+# scale folded in, several Linear layers stacked) is declared ONCE as a list of strided-copy jobs into persistent
+# buffers.  After an optimizer step (parameter `_version` bumped) the first request for any of them refreshes ALL
+# stale ones with a single `fod_multi_permute3` launch (one job table on the device, cached while the set is the
+# same) instead of ~75 small launches scattered over the next forward.
 # ------------------------------------------------------------------------------------------------
+class _Job:
+    __slots__ = ("src", "dst", "dims", "sstr", "dstr", "valid1", "valid2", "scale", "axis")
+
+    def __init__(self, src, dst, dims, sstr, dstr=None, valid1=None, valid2=None, scale=None, axis=-1):
+        d0, d1, d2 = dims
+        self.src, self.dst, self.dims, self.sstr = src, dst, dims, sstr
+        self.dstr = dstr if dstr is not None else (d1 * d2, d2)
+        self.valid1 = d1 if valid1 is None else valid1
+        self.valid2 = d2 if valid2 is None else valid2
+        self.scale, self.axis = scale, axis
+
+
+class _Entry:
+    __slots__ = ("params", "vers", "jobs", "value")
+
+
 class _Prepared:
     def __init__(self):
         self._store = {}
+        self._tables = {}
+        self._chunk = None
 
-    def get(self, p, kind, dtype, make):
-        key = (p.data_ptr(), tuple(p.shape), tuple(p.stride()), kind, dtype)
-        ver = p._version
-        hit = self._store.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1]
-        val = make()
-        self._store[key] = (ver, val)
-        return val
+    def get(self, key, params, build):
+        """`build()` -> (value, jobs): allocates the persistent buffers and declares how they are filled."""
+        e = self._store.get(key)
+        if e is None:
+            e = _Entry()
+            e.params = [p for p in params if p is not None]
+            e.value, e.jobs = build()
+            e.vers = None
+            if len(self._store) > 4096:
+                self.clear()
+            self._store[key] = e
+        if e.vers != tuple(p._version for p in e.params):
+            self.refresh()
+        return e.value
+
+    def refresh(self):
+        stale = [e for e in self._store.values() if e.vers != tuple(p._version for p in e.params)]
+        if not stale:
+            return
+        key = tuple(id(e) for e in stale)
+        tab = self._tables.get(key)
+        if tab is None:
+            tab = self._build_tables([j for e in stale for j in e.jobs])
+            if len(self._tables) > 16:
+                self._tables.clear()
+            self._tables[key] = tab
+        jobs_dev, blk_job, blk_chunk, nblocks, _keep = tab
+        L.call("fod_multi_permute3", ops.ptr(jobs_dev), ops.ptr(blk_job), ops.ptr(blk_chunk), nblocks, ops.stream())
+        for e in stale:
+            e.vers = tuple(p._version for p in e.params)
+
+    def _build_tables(self, jobs):
+        import ctypes as C
+        import numpy as np
+        if self._chunk is None:
+            self._chunk = int(L.LIB.fod_multi_permute_chunk())
+        arr = (L.PermuteJob * len(jobs))()
+        bj, bc = [], []
+        for i, j in enumerate(jobs):
+            d0, d1, d2 = j.dims
+            arr[i] = L.PermuteJob(j.src.data_ptr(), j.dst.data_ptr(), 0 if j.scale is None else j.scale.data_ptr(),
+                                  ops._DT[j.src.dtype], ops._DT[j.dst.dtype], d0, d1, d2, j.valid1, j.valid2, j.axis,
+                                  j.sstr[0], j.sstr[1], j.sstr[2], j.dstr[0], j.dstr[1])
+            n = d0 * d1 * d2
+            for c in range((n + self._chunk - 1) // self._chunk):
+                bj.append(i)
+                bc.append(c)
+        dev = jobs[0].dst.device
+        raw = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
+        up = lambda t: (t.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else t.to(dev))
+        return (up(raw), up(torch.tensor(bj, dtype=torch.int32)), up(torch.tensor(bc, dtype=torch.int32)), len(bj),
+                [(j.src, j.dst, j.scale) for j in jobs])       # keep the operands alive while the table exists
 
     def clear(self):
         self._store.clear()
+        self._tables.clear()
 
 
 PREP = _Prepared()
@@ -98,6 +166,10 @@ def _pad_to(n, v):
     return (n + v - 1) // v * v
 
 
+def _wkey(p, kind, dtype, extra=()):
+    return (p.data_ptr(), tuple(p.shape), tuple(p.stride()), kind, dtype) + tuple(extra)
+
+
 def prep_linear(weight, dtype, transposed):
     """weight [N,K] f32 -> [Np,K] (rows zero-padded to the vector width) or its transpose [K,Np]."""
     N, K = weight.shape
@@ -105,18 +177,16 @@ def prep_linear(weight, dtype, transposed):
     assert K % v == 0, f"Linear in_features {K} must be a multiple of {v} (pad the input)"
     Np = _pad_to(N, v)
     w = weight.detach()
+    sn, sk = w.stride()
 
-    def make():
-        if not transposed:   # dst[1][n][k]
-            if Np == N:
-                return ops.permute3_cast(w, dtype, (1, N, K), (0, K, 1)).view(N, K)
-            out = torch.zeros((Np, K), dtype=dtype, device=w.device)
-            out[:N] = ops.permute3_cast(w, dtype, (1, N, K), (0, K, 1)).view(N, K)
-            return out
-        # dst[1][k][n] = w[n][k], columns n >= N zero
-        return ops.permute3_cast(w, dtype, (1, K, Np), (0, 1, K), valid2=N).view(K, Np)
+    def build():
+        if not transposed:   # dst[1][n][k], rows n >= N zero
+            out = torch.empty((Np, K), dtype=dtype, device=w.device)
+            return out, [_Job(w, out, (1, Np, K), (0, sn, sk), valid1=N)]
+        out = torch.empty((K, Np), dtype=dtype, device=w.device)      # dst[1][k][n] = w[n][k], columns n >= N zero
+        return out, [_Job(w, out, (1, K, Np), (0, sk, sn), valid2=N)]
 
-    return PREP.get(weight, "lin_t" if transposed else "lin", dtype, make)
+    return PREP.get(_wkey(weight, "lin_t" if transposed else "lin", dtype), [weight], build)
 
 
 def prep_conv(weight, dtype, scale, transposed, cin_pad=None):
@@ -127,15 +197,17 @@ def prep_conv(weight, dtype, scale, transposed, cin_pad=None):
     cp = ci if cin_pad is None else cin_pad
     w = weight.detach()
 
-    def make():
+    def build():
         if not transposed:
-            return ops.permute3_cast(w, dtype, (co, kh * kw, cp), (s_co, s_kw, s_ci), valid2=ci,
-                                     scale=scale, scale_axis=0 if scale is not None else -1)
-        return ops.permute3_cast(w, dtype, (ci, kh * kw, co), (s_ci, s_kw, s_co),
-                                 scale=scale, scale_axis=2 if scale is not None else -1)
+            out = torch.empty((co, kh * kw, cp), dtype=dtype, device=w.device)
+            return out, [_Job(w, out, (co, kh * kw, cp), (s_co, s_kw, s_ci), valid2=ci, scale=scale,
+                              axis=0 if scale is not None else -1)]
+        out = torch.empty((ci, kh * kw, co), dtype=dtype, device=w.device)
+        return out, [_Job(w, out, (ci, kh * kw, co), (s_ci, s_kw, s_co), scale=scale,
+                          axis=2 if scale is not None else -1)]
 
     tag = ("conv_t" if transposed else "conv") + ("_s" if scale is not None else "")
-    return PREP.get(weight, tag, dtype, make)
+    return PREP.get(_wkey(weight, tag, dtype, (cp, 0 if scale is None else scale.data_ptr())), [weight], build)
 
 
 def cast(t, dtype, pad_cols=None):
@@ -506,28 +578,30 @@ def cast_ad(x, dtype, pad_cols=None):
 # the attention kernels' stride arguments.
 # ------------------------------------------------------------------------------------------------
 class _CatCache:
-    def __init__(self):
-        self.store = {}
+    """P same-shaped Linear layers stacked: (wcat [P*D_out, D_in], bcat f32 [P*D_out], wcat_t [D_in, P*D_out])."""
 
     def get(self, weights, biases, dtype):
-        key = (tuple(w.data_ptr() for w in weights), dtype)
-        ver = tuple(w._version for w in weights) + tuple(b._version for b in biases)
-        hit = self.store.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1]
         D_out, D_in = weights[0].shape
         P = len(weights)
-        wcat = torch.empty((P * D_out, D_in), dtype=dtype, device=weights[0].device)
-        bcat = torch.empty((P * D_out,), dtype=torch.float32, device=weights[0].device)
-        for i, (w, b) in enumerate(zip(weights, biases)):
-            ops.permute3_cast(w.detach(), dtype, (1, D_out, D_in), (0, D_in, 1), out=wcat[i * D_out:(i + 1) * D_out])
-            ops.permute3_cast(b.detach(), torch.float32, (1, 1, D_out), (0, 0, 1), out=bcat[i * D_out:(i + 1) * D_out])
-        wcat_t = ops.permute3_cast(wcat, dtype, (1, D_in, P * D_out), (0, 1, D_in)).view(D_in, P * D_out)
-        val = (wcat, bcat, wcat_t)
-        if len(self.store) > 64:
-            self.store.clear()
-        self.store[key] = (ver, val)
-        return val
+
+        def build():
+            dev = weights[0].device
+            wcat = torch.empty((P * D_out, D_in), dtype=dtype, device=dev)
+            bcat = torch.empty((P * D_out,), dtype=torch.float32, device=dev)
+            wcat_t = torch.empty((D_in, P * D_out), dtype=dtype, device=dev)
+            jobs = []
+            for i, (w, b) in enumerate(zip(weights, biases)):
+                wd, bd = w.detach(), b.detach()
+                sn, sk = wd.stride()
+                jobs.append(_Job(wd, wcat[i * D_out:(i + 1) * D_out], (1, D_out, D_in), (0, sn, sk)))
+                jobs.append(_Job(bd, bcat[i * D_out:(i + 1) * D_out], (1, 1, D_out), (0, 0, bd.stride(0))))
+                # column block i of the transposed stack: dst[k][i*D_out + n] = w[n][k]
+                jobs.append(_Job(wd, wcat_t[:, i * D_out:(i + 1) * D_out], (1, D_in, D_out), (0, sk, sn),
+                                 dstr=(0, P * D_out)))
+            return (wcat, bcat, wcat_t), jobs
+
+        key = (tuple(w.data_ptr() for w in weights), dtype, "cat")
+        return PREP.get(key, list(weights) + list(biases), build)
 
 
 CAT = _CatCache()

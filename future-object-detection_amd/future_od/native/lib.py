@@ -41,6 +41,15 @@ class AttnShape(C.Structure):
                 ("dk2_batch_stride", C.c_long), ("dk2_token_stride", C.c_long)]
 
 
+class PermuteJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("scale", C.c_void_p),
+                ("src_dtype", C.c_int), ("dst_dtype", C.c_int),
+                ("d0", C.c_int), ("d1", C.c_int), ("d2", C.c_int),
+                ("valid1", C.c_int), ("valid2", C.c_int), ("scale_axis", C.c_int),
+                ("s0", C.c_long), ("s1", C.c_long), ("s2", C.c_long),
+                ("t0", C.c_long), ("t1", C.c_long)]
+
+
 _i, _l, _f, _p = C.c_int, C.c_long, C.c_float, C.c_void_p
 _EP, _CG, _AS = C.POINTER(Epilogue), C.POINTER(ConvGeom), C.POINTER(AttnShape)
 
@@ -55,6 +64,8 @@ SIGNATURES = {
     "fod_conv2d_dgrad": [_i, _p, _p, _p, _CG, _EP, _p],
     "fod_conv2d_wgrad_acc": [_i, _p, _p, _p, _CG, _p, _i, _p],
     "fod_maxpool3x3s2": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "fod_multi_permute3": [_p, _p, _p, _i, _p],
+    "fod_multi_permute_chunk": [],
     "fod_nchw_to_nhwc": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _p],
     "fod_u8_nchw_to_nhwc": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _p, _p, _p],
     "fod_permute3_cast": [_i, _i, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _i, _p],

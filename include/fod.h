@@ -92,6 +92,24 @@ int fod_gemm_tn_grouped(int dtype, const void* G, long ldg, int g_seg_cols, long
 int fod_colsum_acc(int dtype, const void* G, long ldg, int M, int N, int group_rows, float* out,
                    fod_stream_t stream);
 
+/* Many fod_permute3_cast jobs in one launch: dst[i0*t0 + i1*t1 + i2] = src[i0*s0 + i1*s1 + i2*s2] * scale[...]
+ * for i1 < valid1 and i2 < valid2, else 0.  `jobs` is a DEVICE array; block b handles chunk blk_chunk[b]
+ * (fod_multi_permute_chunk() elements) of job blk_job[b].  The per-step refresh of the compute-dtype / transposed /
+ * BN-folded weight copies after the optimizer step (the reference re-reads fp32 weights in every op). */
+typedef struct fod_permute_job {
+  const void* src;
+  void* dst;
+  const float* scale;
+  int src_dtype, dst_dtype;
+  int d0, d1, d2;
+  int valid1, valid2, scale_axis;
+  long s0, s1, s2;
+  long t0, t1;
+} fod_permute_job;
+int fod_multi_permute3(const fod_permute_job* jobs, const int* blk_job, const int* blk_chunk, int nblocks,
+                       fod_stream_t stream);
+int fod_multi_permute_chunk(void);
+
 typedef struct fod_conv_geom {
   int Nimg, H, W, Cin;   /* input  NHWC */
   int Ho, Wo, Cout;      /* output NHWC */
