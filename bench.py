@@ -123,7 +123,7 @@ def main():
     from future_od.optim import FusedAdamW
 
     model, detr = build(a, device, distributed, a.num_images, a.dtype)
-    model.train()
+    model.eval()     # forward + backward in model.eval() with autograd on (dropout off, FrozenBN)
     opt = FusedAdamW(model.parameters(), lr=detr.lr, weight_decay=detr.weight_decay, max_norm=detr.max_norm)
     data = make_batch(BATCH_PER_GPU, T_FRAMES, HEIGHT, WIDTH, seed=1234 + rank, device=device)
 

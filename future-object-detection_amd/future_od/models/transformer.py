@@ -106,6 +106,7 @@ class EgodeepAttention(nn.Module):
         self.value = nn.Linear(D, D)
         self.fun = OutProj(D)
         self.use_mlp = Dff is not None
+        self.droprate = droprate
         if self.use_mlp:
             self.norm1 = nn.LayerNorm(D)
             self.mlp = nn.Sequential(nn.Linear(D, Dff), nn.ReLU(inplace=True), nn.Dropout(droprate),
@@ -119,9 +120,12 @@ class EgodeepAttention(nn.Module):
         """ego [frames, D] -> [frames, D]."""
         out = _lin(_lin(ego, self.value), self.fun.out_proj)
         if self.use_mlp:
-            out = Fn.layer_norm(out, self.norm1.weight, self.norm1.bias, residual=out)   # norm1(out + out)
-            h = _lin(out, self.mlp[0], relu=True)
-            out = Fn.layer_norm(out, self.norm2.weight, self.norm2.bias, residual=_lin(h, self.mlp[3]))
+            # train mode: the reference drops per token; on the collapsed rows the masks are per frame
+            t, p = self.training, self.droprate
+            out = Fn.layer_norm(out, self.norm1.weight, self.norm1.bias, residual=Fn.dropout(out, p, t))   # norm1(out + drop(out))
+            h = Fn.dropout(_lin(out, self.mlp[0], relu=True), p, t)
+            out = Fn.layer_norm(out, self.norm2.weight, self.norm2.bias,
+                                residual=Fn.dropout(_lin(h, self.mlp[3]), p, t))
         return out
 
 
@@ -191,19 +195,22 @@ class TransformerDecoderLayer(nn.Module):
                                          nn.Linear(Dff, D))
         self.norm_out = nn.LayerNorm(D)
         self.Nhead, self.D = Nhead, D
+        self.droprate = dropout            # dropout_sa / dropout_ia / dropout_out and the feed-forward's (reference :201-234)
 
     def forward(self, x, qpos, query_sine, side, layer, is_first=False, pos_proj=None):
         """`pos_proj` (from TransformerDecoder): {"sa": (query_pos(qpos), key_pos(qpos)), "ca": [query_pos_i(qpos)]}."""
+        t, p = self.training, self.droprate
         o = self.self_attend(x, qpos, pos_proj["sa"] if pos_proj else None)
-        x = Fn.layer_norm(x, self.norm_sa.weight, self.norm_sa.bias, residual=o)
+        x = Fn.layer_norm(x, self.norm_sa.weight, self.norm_sa.bias, residual=Fn.dropout(o, p, t))
         # the sine embedding is the same for every image of the layer: all their query_sine projections at once
         qs_all = Fn.group_linear(query_sine, [self.image_attend[i].query_sine for i in range(side.K)])
         for i in range(side.K):
             o = self.image_attend[i](x, qpos, query_sine, side, layer, i, is_first, qs=qs_all[i],
                                      qpos_proj=pos_proj["ca"][i] if (pos_proj and is_first) else None)
-            x = Fn.layer_norm(x, self.norm_ia[i].weight, self.norm_ia[i].bias, residual=o)
-        h = _lin(x, self.feedforward[0], relu=True)
-        return Fn.layer_norm(x, self.norm_out.weight, self.norm_out.bias, residual=_lin(h, self.feedforward[3]))
+            x = Fn.layer_norm(x, self.norm_ia[i].weight, self.norm_ia[i].bias, residual=Fn.dropout(o, p, t))
+        h = Fn.dropout(_lin(x, self.feedforward[0], relu=True), p, t)
+        return Fn.layer_norm(x, self.norm_out.weight, self.norm_out.bias,
+                             residual=Fn.dropout(_lin(h, self.feedforward[3]), p, t))
 
 
 class TransformerDecoder(nn.Module):
@@ -282,6 +289,7 @@ class EncoderAttention(nn.Module):
                                  nn.Linear(Dff, Dsrc), nn.Dropout(droprate))
         self.norm2 = nn.LayerNorm(Dsrc)
         self.D, self.H = Dsrc, num_heads
+        self.droprate = droprate
 
     def forward(self, src, pos):
         """src [F,N,D]; pos table [N,D].  q = k = src + pos, v = src."""
@@ -290,9 +298,11 @@ class EncoderAttention(nn.Module):
         xp = Fn.add(src, pos, b_row_mod=N)
         q, k, v = Fn.in_proj(xp, src, self.attn.in_proj_weight, self.attn.in_proj_bias)
         a = Fn.attention(q, k, v, 1.0 / math.sqrt(D // self.H))
-        src = Fn.layer_norm(src, self.norm1.weight, self.norm1.bias, residual=_lin(a, self.attn.out_proj))
-        h = _lin(src, self.mlp[0], relu=True)
-        return Fn.layer_norm(src, self.norm2.weight, self.norm2.bias, residual=_lin(h, self.mlp[3]))
+        t, p = self.training, self.droprate
+        src = Fn.layer_norm(src, self.norm1.weight, self.norm1.bias,
+                            residual=Fn.dropout(_lin(a, self.attn.out_proj), p, t))
+        h = Fn.dropout(_lin(src, self.mlp[0], relu=True), p, t)
+        return Fn.layer_norm(src, self.norm2.weight, self.norm2.bias, residual=Fn.dropout(_lin(h, self.mlp[3]), p, t))
 
 
 class TransformerEncoderLayer(nn.Module):
@@ -316,6 +326,7 @@ class TransformerEncoderLayer(nn.Module):
         if egodeep is not None and self.egodeep_attend is not None:
             N = x.shape[1]
             e = self.egodeep_attend.forward_single_key(egodeep)
+            e = Fn.dropout(e, self.egodeep_attend.droprate, self.training)          # dropout_eda (reference :444,485)
             x = Fn.layer_norm(x, self.norm_eda.weight, self.norm_eda.bias, residual=e, res_row_div=N)
             if torch.is_grad_enabled():
                 x = Fn.ZeroGradAnchor.apply(x, *self.egodeep_attend.dead_parameters())

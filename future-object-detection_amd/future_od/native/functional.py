@@ -392,6 +392,46 @@ def layer_norm(x, gamma, beta, residual=None, res_row_div=0):
                              res_row_div)
 
 
+# ------------------------------------------------------------------------------------------------
+# Dropout (train mode only; eval and p = 0 never reach these).  No mask tensor: the kernel hashes (seed, index),
+# and the backward is the same call on the gradient.  Seeds advance with every call; data-parallel ranks are offset.
+class _DropSeeds:
+    def __init__(self):
+        self.count = 0
+
+    def next(self):
+        self.count += 1
+        rank = 0
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                rank = dist.get_rank()
+        except Exception:
+            rank = 0
+        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + (rank << 40) + self.count) & 0xFFFFFFFFFFFFFFFF
+
+
+DROP_SEEDS = _DropSeeds()
+
+
+class DropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return ops.dropout(x, p, seed)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.dropout(g.contiguous(), ctx.p, ctx.seed), None, None
+
+
+def dropout(x, p, training):
+    """nn.Dropout(p)(x) semantics: identity unless `training` and p > 0."""
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x.contiguous(), float(p), DROP_SEEDS.next())
+
+
 class AttentionFn(Function):
     @staticmethod
     def forward(ctx, q1, k1, v, q2, k2, scale):

@@ -64,6 +64,7 @@ SIGNATURES = {
     "fod_conv2d_dgrad": [_i, _p, _p, _p, _CG, _EP, _p],
     "fod_conv2d_wgrad_acc": [_i, _p, _p, _p, _CG, _p, _i, _p],
     "fod_maxpool3x3s2": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "fod_dropout": [_i, _p, _p, _l, C.c_ulonglong, _f, _p],
     "fod_multi_permute3": [_p, _p, _p, _i, _p],
     "fod_multi_permute_chunk": [],
     "fod_nchw_to_nhwc": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _p],

@@ -420,6 +420,14 @@ def add(a, b, **kw):
     return eltwise(L.EW_ADD, a, b, **kw)
 
 
+def dropout(a, p, seed):
+    """a * mask / (1 - p) with the stateless mask of call `seed` (the same call on a gradient is the backward)."""
+    _chk(a, "a")
+    out = torch.empty_like(a)
+    call("fod_dropout", dt(a), ptr(out), ptr(a), a.numel(), C.c_ulonglong(seed & 0xFFFFFFFFFFFFFFFF), float(p), stream())
+    return out
+
+
 def posenc_table(h, w, c, dtype, device, temperature=10000.0):
     out = torch.empty((h * w, c), dtype=dtype, device=device)
     call("fod_posenc_table", _DT[dtype], ptr(out), h, w, c, temperature, stream())

@@ -202,6 +202,11 @@ enum {
 int fod_eltwise(int op, int dtype, void* out, const void* a, const void* b, const void* c, long rows,
                 int cols, int b_row_div, int b_row_mod, float alpha, fod_stream_t stream);
 
+/* out[i] = keep(i) ? a[i] / (1 - p) : 0 with keep(i) a stateless hash of (seed, i): the backward pass applies the
+ * same call (same seed) to the incoming gradient, no mask is stored.  nn.Dropout on the sub-layer outputs and inside
+ * the feed-forward blocks in train mode (future_od/models/transformer.py:95-102,201-234,405-417). */
+int fod_dropout(int dtype, void* out, const void* a, long n, unsigned long long seed, float p, fod_stream_t stream);
+
 /* DETR sine table for an h x w map as a token-major [h*w, C] tensor: first C/2 channels encode y,
  * last C/2 encode x (future_od/models/paper.py:57-64,75-80). */
 int fod_posenc_table(int dtype, void* out, int h, int w, int C, float temperature, fod_stream_t stream);

@@ -172,3 +172,28 @@ def test_group_linear_function_matches_separate_linears():
         assert torch.allclose(a[2][i], b[2][i], rtol=3e-2, atol=1e-5), i
         assert torch.allclose(a[3][i], b[3][i], rtol=3e-2, atol=1e-5), i
     assert float(a[2][P - 1].abs().max()) == 0.0 and b[2][P - 1] is None
+
+
+def test_dropout_is_stateless_and_self_consistent():
+    """fod_dropout keeps each element with probability 1 - p, scales by 1 / (1 - p), depends only on (seed, index),
+    and DropoutFn's backward applies the forward's mask to the gradient."""
+    from future_od.native import functional as Fn
+    for dtype in (torch.float32, torch.bfloat16):
+        x = torch.ones(512, 1024, device=DEV, dtype=dtype)
+        y1 = ops.dropout(x, 0.1, 1234)
+        y2 = ops.dropout(x, 0.1, 1234)
+        y3 = ops.dropout(x, 0.1, 1235)
+        assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+        kept = (y1 != 0).float().mean().item()
+        assert abs(kept - 0.9) < 3e-3, kept
+        vals = y1[y1 != 0].float()
+        assert torch.allclose(vals, torch.full_like(vals, 1 / 0.9), rtol=1e-2)
+        # rows / columns are not systematically favoured
+        assert (y1 != 0).float().mean(0).std().item() < 0.03 and (y1 != 0).float().mean(1).std().item() < 0.03
+    x = torch.randn(64, 256, device=DEV, requires_grad=True)
+    seed = Fn.DROP_SEEDS.next()
+    y = Fn.DropoutFn.apply(x, 0.25, seed)
+    y.backward(torch.ones_like(y))
+    mask = (y.detach() != 0).float() / 0.75
+    assert torch.allclose(x.grad, mask, rtol=1e-6, atol=0) and torch.allclose(y.detach(), x.detach() * mask, rtol=1e-6)
+    assert Fn.dropout(x, 0.25, training=False) is x and Fn.dropout(x, 0.0, training=True) is x

@@ -173,6 +173,30 @@ def test_uint8_frames_match_host_normalisation():
     assert torch.equal(a["pred_logits"], b["pred_logits"]) and torch.equal(a["pred_boxes"], b["pred_boxes"])
 
 
+def test_train_mode_dropout():
+    """train() switches the sub-layer / feed-forward dropout on (stateless masks, fresh seed per call): outputs
+    differ from eval and between calls, gradients flow; eval() is the parity graph again, bit for bit."""
+    cfg = Config(backbone="resnet18", enc_layers=1, dec_layers=2)
+    model, _ = build_product(cfg, torch.float32, 6)
+    data = make_batch(2, 3, 64, 96, seed=6, device=DEV, max_boxes=6)
+    imu = torch.cat([data[k] for k in model._imu_keys], dim=2)
+    with torch.no_grad():
+        e1, _ = model._model(data["video"], imu=imu)
+    model.train()
+    with torch.no_grad():
+        t1, _ = model._model(data["video"], imu=imu)
+        t2, _ = model._model(data["video"], imu=imu)
+    assert not torch.equal(t1["pred_logits"], e1["pred_logits"]) and not torch.equal(t1["pred_logits"], t2["pred_logits"])
+    assert float((t1["pred_logits"] - e1["pred_logits"]).abs().max()) < 50.0          # perturbed, not broken
+    out, _, loss, stats, od = model(data=data, distributed=False)
+    loss.backward()
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    model.eval()
+    with torch.no_grad():
+        e2, _ = model._model(data["video"], imu=imu)
+    assert torch.equal(e1["pred_logits"], e2["pred_logits"]) and torch.equal(e1["pred_boxes"], e2["pred_boxes"])
+
+
 def test_dead_frame_skipping_is_exact():
     cfg = Config(backbone="resnet18", enc_layers=1, dec_layers=1)
     model, _ = build_product(cfg, torch.float32, 3)

@@ -39,6 +39,7 @@ def _worker(rank, world, port, q):
                                   backbone="resnet18", enc_layers=1, dec_layers=2)
     args = SimpleNamespace(device=dev, distributed=True, compute_dtype="fp32", num_images=2, backbone="resnet18")
     model = build_model(args, detr)
+    model.eval()              # same graph in both passes of a step (train mode draws fresh dropout masks per call)
     opt = FusedAdamW(model.parameters(), lr=0.0, weight_decay=0.0, max_norm=0.0)     # lr 0: weights stay equal
     data = make_batch(1, 3, 64, 96, seed=100 + rank, device=dev, max_boxes=5)        # a different shard per rank
     worst, report = 0.0, []

@@ -11,7 +11,7 @@ from types import SimpleNamespace
 a = SimpleNamespace(dtype="bf16")
 dev = torch.device("cuda", 0)
 model, detr = bench.build(a, dev, False, 5, "bf16")
-model.train()
+model.eval()      # the benchmark graph: eval mode with autograd on
 opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, max_norm=0.1)
 data = make_batch(2, 6, 900, 1600, seed=1234, device=dev)
 def step():

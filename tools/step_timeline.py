@@ -23,7 +23,7 @@ model, detr = bench.build(a, dev, DDP, 5, "bf16")
 if DDP and os.environ.get("NOOP_COMM") == "1":
     from torch.distributed.algorithms.ddp_comm_hooks.debugging_hooks import noop_hook
     model.register_comm_hook(None, noop_hook)
-model.train()
+model.eval()      # the benchmark graph: eval mode with autograd on
 opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, max_norm=0.1)
 data = make_batch(2, 6, 900, 1600, seed=1234, device=dev)
 
