@@ -32,7 +32,17 @@ struct AttnParams {
   long q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
   long k2_bs, k2_ts, dk2_bs, dk2_ts;   // part-2 keys may be shared by the batch (k2_bs = 0) and have their own pitch
   float scale;
+  // dropout on the attention probabilities (train mode): element (b, h, q, k) of call `seed` is kept iff
+  // drop_mix(q * S + k, seed_lo + (b * H + h) * 0x9E3779B9, seed_hi) >= drop_threshold; 0 = off
+  unsigned drop_threshold, drop_seed_lo, drop_seed_hi;
+  float drop_inv_keep;
 };
+
+// multiplier of probability (q, k): 0 if dropped, 1 / keep otherwise
+FOD_DEVINL float drop_gain(const AttnParams& p, unsigned bh_seed, int q, int k) {
+  return drop_mix((unsigned)q * (unsigned)p.S + (unsigned)k, bh_seed, p.drop_seed_hi) >= p.drop_threshold
+             ? p.drop_inv_keep : 0.f;
+}
 
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -145,7 +155,7 @@ FOD_DEVINL void zero_acc(f32x16& a) {
 // SPLIT = true : the 4 waves of a block share 32 queries and each walks every 4th key tile; partial
 //                (max, sum, O) states are merged through LDS.  Used when Tq is small (decoder queries:
 //                Tq = 128 would otherwise give 16 blocks that each walk 46 key tiles serially).
-template <typename T, int PARTS, bool SPLIT>
+template <typename T, int PARTS, bool SPLIT, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 31, fh = lane >> 5;
@@ -165,6 +175,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
       frag_load_contig(fq[pt][s], Qp[pt] + (long)b * p.q_bs + (long)q * p.q_ts + h * 32 + 16 * s + 8 * fh);
 
   const float c = p.scale * LOG2E;
+  const unsigned bh_seed = p.drop_seed_lo + (unsigned)(b * p.H + h) * 0x9E3779B9u;
   float m = -INFINITY, l = 0.f;
   f32x16 oacc;
   zero_acc<T>(oacc);
@@ -206,6 +217,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     m = m_new;
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+    if (DROP) {                                  // the row sums above are of the undropped probabilities
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] *= drop_gain(p, bh_seed, q0 + fr, k0 + acc_row(r, lane));
+    }
     tv.stage(Vp + (long)k0 * p.v_ts, p.v_ts, p.S - k0, slab_v[wave], lane);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -253,7 +268,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 
 // ------------------------------------------------------------------------------------------------
 // dq pass: wave owns 32 queries.  Also writes delta[q] = sum_d dO[q,d] * O[q,d].
-template <typename T, int PARTS, bool SPLIT>
+template <typename T, int PARTS, bool SPLIT, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 31, fh = lane >> 5;
@@ -286,6 +301,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   if (fh == 0 && q0 + fr < p.Tq && (!SPLIT || wave == 0)) p.delta[sidx] = dl;
 
   const float c = p.scale * LOG2E;
+  const unsigned bh_seed = p.drop_seed_lo + (unsigned)(b * p.H + h) * 0x9E3779B9u;
   f32x16 dq[PARTS];
 #pragma unroll
   for (int pt = 0; pt < PARTS; ++pt) zero_acc<T>(dq[pt]);
@@ -329,7 +345,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
     for (int r = 0; r < 16; ++r) {
       const bool ok = (k0 + acc_row(r, lane)) < p.S;
       const float pr = ok ? exp2f(sacc[r] * c - lse2) : 0.f;
-      sacc[r] = pr * (dpacc[r] - dl) * p.scale;      // dS^T
+      const float dp = DROP ? dpacc[r] * drop_gain(p, bh_seed, q0 + fr, k0 + acc_row(r, lane)) : dpacc[r];
+      sacc[r] = pr * (dp - dl) * p.scale;            // dS^T
     }
 #pragma unroll
     for (int pt = 0; pt < PARTS; ++pt) {
@@ -381,7 +398,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
 
 // ------------------------------------------------------------------------------------------------
 // dk/dv pass: wave owns 32 keys (key on the lane); needs lse2 and delta from the passes above.
-template <typename T, int PARTS>
+template <typename T, int PARTS, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 31, fh = lane >> 5;
@@ -403,6 +420,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
       frag_load_contig(fk[pt][s], Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)key * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
   }
   const float c = p.scale * LOG2E;
+  const unsigned bh_seed = p.drop_seed_lo + (unsigned)(b * p.H + h) * 0x9E3779B9u;
   f32x16 dk[PARTS], dv;
   zero_acc<T>(dv);
 #pragma unroll
@@ -435,8 +453,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
       const bool ok = qq < p.Tq;
       const int qc = ok ? qq : 0;
       const float pr = ok ? exp2f(sacc[r] * c - lse_b[qc]) : 0.f;
-      dpacc[r] = pr * (dpacc[r] - del_b[qc]) * p.scale;   // dS
-      sacc[r] = pr;                                       // P
+      const float gain = DROP ? drop_gain(p, bh_seed, qq, k0 + fr) : 1.f;
+      dpacc[r] = pr * (dpacc[r] * gain - del_b[qc]) * p.scale;   // dS
+      sacc[r] = pr * gain;                                        // P after dropout (for dV)
     }
     tdo.stage(dOb + (long)q0 * p.o_ts, p.o_ts, p.Tq - q0, slab_q[wave][PARTS], lane);
 #pragma unroll
@@ -479,7 +498,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
 //   * lse / delta reach the accumulator layout through LDS: one coalesced load per lane, four ds_read_b128 each
 //     (accumulator rows 8g + 4h .. +3 are consecutive queries).
 // Rows past Tq are clamped duplicates; their P and dS are zeroed, so they add nothing.
-template <int PARTS>
+template <int PARTS, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_pf_kernel(const AttnParams p) {
   typedef __bf16 T;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -503,6 +522,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_pf_kernel(const AttnParams p
       frag_load_contig(fk[pt][s], Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)key * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
   }
   const float c = p.scale * LOG2E;
+  const unsigned bh_seed = p.drop_seed_lo + (unsigned)(b * p.H + h) * 0x9E3779B9u;
   f32x16 dk[PARTS], dv;
   zero_acc<T>(dv);
 #pragma unroll
@@ -561,10 +581,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_pf_kernel(const AttnParams p
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
-        const bool ok = q0 + 8 * g + 4 * fh + e < p.Tq;
+        const int qq = q0 + 8 * g + 4 * fh + e;
+        const bool ok = qq < p.Tq;
         const float pr = ok ? exp2f(sacc[r] * c - ls[e]) : 0.f;
-        dpacc[r] = pr * (dpacc[r] - de[e]) * p.scale;   // dS
-        sacc[r] = pr;                                   // P
+        const float gain = DROP ? drop_gain(p, bh_seed, qq, k0 + fr) : 1.f;
+        dpacc[r] = pr * (dpacc[r] * gain - de[e]) * p.scale;   // dS
+        sacc[r] = pr * gain;                                    // P after dropout (for dV)
       }
     }
 #pragma unroll
@@ -596,36 +618,42 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_pf_kernel(const AttnParams p
   }
 }
 
-template <typename T, int PARTS>
+template <typename T, int PARTS, bool DROP>
 int launch_all(int which, const AttnParams& p, hipStream_t stream) {
   const dim3 block(256);
   // few queries: spend the block's four waves on the key dimension instead (see attn_fwd_kernel)
   const bool split = p.Tq <= 512 && p.S >= 128;
   if (which == 0) {
     if (split)
-      hipLaunchKernelGGL((attn_fwd_kernel<T, PARTS, true>), dim3(ceil_div(p.Tq, 32), p.H, p.B), block, 0, stream, p);
+      hipLaunchKernelGGL((attn_fwd_kernel<T, PARTS, true, DROP>), dim3(ceil_div(p.Tq, 32), p.H, p.B), block, 0, stream, p);
     else
-      hipLaunchKernelGGL((attn_fwd_kernel<T, PARTS, false>), dim3(ceil_div(p.Tq, 128), p.H, p.B), block, 0, stream, p);
+      hipLaunchKernelGGL((attn_fwd_kernel<T, PARTS, false, DROP>), dim3(ceil_div(p.Tq, 128), p.H, p.B), block, 0, stream, p);
   } else if (which == 1) {
     if (split)
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, PARTS, true>), dim3(ceil_div(p.Tq, 32), p.H, p.B), block, 0, stream, p);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, PARTS, true, DROP>), dim3(ceil_div(p.Tq, 32), p.H, p.B), block, 0, stream, p);
     else
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, PARTS, false>), dim3(ceil_div(p.Tq, 128), p.H, p.B), block, 0, stream, p);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, PARTS, false, DROP>), dim3(ceil_div(p.Tq, 128), p.H, p.B), block, 0, stream, p);
   } else {
     const dim3 grid(ceil_div(p.S, 128), p.H, p.B);
     static const char* env_pf = getenv("FOD_ATTN_PF");
     if (sizeof(T) == 2 && !(env_pf && env_pf[0] == '0'))
-      hipLaunchKernelGGL((attn_bwd_dkv_pf_kernel<PARTS>), grid, block, 0, stream, p);
+      hipLaunchKernelGGL((attn_bwd_dkv_pf_kernel<PARTS, DROP>), grid, block, 0, stream, p);
     else
-      hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, PARTS>), grid, block, 0, stream, p);
+      hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, PARTS, DROP>), grid, block, 0, stream, p);
   }
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }
 
+template <typename T, int PARTS>
+int launch_parts(int which, const AttnParams& p, hipStream_t stream) {
+  // dropout on the probabilities (train mode) is a compile-time variant: the plain kernels carry none of its code
+  return p.drop_threshold ? launch_all<T, PARTS, true>(which, p, stream) : launch_all<T, PARTS, false>(which, p, stream);
+}
+
 int dispatch(int dtype, int parts, int which, const AttnParams& p, hipStream_t stream) {
-  if (dtype == FOD_BF16) return parts == 2 ? launch_all<__bf16, 2>(which, p, stream) : launch_all<__bf16, 1>(which, p, stream);
-  if (dtype == FOD_F32) return parts == 2 ? launch_all<float, 2>(which, p, stream) : launch_all<float, 1>(which, p, stream);
+  if (dtype == FOD_BF16) return parts == 2 ? launch_parts<__bf16, 2>(which, p, stream) : launch_parts<__bf16, 1>(which, p, stream);
+  if (dtype == FOD_F32) return parts == 2 ? launch_parts<float, 2>(which, p, stream) : launch_parts<float, 1>(which, p, stream);
   fod_set_error("attention: bad dtype %d", dtype);
   return FOD_ERR_ARG;
 }
@@ -646,6 +674,12 @@ int fill(AttnParams& p, const fod_attn_shape* s) {
   p.v_bs = s->v_batch_stride; p.v_ts = s->v_token_stride;
   p.o_bs = s->o_batch_stride; p.o_ts = s->o_token_stride;
   p.scale = s->scale;
+  FOD_REQUIRE(s->drop_p >= 0.f && s->drop_p < 1.f, "attention: drop_p=%f out of [0, 1)", s->drop_p);
+  p.drop_threshold = (unsigned)((double)s->drop_p * 4294967296.0);
+  p.drop_inv_keep = 1.f / (1.f - s->drop_p);
+  p.drop_seed_lo = (unsigned)(s->drop_seed & 0xFFFFFFFFu);
+  p.drop_seed_hi = (unsigned)(s->drop_seed >> 32);
+  FOD_REQUIRE(p.drop_threshold == 0 || (long)s->Tq * s->S < (1L << 32), "attention: Tq * S too large for dropout indexing");
   FOD_REQUIRE(p.q_ts % 8 == 0 && p.k_ts % 8 == 0 && p.v_ts % 8 == 0 && p.o_ts % 8 == 0 && p.q_bs % 8 == 0 &&
                   p.k_bs % 8 == 0 && p.v_bs % 8 == 0 && p.o_bs % 8 == 0 && p.k2_bs % 8 == 0 && p.k2_ts % 8 == 0 &&
                   p.dk2_bs % 8 == 0 && p.dk2_ts % 8 == 0,

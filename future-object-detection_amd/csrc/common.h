@@ -126,6 +126,18 @@ FOD_DEVINL void frag_gather_accorder(Frag<T>& f, const T* base, long stride, int
   }
 }
 
+// Stateless dropout decision shared by fod_dropout and the attention kernels: element i of call (seed_lo, seed_hi)
+// is kept iff drop_mix(...) >= threshold, threshold = p * 2^32.
+FOD_DEVINL unsigned drop_mix(unsigned i, unsigned seed_lo, unsigned seed_hi) {
+  unsigned h = (i ^ seed_lo) * 0x9E3779B1u + seed_hi;
+  h ^= h >> 15;
+  h *= 0x85EBCA77u;
+  h ^= h >> 13;
+  h *= 0xC2B2AE3Du;
+  h ^= h >> 16;
+  return h;
+}
+
 FOD_DEVINL int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 FOD_DEVINL float wave_sum(float v) {

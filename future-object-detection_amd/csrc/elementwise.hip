@@ -351,16 +351,6 @@ __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N
 
 // Dropout without a stored mask: element i of call `seed` is kept iff mix32(i, seed) >= threshold
 // (threshold = p * 2^32), so the backward pass regenerates the forward's mask from (seed, i) alone.
-FOD_DEVINL unsigned drop_mix(unsigned i, unsigned seed_lo, unsigned seed_hi) {
-  unsigned h = (i ^ seed_lo) * 0x9E3779B1u + seed_hi;
-  h ^= h >> 15;
-  h *= 0x85EBCA77u;
-  h ^= h >> 13;
-  h *= 0xC2B2AE3Du;
-  h ^= h >> 16;
-  return h;
-}
-
 template <typename T>
 __global__ void dropout_kernel(T* __restrict__ out, const T* __restrict__ a, unsigned nchunks, unsigned seed_lo,
                                unsigned seed_hi, unsigned threshold, float inv_keep) {

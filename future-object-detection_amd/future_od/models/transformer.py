@@ -77,6 +77,7 @@ class SlotToSlotAttention(Attention):
         super().__init__(D)
         self.fun = OutProj(D)
         self.Nhead, self.D = Nhead, D
+        self.droprate = dropout            # on the attention probabilities (MultiheadAttention(dropout=...), reference :64)
 
     def forward(self, x, qpos, pos_proj=None):
         """`pos_proj` = (query_pos(qpos), key_pos(qpos)) when the decoder has projected the (layer-independent)
@@ -86,7 +87,7 @@ class SlotToSlotAttention(Attention):
         qc, kc, v = Fn.group_linear(x, [self.query_content, self.key_content, self.value])
         q = Fn.add(qc, qp, b_row_mod=M)
         k = Fn.add(kc, kp, b_row_mod=M)
-        a = Fn.attention(q, k, v, 1.0 / math.sqrt(self.D // self.Nhead))
+        a = Fn.attention(q, k, v, 1.0 / math.sqrt(self.D // self.Nhead), drop_p=self.droprate, training=self.training)
         return _lin(a, self.fun.out_proj)
 
 
@@ -139,6 +140,7 @@ class SlotToImageAttention(Attention):
         self.query_sine = nn.Linear(D, D)
         self.fun = OutProj(D)
         self.D, self.Nhead = D, Nhead
+        self.droprate = dropout            # on the attention probabilities (reference :126)
         self.store_attention = False
 
     def forward(self, x, qpos, query_sine, side, layer, image, is_first, qs=None, qpos_proj=None):
@@ -158,7 +160,8 @@ class SlotToImageAttention(Attention):
             # so the addition moves to the (tiny) query side and the key slots are used as they are
             qs = Fn.add(qs, qc)
         # per head: q = [qc | qs], k = [kc | ks] (64 wide), scale (2D/heads)^-0.5
-        a = Fn.hoisted_cross_attention(qc, qs, side, layer, image, 1.0 / math.sqrt(2 * D // self.Nhead))
+        a = Fn.hoisted_cross_attention(qc, qs, side, layer, image, 1.0 / math.sqrt(2 * D // self.Nhead),
+                                       drop_p=self.droprate, training=self.training)
         if self.store_attention:
             kc, ks, _v = side.slots(layer, image)
             self.stored_attention = _head_mean_weights(qc, kc, qs, ks.unsqueeze(0).expand(B, -1, -1), self.Nhead)
@@ -297,7 +300,7 @@ class EncoderAttention(nn.Module):
         N = pos.shape[0]
         xp = Fn.add(src, pos, b_row_mod=N)
         q, k, v = Fn.in_proj(xp, src, self.attn.in_proj_weight, self.attn.in_proj_bias)
-        a = Fn.attention(q, k, v, 1.0 / math.sqrt(D // self.H))
+        a = Fn.attention(q, k, v, 1.0 / math.sqrt(D // self.H), drop_p=self.droprate, training=self.training)
         t, p = self.training, self.droprate
         src = Fn.layer_norm(src, self.norm1.weight, self.norm1.bias,
                             residual=Fn.dropout(_lin(a, self.attn.out_proj), p, t))

@@ -434,8 +434,9 @@ def dropout(x, p, training):
 
 class AttentionFn(Function):
     @staticmethod
-    def forward(ctx, q1, k1, v, q2, k2, scale):
-        o, lse2 = ops.attn_fwd(q1, k1, v, scale, q2, k2)
+    def forward(ctx, q1, k1, v, q2, k2, scale, drop_p=0.0, drop_seed=0):
+        o, lse2 = ops.attn_fwd(q1, k1, v, scale, q2, k2, drop_p=drop_p, drop_seed=drop_seed)
+        ctx.drop = (drop_p, drop_seed)
         ctx.scale = scale
         ctx.two = q2 is not None
         ctx.save_for_backward(q1, k1, v, q2, k2, o, lse2)
@@ -456,8 +457,9 @@ class AttentionFn(Function):
             # produced q, k, v takes as it is (no gather copies)
             buf = torch.empty((3,) + tuple(q1.shape), dtype=q1.dtype, device=q1.device)
             slots = dict(dq1_out=buf[0], dk1_out=buf[1], dv_out=buf[2])
-        dq1, dk1, dq2, dk2, dv = ops.attn_bwd(q1, k1, v, o, do.contiguous(), lse2, ctx.scale, q2, k2, **slots)
-        return dq1, dk1, dv, dq2, dk2, None
+        dq1, dk1, dq2, dk2, dv = ops.attn_bwd(q1, k1, v, o, do.contiguous(), lse2, ctx.scale, q2, k2,
+                                              drop_p=ctx.drop[0], drop_seed=ctx.drop[1], **slots)
+        return dq1, dk1, dv, dq2, dk2, None, None, None
 
 
 def _strided_ok(t):
@@ -467,8 +469,11 @@ def _strided_ok(t):
             and t.data_ptr() % 16 == 0)
 
 
-def attention(q1, k1, v, scale, q2=None, k2=None):
+def attention(q1, k1, v, scale, q2=None, k2=None, drop_p=0.0, training=False):
+    """`drop_p` (with `training`): dropout on the attention probabilities, as MultiheadAttention(dropout=p)."""
     c = lambda t: None if t is None else (t if _strided_ok(t) else t.contiguous())
+    if training and drop_p > 0.0:
+        return AttentionFn.apply(c(q1), c(k1), c(v), c(q2), c(k2), scale, float(drop_p), DROP_SEEDS.next())
     return AttentionFn.apply(c(q1), c(k1), c(v), c(q2), c(k2), scale)
 
 
@@ -792,11 +797,12 @@ class HoistedCrossAttnFn(Function):
     slot has been filled -- all earlier (higher-layer) calls return None for them."""
 
     @staticmethod
-    def forward(ctx, q1, q2, big_j, ks_all, side, layer, image, scale):
+    def forward(ctx, q1, q2, big_j, ks_all, side, layer, image, scale, drop_p=0.0, drop_seed=0):
         kc, ks, v = side.slots(layer, image)
-        o, lse2 = ops.attn_fwd(q1, kc, v, scale, q2, ks)
+        o, lse2 = ops.attn_fwd(q1, kc, v, scale, q2, ks, drop_p=drop_p, drop_seed=drop_seed)
         ctx.save_for_backward(q1, q2, o, lse2)
         ctx.side, ctx.layer, ctx.image, ctx.scale = side, layer, image, scale
+        ctx.drop = (drop_p, drop_seed)
         return o
 
     @staticmethod
@@ -821,15 +827,19 @@ class HoistedCrossAttnFn(Function):
         if key not in side.dq2:
             side.dq2[key] = torch.empty((side.K,) + tuple(q2.shape), dtype=q2.dtype, device=q2.device)
         dq1, _, dq2, _, _ = ops.attn_bwd(q1, kc, v, o, do.contiguous(), lse2, ctx.scale, q2, ks,
-                                         dk1_out=dkc, dv_out=dv, dk2_out=dks, dq2_out=side.dq2[key][image])
+                                         dk1_out=dkc, dv_out=dv, dk2_out=dks, dq2_out=side.dq2[key][image],
+                                         drop_p=ctx.drop[0], drop_seed=ctx.drop[1])
         g_big = side.dbig[image] if layer == 0 else None
         # a batch-shared ks_all gets the sum of the per-batch slots
         g_ks = None
         if layer == 0 and image == 0:
             g_ks = side.dks if per_batch_pos else _sum_leading(side.dks, side.dks.shape[0])
-        return dq1, dq2, g_big, g_ks, None, None, None, None
+        return dq1, dq2, g_big, g_ks, None, None, None, None, None, None
 
 
-def hoisted_cross_attention(q1, q2, side, layer, image, scale):
+def hoisted_cross_attention(q1, q2, side, layer, image, scale, drop_p=0.0, training=False):
+    if training and drop_p > 0.0:
+        return HoistedCrossAttnFn.apply(q1.contiguous(), q2.contiguous(), side.big[image], side.ks_all, side, layer,
+                                        image, scale, float(drop_p), DROP_SEEDS.next())
     return HoistedCrossAttnFn.apply(q1.contiguous(), q2.contiguous(), side.big[image], side.ks_all, side, layer,
                                     image, scale)

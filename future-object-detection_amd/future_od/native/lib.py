@@ -38,7 +38,8 @@ class AttnShape(C.Structure):
                 ("o_batch_stride", C.c_long), ("o_token_stride", C.c_long),
                 ("scale", C.c_float),
                 ("k2_batch_stride", C.c_long), ("k2_token_stride", C.c_long),
-                ("dk2_batch_stride", C.c_long), ("dk2_token_stride", C.c_long)]
+                ("dk2_batch_stride", C.c_long), ("dk2_token_stride", C.c_long),
+                ("drop_p", C.c_float), ("drop_seed", C.c_ulonglong)]
 
 
 class PermuteJob(C.Structure):

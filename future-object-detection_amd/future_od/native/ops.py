@@ -288,7 +288,7 @@ def _bt(t, name, dtype):
     return bs, ts
 
 
-def _attn_shape(q1, k1, v, o, scale, k2=None, dk2=None):
+def _attn_shape(q1, k1, v, o, scale, k2=None, dk2=None, drop_p=0.0, drop_seed=0):
     dtp = q1.dtype
     B, Tq, E = q1.shape
     S = k1.shape[1]
@@ -306,7 +306,8 @@ def _attn_shape(q1, k1, v, o, scale, k2=None, dk2=None):
     if dk2 is not None:
         assert dk2.shape == (B, S, E)
         d2b, d2t = _bt(dk2, "dk2", dtp)
-    return AttnShape(B, H, Tq, S, qb, qt, kb, kt, vb, vt, ob, ot, scale, k2b, k2t, d2b, d2t), H
+    return AttnShape(B, H, Tq, S, qb, qt, kb, kt, vb, vt, ob, ot, scale, k2b, k2t, d2b, d2t, float(drop_p),
+                     int(drop_seed) & 0xFFFFFFFFFFFFFFFF), H
 
 
 def _same_bt(a, b, name):
@@ -314,13 +315,13 @@ def _same_bt(a, b, name):
         raise L.FodError(f"{name}: gradient slot must have the layout of its operand ({a.stride()} vs {b.stride()})")
 
 
-def attn_fwd(q1, k1, v, scale, q2=None, k2=None):
+def attn_fwd(q1, k1, v, scale, q2=None, k2=None, drop_p=0.0, drop_seed=0):
     """q* [B,Tq,H*32], k1/v [B,S,H*32] (any batch/token strides), k2 [B,S,E] or a batch-shared table [S,E];
     returns (o [B,Tq,H*32] contiguous, lse2 f32 [B,H,Tq])."""
     o = torch.empty(q1.shape, dtype=q1.dtype, device=q1.device)
     if q2 is not None:
         _same_bt(q1, q2, "q2")
-    shp, H = _attn_shape(q1, k1, v, o, scale, k2)
+    shp, H = _attn_shape(q1, k1, v, o, scale, k2, drop_p=drop_p, drop_seed=drop_seed)
     lse2 = torch.empty((q1.shape[0], H, q1.shape[1]), dtype=torch.float32, device=q1.device)
     parts = 2 if q2 is not None else 1
     call("fod_attn_fwd", dt(q1), ptr(q1), ptr(k1), ptr(q2), ptr(k2), ptr(v), ptr(o), ptr(lse2),
@@ -329,7 +330,7 @@ def attn_fwd(q1, k1, v, scale, q2=None, k2=None):
 
 
 def attn_bwd(q1, k1, v, o, dout, lse2, scale, q2=None, k2=None, dk1_out=None, dv_out=None, dk2_out=None,
-             dq1_out=None, dq2_out=None):
+             dq1_out=None, dq2_out=None, drop_p=0.0, drop_seed=0):
     """Gradients (dq1, dk1, dq2, dk2, dv).  dk1_out / dv_out / dk2_out: optional destinations (e.g. slots of a
     larger gradient buffer); dk1_out / dv_out must have k1's / v's strides, dk2_out is always per batch element."""
     _chk(lse2, "lse2", torch.float32)
@@ -349,7 +350,7 @@ def attn_bwd(q1, k1, v, o, dout, lse2, scale, q2=None, k2=None, dk1_out=None, dv
         _same_bt(dq2, q1, "dq2")
         B, S, E = k1.shape
         dk2 = dk2_out if dk2_out is not None else torch.empty((B, S, E), dtype=k1.dtype, device=k1.device)
-    shp, H = _attn_shape(q1, k1, v, o, scale, k2, dk2)
+    shp, H = _attn_shape(q1, k1, v, o, scale, k2, dk2, drop_p=drop_p, drop_seed=drop_seed)
     assert lse2.shape == (q1.shape[0], H, q1.shape[1])
     delta = torch.empty_like(lse2)
     call("fod_attn_bwd", dt(q1), ptr(q1), ptr(k1), ptr(q2), ptr(k2), ptr(v), ptr(o), ptr(dout), ptr(lse2),

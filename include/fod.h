@@ -163,6 +163,11 @@ typedef struct fod_attn_shape {
    * table across the batch (the projected positional table).  dk2 is always written per batch element. */
   long k2_batch_stride, k2_token_stride;
   long dk2_batch_stride, dk2_token_stride;
+  /* dropout on the attention probabilities (train mode; MultiheadAttention(dropout=p), reference
+   * transformer.py:64,92,126,404): 0 = off.  Stateless: probability (b, h, q, k) is kept iff a hash of
+   * (drop_seed, b, h, q, k) >= drop_p * 2^32; forward and backward must be given the same seed. */
+  float drop_p;
+  unsigned long long drop_seed;
 } fod_attn_shape;
 
 /* o = softmax((q1.k1 + q2.k2) * scale) v per head; head h = channels [32h, 32h+32) of every tensor.

@@ -213,6 +213,59 @@ def test_attention_fwd_bwd(dtype, shape):
         check(dk2, leaves[4].grad, dtype, sc, "dk2")
 
 
+def _drop_keep_mask(B, H, Tq, S, seed, p):
+    """The attention kernels' stateless keep decision, restated in numpy (include/fod.h: fod_attn_shape.drop_*)."""
+    M = np.uint64(0xFFFFFFFF)
+    lo, hi = np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32)
+    bh = np.arange(B * H, dtype=np.uint64).reshape(B, H, 1, 1)
+    bh_seed = (lo + bh * np.uint64(0x9E3779B9)) & M
+    idx = (np.arange(Tq, dtype=np.uint64).reshape(1, 1, Tq, 1) * np.uint64(S)
+           + np.arange(S, dtype=np.uint64).reshape(1, 1, 1, S)) & M
+    h = (((idx ^ bh_seed) * np.uint64(0x9E3779B1)) + hi) & M
+    h ^= h >> np.uint64(15)
+    h = (h * np.uint64(0x85EBCA77)) & M
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xC2B2AE3D)) & M
+    h ^= h >> np.uint64(16)
+    return torch.from_numpy((h >= np.uint64(int(p * 4294967296.0))).astype(np.float32))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 4, 77, 150, 1), (1, 8, 128, 49, 2), (1, 2, 600, 333, 1), (2, 8, 128, 300, 2)])
+def test_attention_probability_dropout(dtype, shape):
+    """Dropout on the attention probabilities (train mode): forward and all gradients against torch with the SAME
+    keep mask (the kernels' stateless hash restated in numpy); keep rate as requested."""
+    B, H, Tq, S, parts = shape
+    E, p_drop, seed = H * 32, 0.1, 0x1234567890ABCDEF
+    q1, k1, v = rnd((B, Tq, E), dtype, 1), rnd((B, S, E), dtype, 2), rnd((B, S, E), dtype, 3)
+    q2 = rnd((B, Tq, E), dtype, 4) if parts == 2 else None
+    k2 = rnd((B, S, E), dtype, 5) if parts == 2 else None
+    scale = 1.0 / math.sqrt(32 * parts)
+    keep = _drop_keep_mask(B, H, Tq, S, seed, p_drop)
+    assert abs(float(keep.mean()) - (1 - p_drop)) < 0.02
+    leaves = [t.float().requires_grad_(True) if t is not None else None for t in (q1, k1, v, q2, k2)]
+    heads = lambda t: t.view(t.shape[0], t.shape[1], H, 32).transpose(1, 2)
+    sc = heads(leaves[0]) @ heads(leaves[1]).transpose(-1, -2)
+    if parts == 2:
+        sc = sc + heads(leaves[3]) @ heads(leaves[4]).transpose(-1, -2)
+    prob = torch.softmax(sc * scale, dim=-1) * keep / (1 - p_drop)
+    o_ref = (prob @ heads(leaves[2])).transpose(1, 2).reshape(B, Tq, E)
+    dout = rnd((B, Tq, E), dtype, 6)
+    o_ref.backward(dout.float())
+    g = lambda t: None if t is None else t.to(DEV)
+    o, lse2 = ops.attn_fwd(g(q1), g(k1), g(v), scale, g(q2), g(k2), drop_p=p_drop, drop_seed=seed)
+    check(o, o_ref, dtype, 1, f"attn dropout fwd {shape}")
+    dq1, dk1, dq2, dk2, dv = ops.attn_bwd(g(q1), g(k1), g(v), o, g(dout), lse2, scale, g(q2), g(k2),
+                                          drop_p=p_drop, drop_seed=seed)
+    s_ = math.sqrt(max(Tq, S)) * 0.5
+    check(dq1, leaves[0].grad, dtype, s_, "dq1")
+    check(dk1, leaves[1].grad, dtype, s_, "dk1")
+    check(dv, leaves[2].grad, dtype, s_, "dv")
+    if parts == 2:
+        check(dq2, leaves[3].grad, dtype, s_, "dq2")
+        check(dk2, leaves[4].grad, dtype, s_, "dk2")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("D", [64, 256])
 def test_layernorm(dtype, D):
