@@ -227,17 +227,35 @@ class CDetrDetectorSpatioTemporal(nn.Module):
         return out
 
 
+class JointEncoder(nn.Module):
+    """Self-attention over the tokens of ALL past frames at once (reference paper.py:180-203).  The reference orders
+    them (h w l); every operation of an encoder layer is equivariant under token permutations, so they stay
+    frame-major here ([B, L*N, D], the layout the detector's 'attend all at once' memory uses too).  Layers with
+    the IMU attention are not supported (no configuration of the reference builds a joint encoder at all)."""
+
+    def __init__(self, transformer: TransformerEncoder):
+        super().__init__()
+        for layer in transformer.layers:
+            if getattr(layer, "egodeep_attend", None) is not None:
+                raise NotImplementedError("JointEncoder layers with IMU attention (use_egodeep=True)")
+        self.transformer = transformer
+
+    def forward(self, tokens, pos):
+        """tokens [B, L*N, D]; pos [L*N, D] table or [B, L*N, D]."""
+        return self.transformer(tokens, pos, None)
+
+
 class FuturePredCore(nn.Module):
     """Drop the future frame, encode the past frames, decode the future detections (reference :432-485)."""
 
     def __init__(self, separate_encoder: SeparateEncoder, joint_encoder, detector: CDetrDetectorSpatioTemporal,
                  pos_encoder: PositionalEncoder):
         super().__init__()
-        if joint_encoder is not None:
-            raise NotImplementedError("joint encoders (JointEncoder / JointEncoderSequential / F2F) are not instantiated "
-                                      "by the reference's runs/ (SURVEY.md 8f-2): next")
+        if joint_encoder is not None and not isinstance(joint_encoder, JointEncoder):
+            raise NotImplementedError("JointEncoderSequential / JointEncoderF2F are not instantiated by the reference's "
+                                      "runs/ (SURVEY.md 8f-2): next")
         self.separate_encoder = separate_encoder
-        self.joint_encoder = None
+        self.joint_encoder = joint_encoder
         self.detector = detector
         self.pos_encoder = pos_encoder
         self.compute_dtype = torch.bfloat16
@@ -249,23 +267,29 @@ class FuturePredCore(nn.Module):
         assert past > 0
         all_at_once = self.detector.image_memory_mode == "attend all at once"
         keep = self.detector.frames_needed(past) if (self.skip_dead_frames or all_at_once) else past
+        if self.joint_encoder is not None:
+            keep = past                        # every frame reaches every other one through the joint self-attention
         clip = images[:, past - keep:past]
         imu_k = imu[:, past - keep:past] if imu is not None else None
         tokens, (h, w), _ego = self.separate_encoder(clip, self.pos_encoder, imu_k, dtype=self.compute_dtype)
         F_, N, D = tokens.shape
         frames = list(tokens.view(keep, B, N, D).unbind(0))
-        pos = self.pos_encoder.spatial_table(h, w, D, self.compute_dtype, tokens.device)          # [N, D]
+        spatial = self.pos_encoder.spatial_table(h, w, D, self.compute_dtype, tokens.device)      # [N, D]
+        # encodings of (a) all kept frames as one token sequence, (b) the current (last) frame alone
         if not self.pos_encoder._no_temporal:
             # + the per-(batch, frame) temporal term (reference paper.py:50-55,66-73), computed over ALL past
             # frames (it is normalised by the last one) and cut to the frames that are kept
             offs = temporal_offsets[:, :past] if temporal_offsets is not None else None
             tt = self.pos_encoder.temporal_table(B, past, D, torch.float32, tokens.device, offs)[:, past - keep:]
-            if all_at_once:
-                pos = (pos.float()[None, None] + tt[:, :, None]).reshape(B, keep * N, D).to(self.compute_dtype)
-            else:
-                pos = (pos.float()[None] + tt[:, -1, None]).to(self.compute_dtype).contiguous()   # [B, N, D]
-        elif all_at_once:
-            pos = pos.repeat(keep, 1)                                                             # [keep*N, D]
-        out = self.detector(frames, pos, num_frames_total=past)
+            pos_all = lambda: (spatial.float()[None, None] + tt[:, :, None]).reshape(B, keep * N, D).to(self.compute_dtype)
+            pos_last = lambda: (spatial.float()[None] + tt[:, -1, None]).to(self.compute_dtype).contiguous()   # [B, N, D]
+        else:
+            pos_all = lambda: spatial.repeat(keep, 1)                                             # [keep*N, D]
+            pos_last = lambda: spatial
+        if self.joint_encoder is not None:
+            pa = pos_all()
+            joint = self.joint_encoder(torch.cat(frames, dim=1) if keep > 1 else frames[0], pa)  # [B, keep*N, D]
+            frames = list(joint.view(B, keep, N, D).unbind(1))
+        out = self.detector(frames, pos_all() if all_at_once else pos_last(), num_frames_total=past)
         moods = [["model happy" for _ in range(L)] for _ in range(B)]
         return out, moods

@@ -298,7 +298,7 @@ class EncoderAttention(nn.Module):
         """src [F,N,D]; pos table [N,D].  q = k = src + pos, v = src."""
         D = self.D
         N = pos.shape[0]
-        xp = Fn.add(src, pos, b_row_mod=N)
+        xp = Fn.add(src, pos, b_row_mod=N) if pos.dim() == 2 else Fn.add(src, pos)      # table, or per-batch encoding
         q, k, v = Fn.in_proj(xp, src, self.attn.in_proj_weight, self.attn.in_proj_bias)
         a = Fn.attention(q, k, v, 1.0 / math.sqrt(D // self.H), drop_p=self.droprate, training=self.training)
         t, p = self.training, self.droprate

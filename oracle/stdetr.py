@@ -46,6 +46,7 @@ class Config:
     no_temporal: bool = True            # runs/_model.py:70-72
     first_layer_special_when: str = "always"      # runs/_model.py:65
     image_memory_mode: str = "attend one at a time"  # runs/_model.py:68
+    joint_layers: int = 0               # paper.py:180-203 JointEncoder (runs/_model.py:52 passes None); layers w/o IMU attention
     train_backbone: bool = True         # runs/_model.py:21 (lr_backbone > 0)
     # matcher / loss (st_detr.py:41-51)
     set_cost_class: float = 2.0
@@ -65,6 +66,7 @@ P_CORE = "_model."
 P_SEP = P_CORE + "separate_encoder."
 P_BB = P_SEP + "backbone."
 P_ENC = P_SEP + "transformer.layers."
+P_JOINT = P_CORE + "joint_encoder.transformer.layers."
 P_DET = P_CORE + "detector."
 P_DEC = P_DET + "decoder."
 
@@ -136,6 +138,15 @@ def param_spec(cfg: Config) -> Dict[str, tuple]:
             _lin(spec, p + "egodeep_attend.mlp.3", D, Dff)
             _ln(spec, p + "egodeep_attend.norm2", D)
             _ln(spec, p + "norm_eda", D)
+    for i in range(cfg.joint_layers):                                               # paper.py:180-183
+        p = f"{P_JOINT}{i}."
+        spec[p + "self_attn.attn.in_proj_weight"] = ((3 * D, D), "param")
+        spec[p + "self_attn.attn.in_proj_bias"] = ((3 * D,), "param")
+        _lin(spec, p + "self_attn.attn.out_proj", D, D)
+        _ln(spec, p + "self_attn.norm1", D)
+        _lin(spec, p + "self_attn.mlp.0", Dff, D)
+        _lin(spec, p + "self_attn.mlp.3", D, Dff)
+        _ln(spec, p + "self_attn.norm2", D)
     for i in range(cfg.dec_layers):
         p = f"{P_DEC}layers.{i}."
         for n in ("query_content", "query_pos", "key_content", "key_pos", "value", "fun.out_proj"):
@@ -336,9 +347,9 @@ def egodeep_attention(sd, key, cfg, q_content, q_pos, ego, with_mlp):
     return out
 
 
-def encoder_layer(sd, cfg, i, x, pos, ego):
+def encoder_layer(sd, cfg, i, x, pos, ego, prefix=None):
     """x,pos (N,Bf,D); ego (S,Bf,D) or None.  transformer.py:449-487."""
-    p = f"{P_ENC}{i}."
+    p = f"{prefix or P_ENC}{i}."
     qk = x + pos
     a = stock_mha(sd, p + "self_attn.attn", qk, qk, x, cfg.nheads)
     x = _lnorm(sd, p + "self_attn.norm1", x + a)                     # transformer.py:417
@@ -496,7 +507,7 @@ def core_forward(sd, cfg, images, imu=None, temporal_offsets=None, skip_dead=Fal
     imu = imu[:, :-1] if imu is not None else None
     if temporal_offsets is not None:
         temporal_offsets = temporal_offsets[:, :-1]
-    if skip_dead and cfg.image_memory_mode == "attend one at a time":
+    if skip_dead and cfg.image_memory_mode == "attend one at a time" and not cfg.joint_layers:
         keep = min(cfg.num_images, images.shape[1])
         images = images[:, -keep:]
         imu = imu[:, -keep:] if imu is not None else None
@@ -510,6 +521,12 @@ def core_forward(sd, cfg, images, imu=None, temporal_offsets=None, skip_dead=Fal
     pos = spatial_pos_table(h, w, D, feat.device)[None, None].expand(B, L, -1, -1, -1)
     if not cfg.no_temporal:
         pos = pos + temporal_pos_table(B, L, h, w, D, temporal_offsets, device=feat.device)
+    if cfg.joint_layers:                                               # paper.py:193-198, layers without IMU attention
+        x = feat.permute(3, 4, 1, 0, 2).flatten(0, 2)                 # (h w l) b c
+        pj = pos.permute(3, 4, 1, 0, 2).flatten(0, 2)
+        for i in range(cfg.joint_layers):
+            x = encoder_layer(sd, cfg, i, x, pj, None, prefix=P_JOINT)
+        feat = x.view(h, w, L, B, D).permute(3, 2, 4, 0, 1)
     return detector_forward(sd, cfg, feat, pos, skip_dead, attn_out)
 
 

@@ -70,7 +70,10 @@ def build_reference(cfg: Config, paper, transformer, st_detr):
             imu_layers=nn.Sequential(nn.Linear(cfg.imu_dim, cfg.imu_hidden), nn.ReLU(inplace=True),
                                      nn.Linear(cfg.imu_hidden, cfg.hidden_dim)) if cfg.use_imu else None,
             transformer=enc),
-        joint_encoder=None,
+        joint_encoder=paper.JointEncoder(transformer.TransformerEncoder(layers=nn.ModuleList(
+            transformer.TransformerEncoderLayer(D=cfg.hidden_dim, Nhead=cfg.nheads, Dff=cfg.dim_feedforward,
+                                                use_egodeep=False)
+            for _ in range(cfg.joint_layers)))) if cfg.joint_layers else None,
         detector=paper.CDetrDetectorSpatioTemporal(
             decoder=transformer.TransformerDecoder(
                 layers=nn.ModuleList([
@@ -166,6 +169,8 @@ def main():
                                      2, 4, 64, 96, 14),
         "g12_one_at_a_time_temporal": (Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2,
                                               no_temporal=False), 2, 4, 64, 96, 15),
+        "g13_joint_encoder": (Config(backbone="resnet18", enc_layers=1, joint_layers=1, dec_layers=1, num_images=2,
+                                     no_temporal=False), 2, 4, 64, 96, 16),
     }
     for name, (cfg, B, L, H, W, seed) in cases.items():
         if ONLY and name not in ONLY:

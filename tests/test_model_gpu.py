@@ -19,7 +19,7 @@ DEV = "cuda:0"
 
 if torch.cuda.is_available():
     import future_od.models.transformer as T
-    from future_od.models.paper import (CDetrBackbone, CDetrDetectorSpatioTemporal, FuturePredCore,
+    from future_od.models.paper import (CDetrBackbone, CDetrDetectorSpatioTemporal, FuturePredCore, JointEncoder,
                                         PositionalEncoder, SeparateEncoder)
     from future_od.models.st_detr import SpatioTemporalDETR, SpatioTemporalDETRArgs
     from future_od.native import functional as Fn
@@ -40,7 +40,9 @@ def build_product(cfg: Config, dtype, seed):
             transformer=T.TransformerEncoder(nn.ModuleList(
                 T.TransformerEncoderLayer(cfg.hidden_dim, cfg.nheads, cfg.dim_feedforward, use_egodeep=cfg.use_imu)
                 for _ in range(cfg.enc_layers)))),
-        joint_encoder=None,
+        joint_encoder=JointEncoder(T.TransformerEncoder(nn.ModuleList(
+            T.TransformerEncoderLayer(cfg.hidden_dim, cfg.nheads, cfg.dim_feedforward, use_egodeep=False)
+            for _ in range(cfg.joint_layers)))) if cfg.joint_layers else None,
         detector=CDetrDetectorSpatioTemporal(
             decoder=T.TransformerDecoder(nn.ModuleList(
                 [T.TransformerDecoderLayer(cfg.hidden_dim, cfg.nheads, cfg.dim_feedforward, 0.1, cfg.num_images)
@@ -68,6 +70,8 @@ CASES = {
                                        image_memory_mode="attend all at once", no_temporal=False),
     "g12_one_at_a_time_temporal": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2,
                                          no_temporal=False),
+    "g13_joint_encoder": Config(backbone="resnet18", enc_layers=1, joint_layers=1, dec_layers=1, num_images=2,
+                                no_temporal=False),
 }
 
 
