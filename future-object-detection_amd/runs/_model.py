@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 import future_od.models.transformer as transformer
-from future_od.models.paper import (CDetrBackbone, CDetrDetectorSpatioTemporal, FuturePredCore,
+from future_od.models.paper import (JointEncoder, CDetrBackbone, CDetrDetectorSpatioTemporal, FuturePredCore,
                                     PositionalEncoder, SeparateEncoder)
 from future_od.models.st_detr import SpatioTemporalDETR, SpatioTemporalDETRArgs
 from future_od.native import functional as Fn
@@ -36,7 +36,10 @@ def build_model(args, detr_args: SpatioTemporalDETRArgs):
                 transformer.TransformerEncoderLayer(D=detr_args.hidden_dim, Nhead=detr_args.enc_nheads,
                                                     Dff=detr_args.dim_feedforward, use_egodeep=True)
                 for _ in range(detr_args.enc_layers)))),
-        joint_encoder=None,
+        joint_encoder=JointEncoder(transformer.TransformerEncoder(layers=nn.ModuleList(
+            transformer.TransformerEncoderLayer(D=detr_args.hidden_dim, Nhead=detr_args.enc_nheads,
+                                                Dff=detr_args.dim_feedforward, use_egodeep=False)
+            for _ in range(getattr(args, "joint_layers", 0))))) if getattr(args, "joint_layers", 0) else None,
         detector=CDetrDetectorSpatioTemporal(
             decoder=transformer.TransformerDecoder(
                 layers=nn.ModuleList([
