@@ -113,6 +113,17 @@ FOD_DEVINL void gemm_nt_body(const NtParams& p) {
   // bounds check), so that a tap adds or subtracts one uniform byte delta (tap_off below)
   unsigned a_base[4];
   int a_h[4], a_w[4];
+  // pixel (img, ph, pw) of this thread's first row by division, of the next three (+32 rows each) by stepping:
+  // eight 32-bit divisions per thread were ~0.5 us of every block's prologue
+  int px_img = 0, px_h = 0, px_w = 0;
+  if (MODE != MODE_DENSE) {
+    const int mfirst = m0 + r0;
+    const int hw = p.Hd * p.Wd;
+    px_img = mfirst / hw;
+    const int rem = mfirst - px_img * hw;
+    px_h = rem / p.Wd;
+    px_w = rem - px_h * p.Wd;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + r0 + 32 * i;
@@ -122,11 +133,15 @@ FOD_DEVINL void gemm_nt_body(const NtParams& p) {
       a_base[i] = valid ? (unsigned)((long)row * p.lda * (long)sizeof(T)) : OOB;
       a_h[i] = a_w[i] = 0;
     } else {
-      const int hw = p.Hd * p.Wd;
-      const int img = m / hw;
-      const int rem = m - img * hw;
-      const int ph = rem / p.Wd;
-      const int pw = rem - ph * p.Wd;
+      const int img = px_img, ph = px_h, pw = px_w;
+      px_w += 32;                                  // the next row of this thread
+      while (px_w >= p.Wd) {
+        px_w -= p.Wd;
+        if (++px_h == p.Hd) {
+          px_h = 0;
+          ++px_img;
+        }
+      }
       a_base[i] = (unsigned)((long)img * p.Hs * p.Ws * p.Cs * (long)sizeof(T));
       if (MODE == MODE_CONV) {
         a_h[i] = valid ? ph * p.stride - p.pad : -(1 << 28);
@@ -273,42 +288,49 @@ FOD_DEVINL void gemm_nt_body(const NtParams& p) {
   FOD_STAMP(2);
 
   const int fr = lane & 31, fh = lane >> 5;
-  auto compute = [&](int buf) {
+  // Fragment reads run ONE k-step ahead of the MFMAs that use them (two register sets): issued and waited for
+  // inside the same k-step, every k-step exposed the LDS latency before its four MFMAs -- with two waves per
+  // SIMD that was about a fifth of the k-loop (0.94 us per 64-deep tile under load).
+  auto read_frags = [&](int buf, int ks, Frag<T>* fa, Frag<T>* fb) {
     const unsigned char* a_s = sA + buf * BM * ROW_BYTES;
     const unsigned char* b_s = sB + buf * BN * ROW_BYTES;
 #pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = wm * 64 + i * 32 + fr;
+      if (sizeof(T) == 2) {
+        const uint4 v = *reinterpret_cast<const uint4*>(a_s + lds_off(row, 2 * ks + fh));
+        __builtin_memcpy(&fa[i], &v, 16);
+      } else {
+        const uint4 v0 = *reinterpret_cast<const uint4*>(a_s + lds_off(row, 4 * ks + 2 * fh));
+        const uint4 v1 = *reinterpret_cast<const uint4*>(a_s + lds_off(row, 4 * ks + 2 * fh + 1));
+        __builtin_memcpy(reinterpret_cast<char*>(&fa[i]), &v0, 16);
+        __builtin_memcpy(reinterpret_cast<char*>(&fa[i]) + 16, &v1, 16);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int row = wn * (32 * NT) + j * 32 + fr;
+      if (sizeof(T) == 2) {
+        const uint4 v = *reinterpret_cast<const uint4*>(b_s + lds_off(row, 2 * ks + fh));
+        __builtin_memcpy(&fb[j], &v, 16);
+      } else {
+        const uint4 v0 = *reinterpret_cast<const uint4*>(b_s + lds_off(row, 4 * ks + 2 * fh));
+        const uint4 v1 = *reinterpret_cast<const uint4*>(b_s + lds_off(row, 4 * ks + 2 * fh + 1));
+        __builtin_memcpy(reinterpret_cast<char*>(&fb[j]), &v0, 16);
+        __builtin_memcpy(reinterpret_cast<char*>(&fb[j]) + 16, &v1, 16);
+      }
+    }
+  };
+  auto compute = [&](int buf) {
+    Frag<T> fa[2][2], fb[2][NT];
+    read_frags(buf, 0, fa[0], fb[0]);
+#pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      Frag<T> fa[2], fb[NT];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = wm * 64 + i * 32 + fr;
-        if (sizeof(T) == 2) {
-          const uint4 v = *reinterpret_cast<const uint4*>(a_s + lds_off(row, 2 * ks + fh));
-          __builtin_memcpy(&fa[i], &v, 16);
-        } else {
-          const uint4 v0 = *reinterpret_cast<const uint4*>(a_s + lds_off(row, 4 * ks + 2 * fh));
-          const uint4 v1 = *reinterpret_cast<const uint4*>(a_s + lds_off(row, 4 * ks + 2 * fh + 1));
-          __builtin_memcpy(reinterpret_cast<char*>(&fa[i]), &v0, 16);
-          __builtin_memcpy(reinterpret_cast<char*>(&fa[i]) + 16, &v1, 16);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int row = wn * (32 * NT) + j * 32 + fr;
-        if (sizeof(T) == 2) {
-          const uint4 v = *reinterpret_cast<const uint4*>(b_s + lds_off(row, 2 * ks + fh));
-          __builtin_memcpy(&fb[j], &v, 16);
-        } else {
-          const uint4 v0 = *reinterpret_cast<const uint4*>(b_s + lds_off(row, 4 * ks + 2 * fh));
-          const uint4 v1 = *reinterpret_cast<const uint4*>(b_s + lds_off(row, 4 * ks + 2 * fh + 1));
-          __builtin_memcpy(reinterpret_cast<char*>(&fb[j]), &v0, 16);
-          __builtin_memcpy(reinterpret_cast<char*>(&fb[j]) + 16, &v1, 16);
-        }
-      }
+      if (ks + 1 < KSTEPS) read_frags(buf, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) mma16(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < NT; ++j) mma16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
     }
   };
   // step k: LDS buffer k&1 holds tile k; tile k+1 is in flight in ring[(k+1)%3]; issue tile k+2.

@@ -29,11 +29,11 @@ static void show(const char* what, int n) {
 }
 
 int main() {
-  const size_t big = 64u << 20;
-  void *a, *b, *c;
+  const size_t big = 640u << 20;
+  void *a, *b, *c_;
   float* bias;
-  hipMalloc(&a, big); hipMalloc(&b, big); hipMalloc(&c, big); hipMalloc((void**)&bias, 1 << 20);
-  hipMemset(a, 0, big); hipMemset(b, 0, big); hipMemset(c, 0, big); hipMemset(bias, 0, 1 << 20);
+  hipMalloc(&a, big); hipMalloc(&b, big); hipMalloc(&c_, big); hipMalloc((void**)&bias, 1 << 20);
+  hipMemset(a, 0, big); hipMemset(b, 0, big); hipMemset(c_, 0, big); hipMemset(bias, 0, 1 << 20);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   char name[64];
@@ -42,7 +42,7 @@ int main() {
   for (auto& s : shapes)
     for (int rep = 0; rep < 3; ++rep) {
       hipEventRecord(e0, 0);
-      int rc = fod_gemm_tn_acc(FOD_BF16, a, s[1], b, s[2], (float*)c, s[2], s[0], s[1], s[2], nullptr, nullptr, 0, 0);
+      int rc = fod_gemm_tn_acc(FOD_BF16, a, s[1], b, s[2], (float*)c_, s[2], s[0], s[1], s[2], nullptr, nullptr, 0, 0);
       hipEventRecord(e1, 0);
       hipDeviceSynchronize();
       float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -56,7 +56,7 @@ int main() {
   for (auto& s : shapes)
     for (int rep = 0; rep < 3; ++rep) {
       hipEventRecord(e0, 0);
-      int rc = fod_gemm_nt(FOD_BF16, a, s[2], 0, b, s[2], c, s[1], s[0], s[1], s[2], &epi, 0);
+      int rc = fod_gemm_nt(FOD_BF16, a, s[2], 0, b, s[2], c_, s[1], s[0], s[1], s[2], &epi, 0);
       hipEventRecord(e1, 0);
       hipDeviceSynchronize();
       float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -68,6 +68,25 @@ int main() {
         if (s[0] > 3000) printf("      epilogue: s3->s5 (acc to LDS) %.2f us, s5->s6 (barrier) %.2f us, s6->s4 (rows out) %.2f us\n",
                                 (h[5] - h[3]) * 0.01, (h[6] - h[5]) * 0.01, (h[4] - h[6]) * 0.01);
       }
+    }
+  // implicit-GEMM convolutions: {Nimg, H, W, Cin, Cout, k, stride, pad}
+  const int convs[][8] = {{10, 57, 100, 256, 256, 3, 1, 1}, {10, 225, 400, 64, 256, 1, 1, 0}, {10, 113, 200, 512, 128, 1, 1, 0}};
+  for (auto& c : convs)
+    for (int rep = 0; rep < 3; ++rep) {
+      fod_conv_geom g = {};
+      g.Nimg = c[0]; g.H = c[1]; g.W = c[2]; g.Cin = c[3]; g.Cout = c[4]; g.kh = g.kw = c[5]; g.stride = c[6]; g.pad = c[7];
+      g.Ho = (g.H + 2 * g.pad - g.kh) / g.stride + 1;
+      g.Wo = (g.W + 2 * g.pad - g.kw) / g.stride + 1;
+      fod_epilogue epi = {};
+      epi.shift = bias;
+      epi.relu = 1;
+      hipEventRecord(e0, 0);
+      int rc = fod_conv2d_fwd(FOD_BF16, a, b, c_, &g, &epi, 0);
+      hipEventRecord(e1, 0);
+      hipDeviceSynchronize();
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      snprintf(name, sizeof name, "conv %dx%d %d->%d k%d rc%d ev %.1fus", c[1], c[2], c[3], c[4], c[5], rc, ms * 1e3);
+      show(name, 5);
     }
 #endif
   return 0;
