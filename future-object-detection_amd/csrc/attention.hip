@@ -20,6 +20,9 @@
 #include "common.h"
 
 namespace {
+// 2^x as ONE v_exp_f32: exp2f() lowers to six instructions (range test, two selects, add, exp, ldexp) to keep
+// denormal results; every argument here is <= 0 and a result below 2^-126 may flush to zero.
+FOD_DEVINL float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 struct AttnParams {
   const void *q1, *k1, *q2, *k2, *v;
@@ -74,6 +77,12 @@ FOD_DEVINL void store_acc_t(T* rowptr, const f32x16& acc, int fh, float mul) {
 //         fragment pair and is address-unit bound).  64-byte LDS rows: the four rows of a 16-lane group land
 //         16 banks apart and the two column halves 8 banks apart -> conflict-free.
 //   Wave-private, so no barrier: LDS operations of one wave execute in order.
+// Byte offset of 16-byte chunk `chunk` (0..3) of row `row` in a wave's [32][64-byte] slab.  The chunk position is
+// XORed with (row >> 2): a lane-per-row writer (16 consecutive rows, one chunk) would otherwise put rows r, r+4,
+// r+8, r+12 on the same 16 banks (4-way conflict, SQ_LDS_BANK_CONFLICT ~1.7x the LDS issue cycles of the
+// backward kernels); the row-quad writers and the transposing reads see a uniform key and stay conflict-free.
+FOD_DEVINL int slab_at(int row, int chunk) { return row * 64 + ((chunk ^ (row >> 2)) & 3) * 16; }
+
 template <typename T>
 struct TransTile;
 template <>
@@ -86,6 +95,7 @@ struct TransTile<float> {
   }
   FOD_DEVINL void prefetch(const float* b, long st, int nr, int) { base = b; stride = st; nrows = nr; }
   FOD_DEVINL void commit(unsigned char*, int) {}
+  FOD_DEVINL void adopt(const unsigned char*) {}
   FOD_DEVINL void frag(Frag<float>& f, int s, int lane) const {
     frag_gather_accorder(f, base + (lane & 31), stride, s, lane >> 5, nrows);
   }
@@ -103,18 +113,18 @@ struct TransTile<__bf16> {
       pre[i] = *reinterpret_cast<const uint4*>(b + (long)min(row, max(nr, 1) - 1) * st + chunk * 8);
     }
   }
+  FOD_DEVINL void adopt(const unsigned char* slab) { lds = slab; }          // the caller wrote the slab itself
   FOD_DEVINL void commit(unsigned char* slab, int lane) {
     const int chunk = lane & 3;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(slab + ((lane >> 2) + 16 * i) * 64 + chunk * 16) = pre[i];
+    for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(slab + slab_at((lane >> 2) + 16 * i, chunk)) = pre[i];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     lds = slab;
   }
   // the tile is already in registers as the two natural fragments of row (lane & 31): write those
   FOD_DEVINL void from_frags(const Frag<__bf16>& f0, const Frag<__bf16>& f1, unsigned char* slab, int lane) {
-    unsigned char* q = slab + (lane & 31) * 64 + 16 * (lane >> 5);
-    *reinterpret_cast<Frag<__bf16>*>(q) = f0;
-    *reinterpret_cast<Frag<__bf16>*>(q + 32) = f1;
+    *reinterpret_cast<Frag<__bf16>*>(slab + slab_at(lane & 31, lane >> 5)) = f0;
+    *reinterpret_cast<Frag<__bf16>*>(slab + slab_at(lane & 31, 2 + (lane >> 5))) = f1;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     lds = slab;
   }
@@ -126,7 +136,7 @@ struct TransTile<__bf16> {
       const int rc = min(row, nr - 1);                      // clamped (nr >= 1), zeroed below if out of range
       uint4 v = *reinterpret_cast<const uint4*>(b + (long)rc * st + chunk * 8);
       if (row >= nr) v = make_uint4(0, 0, 0, 0);
-      *reinterpret_cast<uint4*>(slab + row * 64 + chunk * 16) = v;
+      *reinterpret_cast<uint4*>(slab + slab_at(row, chunk)) = v;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     lds = slab;
@@ -137,8 +147,9 @@ struct TransTile<__bf16> {
     const int col = 16 * (g & 1) + 4 * pp;
     const int r0 = 16 * s + 4 * h + q;
     typedef __attribute__((address_space(3))) short4_t* lds_s4;
-    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(lds + r0 * 64 + col * 2));
-    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(lds + (r0 + 8) * 64 + col * 2));
+    const int chunk = col >> 3, half = (col & 4) * 2;     // 16-byte chunk of the row and the 8-byte half within it
+    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(lds + slab_at(r0, chunk) + half));
+    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4)(lds + slab_at(r0 + 8, chunk) + half));
     short tmp[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     __builtin_memcpy(&f, tmp, 16);
   }
@@ -179,55 +190,167 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   float m = -INFINITY, l = 0.f;
   f32x16 oacc;
   zero_acc<T>(oacc);
-  __shared__ __attribute__((aligned(16))) unsigned char slab_v[4][2048];
+  __shared__ __attribute__((aligned(16))) unsigned char slab_v[4][2][2048];
   TransTile<T> tv;
 
   // (Requesting the next key tile one trip ahead, as the two backward passes do, was measured SLOWER here: at 4
   // waves per SIMD the other waves already cover the L2 round trip, the extra register copies and waits do not.)
-  for (int k0 = SPLIT ? wave * 32 : 0; k0 < p.S; k0 += SPLIT ? 128 : 32) {
-    const int kr = min(k0 + fr, p.S - 1);
-    f32x16 sacc;
-    zero_acc<T>(sacc);
+  if constexpr (!SPLIT) {
+    // 64 keys per trip (two 32-key score tiles): the running max, the rescale of O and the sum bookkeeping are paid
+    // once per 64 keys; the scale rides in the exponent's fma; only the last trip masks keys past S.  The loop is
+    // VALU-bound (16 exp2 per lane per 32 keys are quarter rate): per 32 keys ~170 -> ~90 instruction slots.
+    TransTile<T> tv2[2];
+    // Full trips (bf16) address K and V as a wave-uniform base that advances with k0 (scalar unit) plus per-lane
+    // byte offsets that never change: no per-trip vector multiplies (v_mul_lo / v_mad_u64 are quarter rate).
+    unsigned kofs[2][PARTS], vofs[2][2];
 #pragma unroll
-    for (int pt = 0; pt < PARTS; ++pt)
+    for (int t = 0; t < 2; ++t) {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        Frag<T> fk;
-        frag_load_contig(fk, Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)kr * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
-        mma16(fk, fq[pt][s], sacc);
+      for (int pt = 0; pt < PARTS; ++pt)
+        kofs[t][pt] = (unsigned)((32 * t + fr) * (int)(pt ? p.k2_ts : p.k_ts) + 8 * fh) * (unsigned)sizeof(T);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        vofs[t][i] = (unsigned)((32 * t + (lane >> 2) + 16 * i) * (int)p.v_ts + 8 * (lane & 3)) * (unsigned)sizeof(T);
+    }
+    for (int k0 = 0; k0 < p.S; k0 += 64) {
+      Frag<T> fk[2][PARTS][2];
+      if (sizeof(T) == 2 && k0 + 64 <= p.S) {
+        const unsigned char* vb = reinterpret_cast<const unsigned char*>(Vp + (long)k0 * p.v_ts);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+          for (int pt = 0; pt < PARTS; ++pt) {
+            const unsigned char* kb = reinterpret_cast<const unsigned char*>(
+                Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)k0 * (pt ? p.k2_ts : p.k_ts) + h * 32);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+              fk[t][pt][s] = *reinterpret_cast<const Frag<T>*>(kb + kofs[t][pt] + 32 * s);
+          }
+          uint4 v[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) v[i] = *reinterpret_cast<const uint4*>(vb + vofs[t][i]);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<uint4*>(slab_v[wave][t] + slab_at((lane >> 2) + 16 * i, lane & 3)) = v[i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < 2; ++t) tv2[t].adopt(slab_v[wave][t]);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int kr = min(k0 + 32 * t + fr, p.S - 1);
+#pragma unroll
+          for (int pt = 0; pt < PARTS; ++pt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+              frag_load_contig(fk[t][pt][s], Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)kr * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
+          const int kt = min(k0 + 32 * t, p.S - 1);            // an empty tile re-reads the last key (P = 0)
+          tv2[t].stage(Vp + (long)kt * p.v_ts, p.v_ts, p.S - kt, slab_v[wave][t], lane);
+        }
       }
-    float mx = -INFINITY;
+      f32x16 sacc[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const bool ok = (k0 + acc_row(r, lane)) < p.S;
-      sacc[r] = ok ? sacc[r] * c : -INFINITY;
-      mx = fmaxf(mx, sacc[r]);
+      for (int t = 0; t < 2; ++t) {
+        zero_acc<T>(sacc[t]);
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) mma16(fk[t][pt][s], fq[pt][s], sacc[t]);
+      }
+      if (k0 + 64 > p.S) {                       // last trip only: keys past S
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (k0 + 32 * t + acc_row(r, lane) >= p.S) sacc[t][r] = -INFINITY;
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[t][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m, mx * c);      // c > 0: the max of the scaled scores
+      const float alpha = ex2(m - m_new);
+      float rs = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          sacc[t][r] = ex2(fmaf(sacc[t][r], c, -m_new));
+          rs += sacc[t][r];
+        }
+      rs += __shfl_xor(rs, 32);
+      l = l * alpha + rs;
+      m = m_new;
+      if (__any(alpha != 1.f)) {                 // the running max settles after a few trips: skip the rescale then
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+      }
+      if (DROP) {                                // the row sums above are of the undropped probabilities
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[t][r] *= drop_gain(p, bh_seed, q0 + fr, k0 + 32 * t + acc_row(r, lane));
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          Frag<T> fp, fv;
+          frag_from_acc(fp, sacc[t], s);
+          tv2[t].frag(fv, s, lane);
+          mma16(fv, fp, oacc);
+        }
+      if (sizeof(T) == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next commit
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m, mx);
-    const float alpha = exp2f(m - m_new);
-    float rs = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      sacc[r] = exp2f(sacc[r] - m_new);
-      rs += sacc[r];
-    }
-    rs += __shfl_xor(rs, 32);
-    l = l * alpha + rs;
-    m = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
-    if (DROP) {                                  // the row sums above are of the undropped probabilities
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[r] *= drop_gain(p, bh_seed, q0 + fr, k0 + acc_row(r, lane));
-    }
-    tv.stage(Vp + (long)k0 * p.v_ts, p.v_ts, p.S - k0, slab_v[wave], lane);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      Frag<T> fp, fv;
-      frag_from_acc(fp, sacc, s);
-      tv.frag(fv, s, lane);
-      mma16(fv, fp, oacc);
+  } else {
+    for (int k0 = SPLIT ? wave * 32 : 0; k0 < p.S; k0 += SPLIT ? 128 : 32) {
+      const int kr = min(k0 + fr, p.S - 1);
+      f32x16 sacc;
+      zero_acc<T>(sacc);
+  #pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt)
+  #pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          Frag<T> fk;
+          frag_load_contig(fk, Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)kr * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
+          mma16(fk, fq[pt][s], sacc);
+        }
+      float mx = -INFINITY;
+  #pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool ok = (k0 + acc_row(r, lane)) < p.S;
+        sacc[r] = ok ? sacc[r] * c : -INFINITY;
+        mx = fmaxf(mx, sacc[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m, mx);
+      const float alpha = ex2(m - m_new);
+      float rs = 0.f;
+  #pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sacc[r] = ex2(sacc[r] - m_new);
+        rs += sacc[r];
+      }
+      rs += __shfl_xor(rs, 32);
+      l = l * alpha + rs;
+      m = m_new;
+  #pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+      if (DROP) {                                  // the row sums above are of the undropped probabilities
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] *= drop_gain(p, bh_seed, q0 + fr, k0 + acc_row(r, lane));
+      }
+      tv.stage(Vp + (long)k0 * p.v_ts, p.v_ts, p.S - k0, slab_v[wave][0], lane);
+  #pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        Frag<T> fp, fv;
+        frag_from_acc(fp, sacc, s);
+        tv.frag(fv, s, lane);
+        mma16(fv, fp, oacc);
+      }
     }
   }
   if (SPLIT) {
@@ -247,7 +370,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     l = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      sc[w] = exp2f(s_m[w][fr] - mstar);      // a wave that saw no key has m = -inf -> weight 0
+      sc[w] = ex2(s_m[w][fr] - mstar);      // a wave that saw no key has m = -inf -> weight 0
       l += s_l[w][fr] * sc[w];
     }
 #pragma unroll
@@ -312,17 +435,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   constexpr int KSTEP = SPLIT ? 128 : 32;
   const int kfirst = SPLIT ? wave * 32 : 0;
   Frag<T> fk_next[PARTS][2], fv_next[2];
-  auto request = [&](int k0) {
-    const int kr = min(k0 + fr, p.S - 1);
+  // Per-lane byte offsets of key row (k + fr) advance by a constant per trip and are clamped to the last row's
+  // offset: one add and one min per operand instead of a clamped row index times a stride (quarter-rate multiplies).
+  const unsigned char* Kb[2];
+  unsigned ko[PARTS], kmax[PARTS], kstep[PARTS];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+  for (int pt = 0; pt < PARTS; ++pt) {
+    const unsigned ts = (unsigned)(pt ? p.k2_ts : p.k_ts) * (unsigned)sizeof(T);
+    Kb[pt] = reinterpret_cast<const unsigned char*>(Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + h * 32);
+    ko[pt] = (unsigned)(kfirst + fr) * ts + 8 * fh * (unsigned)sizeof(T);
+    kmax[pt] = (unsigned)(p.S - 1) * ts + 8 * fh * (unsigned)sizeof(T);
+    kstep[pt] = KSTEP * ts;
+  }
+  const unsigned char* Vb = reinterpret_cast<const unsigned char*>(Vp);
+  const unsigned vts = (unsigned)p.v_ts * (unsigned)sizeof(T);
+  unsigned vo = (unsigned)(kfirst + fr) * vts + 8 * fh * (unsigned)sizeof(T);
+  const unsigned vmax = (unsigned)(p.S - 1) * vts + 8 * fh * (unsigned)sizeof(T), vstep = KSTEP * vts;
+  auto request = [&]() {
 #pragma unroll
-      for (int pt = 0; pt < PARTS; ++pt)
-        frag_load_contig(fk_next[pt][s], Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)kr * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
-      frag_load_contig(fv_next[s], Vp + (long)kr * p.v_ts + 16 * s + 8 * fh);
+    for (int pt = 0; pt < PARTS; ++pt) {
+      const unsigned o = min(ko[pt], kmax[pt]);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) fk_next[pt][s] = *reinterpret_cast<const Frag<T>*>(Kb[pt] + o + 16 * s * sizeof(T));
+      ko[pt] += kstep[pt];
     }
+    const unsigned o = min(vo, vmax);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) fv_next[s] = *reinterpret_cast<const Frag<T>*>(Vb + o + 16 * s * sizeof(T));
+    vo += vstep;
   };
-  if (kfirst < p.S) request(kfirst);
+  if (kfirst < p.S) request();
   for (int k0 = kfirst; k0 < p.S; k0 += KSTEP) {
     Frag<T> fk[PARTS][2], fv[2];
 #pragma unroll
@@ -331,7 +473,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
 #pragma unroll
       for (int pt = 0; pt < PARTS; ++pt) fk[pt][s] = fk_next[pt][s];
     }
-    request(k0 + KSTEP);
+    request();                                 // past the end: clamped re-reads of the last row, unused
     f32x16 sacc, dpacc;
     zero_acc<T>(sacc);
     zero_acc<T>(dpacc);
@@ -343,10 +485,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const bool ok = (k0 + acc_row(r, lane)) < p.S;
-      const float pr = ok ? exp2f(sacc[r] * c - lse2) : 0.f;
+      const float pr = ex2(fmaf(sacc[r], c, -lse2));
       const float dp = DROP ? dpacc[r] * drop_gain(p, bh_seed, q0 + fr, k0 + acc_row(r, lane)) : dpacc[r];
       sacc[r] = pr * (dp - dl) * p.scale;            // dS^T
+    }
+    if (k0 + 32 > p.S) {                             // last tile only: keys past S (clamped duplicates) add nothing
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (k0 + acc_row(r, lane) >= p.S) sacc[r] = 0.f;
     }
 #pragma unroll
     for (int pt = 0; pt < PARTS; ++pt) {
@@ -452,7 +598,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
       const int qq = q0 + acc_row(r, lane);
       const bool ok = qq < p.Tq;
       const int qc = ok ? qq : 0;
-      const float pr = ok ? exp2f(sacc[r] * c - lse_b[qc]) : 0.f;
+      const float pr = ok ? ex2(sacc[r] * c - lse_b[qc]) : 0.f;
       const float gain = DROP ? drop_gain(p, bh_seed, qq, k0 + fr) : 1.f;
       dpacc[r] = pr * (dpacc[r] * gain - del_b[qc]) * p.scale;   // dS
       sacc[r] = pr * gain;                                        // P after dropout (for dV)
@@ -536,32 +682,39 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_pf_kernel(const AttnParams p
     Frag<T> q[PARTS][2], d[2];
     float st;                       // lanes 0-31: lse of query q0 + lane, lanes 32-63: delta of query q0 + lane - 32
   };
-  auto request = [&](int q0, Tile& t) {
-    const int qr = min(q0 + fr, p.Tq - 1);
+  // byte offsets of query row (q + fr): advance by a constant per trip, clamped to the last row's offset
+  const unsigned qts = (unsigned)p.q_ts * 2u, ots = (unsigned)p.o_ts * 2u;
+  unsigned qo = (unsigned)fr * qts, oo = (unsigned)fr * ots, so = (unsigned)fr * 4u;
+  const unsigned qmax = (unsigned)(p.Tq - 1) * qts, omax = (unsigned)(p.Tq - 1) * ots, smax = (unsigned)(p.Tq - 1) * 4u;
+  const unsigned char* st_b = reinterpret_cast<const unsigned char*>(fh ? del_b : lse_b);
+  auto request = [&](Tile& t) {
+    const unsigned q_o = min(qo, qmax), o_o = min(oo, omax);
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
-      for (int pt = 0; pt < PARTS; ++pt) frag_load_contig(t.q[pt][s], Qb[pt] + (long)qr * p.q_ts + 16 * s);
-      frag_load_contig(t.d[s], dOb + (long)qr * p.o_ts + 16 * s);
+      for (int pt = 0; pt < PARTS; ++pt)
+        t.q[pt][s] = *reinterpret_cast<const Frag<T>*>(reinterpret_cast<const unsigned char*>(Qb[pt]) + q_o + 32 * s);
+      t.d[s] = *reinterpret_cast<const Frag<T>*>(reinterpret_cast<const unsigned char*>(dOb) + o_o + 32 * s);
     }
-    t.st = (fh ? del_b : lse_b)[qr];
+    t.st = *reinterpret_cast<const float*>(st_b + min(so, smax));
+    qo += 32 * qts; oo += 32 * ots; so += 128;
   };
   TransTile<T> tdo, tq[PARTS];
   tdo.lds = slab_q[wave][PARTS];
 #pragma unroll
   for (int pt = 0; pt < PARTS; ++pt) tq[pt].lds = slab_q[wave][pt];
-  const int slab_off = fr * 64 + 16 * fh;                // this lane's two 16-byte pieces of a row-major [32][32] tile
+  const int slab_off[2] = {slab_at(fr, fh), slab_at(fr, 2 + fh)};   // this lane's two 16-byte pieces of row fr
 
   Tile cur, nxt;
-  request(0, cur);
+  request(cur);
   for (int q0 = 0; q0 < p.Tq; q0 += 32) {
-    request(q0 + 32, nxt);                               // past the end: clamped re-reads of the last row, unused
+    request(nxt);                               // past the end: clamped re-reads of the last row, unused
     // tile t -> the wave's slabs (transposed operands) and its row statistics -> LDS
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      *reinterpret_cast<Frag<T>*>(slab_q[wave][PARTS] + slab_off + 32 * s) = cur.d[s];
+      *reinterpret_cast<Frag<T>*>(slab_q[wave][PARTS] + slab_off[s]) = cur.d[s];
 #pragma unroll
-      for (int pt = 0; pt < PARTS; ++pt) *reinterpret_cast<Frag<T>*>(slab_q[wave][pt] + slab_off + 32 * s) = cur.q[pt][s];
+      for (int pt = 0; pt < PARTS; ++pt) *reinterpret_cast<Frag<T>*>(slab_q[wave][pt] + slab_off[s]) = cur.q[pt][s];
     }
     stat[wave][fh][fr] = cur.st;
     f32x16 sacc, dpacc;
@@ -582,12 +735,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_pf_kernel(const AttnParams p
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
         const int qq = q0 + 8 * g + 4 * fh + e;
-        const bool ok = qq < p.Tq;
-        const float pr = ok ? exp2f(sacc[r] * c - ls[e]) : 0.f;
+        const float pr = ex2(fmaf(sacc[r], c, -ls[e]));
         const float gain = DROP ? drop_gain(p, bh_seed, qq, k0 + fr) : 1.f;
         dpacc[r] = pr * (dpacc[r] * gain - de[e]) * p.scale;   // dS
         sacc[r] = pr * gain;                                    // P after dropout (for dV)
       }
+    }
+    if (q0 + 32 > p.Tq) {                        // last tile only: queries past Tq (clamped duplicates) add nothing
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (q0 + acc_row(r, lane) >= p.Tq) { sacc[r] = 0.f; dpacc[r] = 0.f; }
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
