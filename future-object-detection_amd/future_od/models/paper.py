@@ -245,15 +245,35 @@ class JointEncoder(nn.Module):
         return self.transformer(tokens, pos, None)
 
 
+class JointEncoderSequential(nn.Module):
+    """Frame-by-frame joint encoding (reference paper.py:206-234): frame l runs through the encoder layers with
+    cross-attention onto the PREVIOUS frame's encoded output (`prevout_attn`) and onto the raw features of earlier
+    frames, most recent first (`previmage_attn`), plus that frame's IMU token.  Frames stay [B, N, D] slices of
+    the frame-major token tensor; no (h w)-first rearrangement exists here."""
+
+    def __init__(self, transformer: TransformerEncoder):
+        super().__init__()
+        self.transformer = transformer
+
+    def forward(self, frames, pos_of_frame, egodeep=None):
+        """frames: list of [B, N, D]; pos_of_frame(l) -> [N, D] table or [B, N, D]; egodeep [L, B, D] or None."""
+        outs, out, memory = [], None, []
+        for l, x in enumerate(frames):
+            out = self.transformer(x, pos_of_frame(l), None if egodeep is None else egodeep[l], prevout=out,
+                                   memory=memory)
+            memory = [x] + memory
+            outs.append(out)
+        return outs
+
+
 class FuturePredCore(nn.Module):
     """Drop the future frame, encode the past frames, decode the future detections (reference :432-485)."""
 
     def __init__(self, separate_encoder: SeparateEncoder, joint_encoder, detector: CDetrDetectorSpatioTemporal,
                  pos_encoder: PositionalEncoder):
         super().__init__()
-        if joint_encoder is not None and not isinstance(joint_encoder, JointEncoder):
-            raise NotImplementedError("JointEncoderSequential / JointEncoderF2F are not instantiated by the reference's "
-                                      "runs/ (SURVEY.md 8f-2): next")
+        if joint_encoder is not None and not isinstance(joint_encoder, (JointEncoder, JointEncoderSequential)):
+            raise NotImplementedError("JointEncoderF2F is not instantiated by the reference's runs/ (SURVEY.md 8f-2)")
         self.separate_encoder = separate_encoder
         self.joint_encoder = joint_encoder
         self.detector = detector
@@ -282,11 +302,15 @@ class FuturePredCore(nn.Module):
             offs = temporal_offsets[:, :past] if temporal_offsets is not None else None
             tt = self.pos_encoder.temporal_table(B, past, D, torch.float32, tokens.device, offs)[:, past - keep:]
             pos_all = lambda: (spatial.float()[None, None] + tt[:, :, None]).reshape(B, keep * N, D).to(self.compute_dtype)
-            pos_last = lambda: (spatial.float()[None] + tt[:, -1, None]).to(self.compute_dtype).contiguous()   # [B, N, D]
+            pos_at = lambda l: (spatial.float()[None] + tt[:, l, None]).to(self.compute_dtype).contiguous()    # [B, N, D]
         else:
             pos_all = lambda: spatial.repeat(keep, 1)                                             # [keep*N, D]
-            pos_last = lambda: spatial
-        if self.joint_encoder is not None:
+            pos_at = lambda l: spatial
+        pos_last = lambda: pos_at(keep - 1)
+        if isinstance(self.joint_encoder, JointEncoderSequential):
+            ego = _ego.view(keep, B, D) if _ego is not None else None
+            frames = self.joint_encoder(frames, pos_at, ego)
+        elif self.joint_encoder is not None:
             pa = pos_all()
             joint = self.joint_encoder(torch.cat(frames, dim=1) if keep > 1 else frames[0], pa)  # [B, keep*N, D]
             frames = list(joint.view(B, keep, N, D).unbind(1))

@@ -294,12 +294,18 @@ class EncoderAttention(nn.Module):
         self.D, self.H = Dsrc, num_heads
         self.droprate = droprate
 
-    def forward(self, src, pos):
-        """src [F,N,D]; pos table [N,D].  q = k = src + pos, v = src."""
+    def forward(self, src, pos, other=None):
+        """src [F,N,D]; pos table [N,D] or per-batch [F,N,D].  Self form: q = k = src + pos, v = src.  Cross form
+        (`other` [F,N,D]: the previous frame's output or an earlier frame's features, reference :464-478):
+        q = src + pos, k = other + pos, v = other."""
         D = self.D
-        N = pos.shape[0]
-        xp = Fn.add(src, pos, b_row_mod=N) if pos.dim() == 2 else Fn.add(src, pos)      # table, or per-batch encoding
-        q, k, v = Fn.in_proj(xp, src, self.attn.in_proj_weight, self.attn.in_proj_bias)
+        N = pos.shape[-2]
+        add_pos = (lambda t: Fn.add(t, pos, b_row_mod=N)) if pos.dim() == 2 else (lambda t: Fn.add(t, pos))
+        xp = add_pos(src)
+        if other is None:
+            q, k, v = Fn.in_proj(xp, src, self.attn.in_proj_weight, self.attn.in_proj_bias)
+        else:
+            q, k, v = Fn.in_proj_cross(xp, add_pos(other), other, self.attn.in_proj_weight, self.attn.in_proj_bias)
         a = Fn.attention(q, k, v, 1.0 / math.sqrt(D // self.H), drop_p=self.droprate, training=self.training)
         t, p = self.training, self.droprate
         src = Fn.layer_norm(src, self.norm1.weight, self.norm1.bias,
@@ -309,23 +315,30 @@ class EncoderAttention(nn.Module):
 
 
 class TransformerEncoderLayer(nn.Module):
+    """Reference transformer.py:422-487.  `use_prevout` / `num_previmages` add cross-attention blocks onto the
+    previous frame's output / earlier frames' features (only JointEncoderSequential feeds them)."""
+
     def __init__(self, D, Nhead, Dff=2048, droprate=0.1, num_previmages=0, use_prevout=False, use_egodeep=False):
         super().__init__()
-        if num_previmages or use_prevout:
-            raise NotImplementedError("prevout / previmage encoder attention is only used by "
-                                      "JointEncoderSequential, which runs/ never builds (SURVEY.md 8a a24)")
         self.self_attn = EncoderAttention(D, Nhead, Dff, droprate=droprate)
-        self.prevout_attn = None
-        self.previmage_attn = nn.ModuleList()
+        self.prevout_attn = EncoderAttention(D, Nhead, Dff, droprate=droprate) if use_prevout else None
+        self.previmage_attn = nn.ModuleList(
+            [EncoderAttention(D, Nhead, Dff, droprate=droprate) for _ in range(num_previmages)])
         if use_egodeep:
             self.egodeep_attend = EgodeepAttention(D, Nhead, droprate=droprate, Dff=Dff)
             self.norm_eda = nn.LayerNorm(D)
         else:
             self.egodeep_attend = None
 
-    def forward(self, x, pos, egodeep: Optional[Tensor] = None):
-        """x [F,N,D]; pos table [N,D]; egodeep [F,D] (one IMU token per frame) or None."""
+    def forward(self, x, pos, egodeep: Optional[Tensor] = None, prevout: Optional[Tensor] = None, memory=None):
+        """x [F,N,D]; pos table [N,D] or [F,N,D]; egodeep [F,D] (one IMU token per frame) or None; prevout [F,N,D]
+        or None; memory: list of [F,N,D] (most recent first) or None."""
         x = self.self_attn(x, pos)
+        if prevout is not None and self.prevout_attn is not None:
+            x = self.prevout_attn(x, pos, other=prevout)
+        if memory is not None:
+            for prev, attn in zip(memory, self.previmage_attn):
+                x = attn(x, pos, other=prev)
         if egodeep is not None and self.egodeep_attend is not None:
             N = x.shape[1]
             e = self.egodeep_attend.forward_single_key(egodeep)
@@ -342,7 +355,7 @@ class TransformerEncoder(nn.Module):
         self.layers = layers
         _reset_parameters(self.parameters())
 
-    def forward(self, x, pos, egodeep: Optional[Tensor] = None):
+    def forward(self, x, pos, egodeep: Optional[Tensor] = None, prevout: Optional[Tensor] = None, memory=None):
         for layer in self.layers:
-            x = layer(x, pos, egodeep)
+            x = layer(x, pos, egodeep, prevout, memory)
         return x

@@ -535,6 +535,44 @@ def in_proj(xp, src, weight, bias):
     return InProjFn.apply(xp.contiguous(), src.contiguous(), weight, bias)
 
 
+class InProjCrossFn(Function):
+    """The packed input projection with three different inputs (encoder cross-attention onto the previous output /
+    a previous frame, reference transformer.py:464-478: q-input = x + pos, k-input = other + pos, v-input = other).
+    Three GEMMs; the packed weight / bias still get ONE gradient tensor each."""
+
+    @staticmethod
+    def forward(ctx, xq, xk, xv, w, b):
+        D = w.shape[1]
+        dtype = xq.dtype
+        q = ops.gemm_nt(xq, prep_linear(w[:D], dtype, False), shift=b[:D]).view(xq.shape)
+        k = ops.gemm_nt(xk, prep_linear(w[D:2 * D], dtype, False), shift=b[D:2 * D]).view(xk.shape)
+        v = ops.gemm_nt(xv, prep_linear(w[2 * D:], dtype, False), shift=b[2 * D:]).view(xv.shape)
+        ctx.save_for_backward(xq, xk, xv)
+        ctx.w, ctx.b = w, b
+        return q, k, v
+
+    @staticmethod
+    def backward(ctx, dq, dk, dv):
+        xs = ctx.saved_tensors
+        w, b = ctx.w, ctx.b
+        D = w.shape[1]
+        dtype = xs[0].dtype
+        dw = zeros_f32((3 * D, D), xs[0].device)
+        db = zeros_f32((3 * D,), xs[0].device)
+        dxs = []
+        for i, (x, g) in enumerate(zip(xs, (dq, dk, dv))):
+            rows = x.numel() // D
+            g = g.contiguous().view(rows, D)
+            sl = slice(i * D, (i + 1) * D)
+            dxs.append(ops.gemm_nt(g, prep_linear(w[sl], dtype, True)).view(x.shape) if ctx.needs_input_grad[i] else None)
+            ops.gemm_tn_acc(g, x.view(rows, D), dw[sl], colsum=db[sl], zeroed=True)
+        return dxs[0], dxs[1], dxs[2], dw, db
+
+
+def in_proj_cross(xq, xk, xv, weight, bias):
+    return InProjCrossFn.apply(xq.contiguous(), xk.contiguous(), xv.contiguous(), weight, bias)
+
+
 class RefPointSineFn(Function):
     """ref_logit [R,2] -> (ref f32 [R,2] = sigmoid, sine [R,D] ordered (y | x))."""
 

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 import future_od.models.transformer as transformer
-from future_od.models.paper import (JointEncoder, CDetrBackbone, CDetrDetectorSpatioTemporal, FuturePredCore,
+from future_od.models.paper import (JointEncoder, JointEncoderSequential, CDetrBackbone, CDetrDetectorSpatioTemporal, FuturePredCore,
                                     PositionalEncoder, SeparateEncoder)
 from future_od.models.st_detr import SpatioTemporalDETR, SpatioTemporalDETRArgs
 from future_od.native import functional as Fn
@@ -20,6 +20,26 @@ from future_od.parallel import FodDataParallel
 
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32,
            torch.bfloat16: torch.bfloat16, torch.float32: torch.float32}
+
+
+def _joint_encoder(args, detr_args):
+    """None as the reference's runs/_model.py:52 passes, or (knobs of this package) `joint_layers` layers of
+    paper.py's JointEncoder (`joint_mode="joint"`: all frames' tokens at once) or JointEncoderSequential
+    (`joint_mode="sequential"`: frame by frame, `joint_prevout` / `joint_previmages` / `joint_egodeep` choosing
+    the cross-attention blocks of its layers, reference transformer.py:422-447)."""
+    n = getattr(args, "joint_layers", 0)
+    if not n:
+        return None
+    sequential = getattr(args, "joint_mode", "joint") == "sequential"
+    layers = nn.ModuleList(
+        transformer.TransformerEncoderLayer(
+            D=detr_args.hidden_dim, Nhead=detr_args.enc_nheads, Dff=detr_args.dim_feedforward,
+            num_previmages=getattr(args, "joint_previmages", 0) if sequential else 0,
+            use_prevout=bool(getattr(args, "joint_prevout", False)) and sequential,
+            use_egodeep=bool(getattr(args, "joint_egodeep", False)) and sequential)
+        for _ in range(n))
+    enc = transformer.TransformerEncoder(layers=layers)
+    return JointEncoderSequential(enc) if sequential else JointEncoder(enc)
 
 
 def build_model(args, detr_args: SpatioTemporalDETRArgs):
@@ -36,10 +56,7 @@ def build_model(args, detr_args: SpatioTemporalDETRArgs):
                 transformer.TransformerEncoderLayer(D=detr_args.hidden_dim, Nhead=detr_args.enc_nheads,
                                                     Dff=detr_args.dim_feedforward, use_egodeep=True)
                 for _ in range(detr_args.enc_layers)))),
-        joint_encoder=JointEncoder(transformer.TransformerEncoder(layers=nn.ModuleList(
-            transformer.TransformerEncoderLayer(D=detr_args.hidden_dim, Nhead=detr_args.enc_nheads,
-                                                Dff=detr_args.dim_feedforward, use_egodeep=False)
-            for _ in range(getattr(args, "joint_layers", 0))))) if getattr(args, "joint_layers", 0) else None,
+        joint_encoder=_joint_encoder(args, detr_args),
         detector=CDetrDetectorSpatioTemporal(
             decoder=transformer.TransformerDecoder(
                 layers=nn.ModuleList([

@@ -47,6 +47,10 @@ class Config:
     first_layer_special_when: str = "always"      # runs/_model.py:65
     image_memory_mode: str = "attend one at a time"  # runs/_model.py:68
     joint_layers: int = 0               # paper.py:180-203 JointEncoder (runs/_model.py:52 passes None); layers w/o IMU attention
+    joint_mode: str = "joint"           # "joint" = JointEncoder (paper.py:180-203), "sequential" = JointEncoderSequential (:206-234)
+    joint_previmages: int = 0           # sequential only: transformer.py:439-441 previmage_attn blocks per layer
+    joint_prevout: bool = False         # sequential only: transformer.py:435-438 prevout_attn
+    joint_egodeep: bool = False         # sequential only: transformer.py:442-447 IMU attention in the joint layers
     train_backbone: bool = True         # runs/_model.py:21 (lr_backbone > 0)
     # matcher / loss (st_detr.py:41-51)
     set_cost_class: float = 2.0
@@ -138,15 +142,31 @@ def param_spec(cfg: Config) -> Dict[str, tuple]:
             _lin(spec, p + "egodeep_attend.mlp.3", D, Dff)
             _ln(spec, p + "egodeep_attend.norm2", D)
             _ln(spec, p + "norm_eda", D)
-    for i in range(cfg.joint_layers):                                               # paper.py:180-183
+    def enc_attention(p):                                                           # transformer.py:401-413
+        spec[p + "attn.in_proj_weight"] = ((3 * D, D), "param")
+        spec[p + "attn.in_proj_bias"] = ((3 * D,), "param")
+        _lin(spec, p + "attn.out_proj", D, D)
+        _ln(spec, p + "norm1", D)
+        _lin(spec, p + "mlp.0", Dff, D)
+        _lin(spec, p + "mlp.3", D, Dff)
+        _ln(spec, p + "norm2", D)
+
+    seq = cfg.joint_mode == "sequential"
+    for i in range(cfg.joint_layers):                                               # paper.py:180-183, 206
         p = f"{P_JOINT}{i}."
-        spec[p + "self_attn.attn.in_proj_weight"] = ((3 * D, D), "param")
-        spec[p + "self_attn.attn.in_proj_bias"] = ((3 * D,), "param")
-        _lin(spec, p + "self_attn.attn.out_proj", D, D)
-        _ln(spec, p + "self_attn.norm1", D)
-        _lin(spec, p + "self_attn.mlp.0", Dff, D)
-        _lin(spec, p + "self_attn.mlp.3", D, Dff)
-        _ln(spec, p + "self_attn.norm2", D)
+        enc_attention(p + "self_attn.")
+        if seq and cfg.joint_prevout:                                               # transformer.py:435-436
+            enc_attention(p + "prevout_attn.")
+        for j in range(cfg.joint_previmages if seq else 0):                         # transformer.py:439-441
+            enc_attention(p + f"previmage_attn.{j}.")
+        if seq and cfg.joint_egodeep:                                               # transformer.py:442-445
+            for nm in ("query_content", "query_pos", "key", "value", "fun.out_proj"):
+                _lin(spec, p + "egodeep_attend." + nm, D, D)
+            _ln(spec, p + "egodeep_attend.norm1", D)
+            _lin(spec, p + "egodeep_attend.mlp.0", Dff, D)
+            _lin(spec, p + "egodeep_attend.mlp.3", D, Dff)
+            _ln(spec, p + "egodeep_attend.norm2", D)
+            _ln(spec, p + "norm_eda", D)
     for i in range(cfg.dec_layers):
         p = f"{P_DEC}layers.{i}."
         for n in ("query_content", "query_pos", "key_content", "key_pos", "value", "fun.out_proj"):
@@ -347,14 +367,28 @@ def egodeep_attention(sd, key, cfg, q_content, q_pos, ego, with_mlp):
     return out
 
 
-def encoder_layer(sd, cfg, i, x, pos, ego, prefix=None):
-    """x,pos (N,Bf,D); ego (S,Bf,D) or None.  transformer.py:449-487."""
+def encoder_attention(sd, cfg, key, src, q_in, k_in, v_in):
+    """EncoderAttention.forward, transformer.py:415-419."""
+    a = stock_mha(sd, key + ".attn", q_in, k_in, v_in, cfg.nheads)
+    x = _lnorm(sd, key + ".norm1", src + a)                          # transformer.py:417
+    h = F.relu(_linear(sd, key + ".mlp.0", x))
+    return _lnorm(sd, key + ".norm2", x + _linear(sd, key + ".mlp.3", h))
+
+
+def encoder_layer(sd, cfg, i, x, pos, ego, prefix=None, prevout=None, memory=None):
+    """x,pos (N,Bf,D); ego (S,Bf,D) or None; prevout (N,Bf,D) or None; memory: list of (N,Bf,D), most recent
+    first, or None.  transformer.py:449-487."""
     p = f"{prefix or P_ENC}{i}."
-    qk = x + pos
-    a = stock_mha(sd, p + "self_attn.attn", qk, qk, x, cfg.nheads)
-    x = _lnorm(sd, p + "self_attn.norm1", x + a)                     # transformer.py:417
-    h = F.relu(_linear(sd, p + "self_attn.mlp.0", x))
-    x = _lnorm(sd, p + "self_attn.norm2", x + _linear(sd, p + "self_attn.mlp.3", h))
+    x = encoder_attention(sd, cfg, p + "self_attn", x, x + pos, x + pos, x)
+    if prevout is not None and (p + "prevout_attn.attn.in_proj_weight") in sd:        # transformer.py:463-469
+        x = encoder_attention(sd, cfg, p + "prevout_attn", x, x + pos, prevout + pos, prevout)
+    if memory is not None:                                                            # transformer.py:470-478 (zip)
+        for j, prev in enumerate(memory):
+            if (p + f"previmage_attn.{j}.attn.in_proj_weight") not in sd:
+                break
+            x = encoder_attention(sd, cfg, p + f"previmage_attn.{j}", x, x + pos, prev + pos, prev)
+    if ego is not None and (p + "egodeep_attend.key.weight") not in sd:
+        ego = None                                                    # layer built with use_egodeep=False
     if ego is not None and cfg.use_imu:
         e = egodeep_attention(sd, p + "egodeep_attend", cfg, x, pos, ego, with_mlp=True)
         x = _lnorm(sd, p + "norm_eda", x + e)                         # transformer.py:485-486
@@ -521,7 +555,20 @@ def core_forward(sd, cfg, images, imu=None, temporal_offsets=None, skip_dead=Fal
     pos = spatial_pos_table(h, w, D, feat.device)[None, None].expand(B, L, -1, -1, -1)
     if not cfg.no_temporal:
         pos = pos + temporal_pos_table(B, L, h, w, D, temporal_offsets, device=feat.device)
-    if cfg.joint_layers:                                               # paper.py:193-198, layers without IMU attention
+    if cfg.joint_layers and cfg.joint_mode == "sequential":           # paper.py:219-234
+        xs = feat.permute(1, 3, 4, 0, 2).flatten(1, 2)                 # l (h w) b c
+        ps = pos.permute(1, 3, 4, 0, 2).flatten(1, 2)
+        outs, out, memory = [], None, []
+        for l in range(L):
+            ego_l = _ego[:, l][None] if _ego is not None else None    # (1, B, D): paper.py:221
+            x = xs[l]
+            for i in range(cfg.joint_layers):                          # TransformerEncoder.forward, :503-511
+                x = encoder_layer(sd, cfg, i, x, ps[l], ego_l, prefix=P_JOINT, prevout=out, memory=memory)
+            out = x
+            memory = [xs[l]] + memory
+            outs.append(out)
+        feat = torch.stack(outs, 0).view(L, h, w, B, D).permute(3, 0, 4, 1, 2)
+    elif cfg.joint_layers:                                             # paper.py:193-198, layers without IMU attention
         x = feat.permute(3, 4, 1, 0, 2).flatten(0, 2)                 # (h w l) b c
         pj = pos.permute(3, 4, 1, 0, 2).flatten(0, 2)
         for i in range(cfg.joint_layers):

@@ -52,6 +52,21 @@ def import_reference():
     return paper, transformer, st_detr, set_criterion, od_map
 
 
+def joint_encoder(cfg: Config, paper, transformer):
+    """None (runs/_model.py:52), paper.JointEncoder, or paper.JointEncoderSequential with the reference's own
+    TransformerEncoderLayer options (transformer.py:423-447)."""
+    if not cfg.joint_layers:
+        return None
+    seq = cfg.joint_mode == "sequential"
+    enc = transformer.TransformerEncoder(layers=nn.ModuleList(
+        transformer.TransformerEncoderLayer(D=cfg.hidden_dim, Nhead=cfg.nheads, Dff=cfg.dim_feedforward,
+                                            num_previmages=cfg.joint_previmages if seq else 0,
+                                            use_prevout=cfg.joint_prevout and seq,
+                                            use_egodeep=cfg.joint_egodeep and seq)
+        for _ in range(cfg.joint_layers)))
+    return paper.JointEncoderSequential(enc) if seq else paper.JointEncoder(enc)
+
+
 def build_reference(cfg: Config, paper, transformer, st_detr):
     """The graph of runs/_model.py:14-74 with its literals replaced by cfg."""
     args = st_detr.SpatioTemporalDETRArgs(
@@ -70,10 +85,7 @@ def build_reference(cfg: Config, paper, transformer, st_detr):
             imu_layers=nn.Sequential(nn.Linear(cfg.imu_dim, cfg.imu_hidden), nn.ReLU(inplace=True),
                                      nn.Linear(cfg.imu_hidden, cfg.hidden_dim)) if cfg.use_imu else None,
             transformer=enc),
-        joint_encoder=paper.JointEncoder(transformer.TransformerEncoder(layers=nn.ModuleList(
-            transformer.TransformerEncoderLayer(D=cfg.hidden_dim, Nhead=cfg.nheads, Dff=cfg.dim_feedforward,
-                                                use_egodeep=False)
-            for _ in range(cfg.joint_layers)))) if cfg.joint_layers else None,
+        joint_encoder=joint_encoder(cfg, paper, transformer),
         detector=paper.CDetrDetectorSpatioTemporal(
             decoder=transformer.TransformerDecoder(
                 layers=nn.ModuleList([
@@ -171,6 +183,11 @@ def main():
                                               no_temporal=False), 2, 4, 64, 96, 15),
         "g13_joint_encoder": (Config(backbone="resnet18", enc_layers=1, joint_layers=1, dec_layers=1, num_images=2,
                                      no_temporal=False), 2, 4, 64, 96, 16),
+        # JointEncoderSequential: frame by frame with attention onto the previous output, two earlier frames and the
+        # frame's IMU token (paper.py:206-234, transformer.py:463-487)
+        "g14_joint_sequential": (Config(backbone="resnet18", enc_layers=1, joint_layers=2, joint_mode="sequential",
+                                        joint_previmages=2, joint_prevout=True, joint_egodeep=True, dec_layers=1,
+                                        num_images=2, no_temporal=False), 2, 5, 64, 96, 17),
     }
     for name, (cfg, B, L, H, W, seed) in cases.items():
         if ONLY and name not in ONLY:

@@ -19,10 +19,22 @@ DEV = "cuda:0"
 
 if torch.cuda.is_available():
     import future_od.models.transformer as T
-    from future_od.models.paper import (CDetrBackbone, CDetrDetectorSpatioTemporal, FuturePredCore, JointEncoder,
+    from future_od.models.paper import (CDetrBackbone, CDetrDetectorSpatioTemporal, FuturePredCore, JointEncoder, JointEncoderSequential,
                                         PositionalEncoder, SeparateEncoder)
     from future_od.models.st_detr import SpatioTemporalDETR, SpatioTemporalDETRArgs
     from future_od.native import functional as Fn
+
+
+def build_joint(cfg: Config):
+    if not cfg.joint_layers:
+        return None
+    seq = cfg.joint_mode == "sequential"
+    enc = T.TransformerEncoder(nn.ModuleList(
+        T.TransformerEncoderLayer(cfg.hidden_dim, cfg.nheads, cfg.dim_feedforward,
+                                  num_previmages=cfg.joint_previmages if seq else 0,
+                                  use_prevout=cfg.joint_prevout and seq, use_egodeep=cfg.joint_egodeep and seq)
+        for _ in range(cfg.joint_layers)))
+    return JointEncoderSequential(enc) if seq else JointEncoder(enc)
 
 
 def build_product(cfg: Config, dtype, seed):
@@ -40,9 +52,7 @@ def build_product(cfg: Config, dtype, seed):
             transformer=T.TransformerEncoder(nn.ModuleList(
                 T.TransformerEncoderLayer(cfg.hidden_dim, cfg.nheads, cfg.dim_feedforward, use_egodeep=cfg.use_imu)
                 for _ in range(cfg.enc_layers)))),
-        joint_encoder=JointEncoder(T.TransformerEncoder(nn.ModuleList(
-            T.TransformerEncoderLayer(cfg.hidden_dim, cfg.nheads, cfg.dim_feedforward, use_egodeep=False)
-            for _ in range(cfg.joint_layers)))) if cfg.joint_layers else None,
+        joint_encoder=build_joint(cfg),
         detector=CDetrDetectorSpatioTemporal(
             decoder=T.TransformerDecoder(nn.ModuleList(
                 [T.TransformerDecoderLayer(cfg.hidden_dim, cfg.nheads, cfg.dim_feedforward, 0.1, cfg.num_images)
@@ -72,6 +82,9 @@ CASES = {
                                          no_temporal=False),
     "g13_joint_encoder": Config(backbone="resnet18", enc_layers=1, joint_layers=1, dec_layers=1, num_images=2,
                                 no_temporal=False),
+    "g14_joint_sequential": Config(backbone="resnet18", enc_layers=1, joint_layers=2, joint_mode="sequential",
+                                   joint_previmages=2, joint_prevout=True, joint_egodeep=True, dec_layers=1,
+                                   num_images=2, no_temporal=False),
 }
 
 

@@ -74,6 +74,9 @@ CASES = {
                                          no_temporal=False),
     "g13_joint_encoder": Config(backbone="resnet18", enc_layers=1, joint_layers=1, dec_layers=1, num_images=2,
                                 no_temporal=False),
+    "g14_joint_sequential": Config(backbone="resnet18", enc_layers=1, joint_layers=2, joint_mode="sequential",
+                                   joint_previmages=2, joint_prevout=True, joint_egodeep=True, dec_layers=1,
+                                   num_images=2, no_temporal=False),
 }
 
 
