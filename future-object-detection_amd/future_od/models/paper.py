@@ -186,13 +186,32 @@ class CDetrDetectorSpatioTemporal(nn.Module):
         self.image_memory_mode = image_memory_mode
         self.num_images = len(self.decoder.layers[0].image_attend)
         assert all(self.num_images == len(layer.image_attend) for layer in self.decoder.layers)
-        self.use_slotstates = False
+        self.use_slotstates = self.decoder.layers[0].slotstates_attend is not None
+        assert all(self.use_slotstates == (layer.slotstates_attend is not None) for layer in self.decoder.layers)
+        self.use_egodeep = self.decoder.layers[0].egodeep_attend is not None
+        if self.use_egodeep and image_memory_mode == "attend all at once":
+            raise NotImplementedError("decoder-side IMU attention over the tokens of ALL frames (only the "
+                                      "one-token-per-frame form is built)")
 
     def frames_needed(self, L):
-        """Past frames that can reach the output: all of them when they form one memory, else the last num_images."""
-        return L if self.image_memory_mode == "attend all at once" else min(self.num_images, L)
+        """Past frames that can reach the output: all of them when they form one memory or when slot states carry
+        every frame's queries forward, else the last num_images."""
+        if self.image_memory_mode == "attend all at once" or self.use_slotstates:
+            return L
+        return min(self.num_images, L)
 
-    def forward(self, frame_tokens: List[Tensor], pos, num_frames_total: int):
+    def forward_recurrent(self, frame_tokens: List[Tensor], pos_of_frame, egodeep=None):
+        """The reference's sweep over every past frame (paper.py:340-350) when it is live: the final queries of
+        frame l are the slot states of frame l+1 (paper.py:396-399).  egodeep [L,B,D] or None."""
+        out, prev, slot = None, [], None
+        for l, x in enumerate(frame_tokens):
+            mems = [x] + prev
+            out, slot = self.detect(mems, pos_of_frame(l), l == 0, slot,
+                                    egodeep[l] if (egodeep is not None and self.use_egodeep) else None)
+            prev = mems[: self.num_images - 1]
+        return out
+
+    def forward(self, frame_tokens: List[Tensor], pos, num_frames_total: int, egodeep=None):
         """frame_tokens: the LAST frames of the clip, oldest first, each [B,N,D].
         'attend one at a time' (reference paper.py:340-350): `pos` = encoding of the current (last) frame, [N,D]
         or [B,N,D]; equivalent to the reference's sweep over all frames keeping the last result.
@@ -202,12 +221,13 @@ class CDetrDetectorSpatioTemporal(nn.Module):
         if self.image_memory_mode == "attend all at once":
             assert K == num_frames_total, "every past frame is part of the memory"
             mem = torch.cat(frame_tokens, dim=1) if K > 1 else frame_tokens[0]
-            return self.detect([mem], pos, True)
+            return self.detect([mem], pos, True)[0]
         first_frame = num_frames_total == 1
         mems = [frame_tokens[K - 1 - j] for j in range(min(K, self.num_images))]   # current, then previous
-        return self.detect(mems, pos, first_frame)
+        return self.detect(mems, pos, first_frame, None, egodeep if self.use_egodeep else None)[0]
 
-    def detect(self, mems, pos_table, first_frame=True):
+    def detect(self, mems, pos_table, first_frame=True, slotstates=None, egodeep=None):
+        """-> (outputs, final queries [B,M,D] = the next frame's slot states)."""
         B, N, D = mems[0].shape
         dtype = mems[0].dtype
         M = self.query_embed.weight.shape[0]
@@ -215,7 +235,8 @@ class CDetrDetectorSpatioTemporal(nn.Module):
         x0 = torch.zeros((B, M, D), dtype=dtype, device=qpos.device)
         special = (first_frame and self._first_layer_special_when == "first frame") or \
             self._first_layer_special_when == "always"
-        hs, ref = self.decoder(x0, qpos, mems, [pos_table] * len(mems), first_layer_special=special)
+        hs, ref = self.decoder(x0, qpos, mems, [pos_table] * len(mems), first_layer_special=special,
+                               slotstates=slotstates, egodeep=egodeep)
         Lv = hs.shape[0]
         logits = Fn.linear(hs, self.class_embed.weight, self.class_embed.bias, out_f32=True)      # [Lv,B,M,C] f32
         t = self.bbox_embed(hs)                                                                    # [Lv,B,M,4]
@@ -224,7 +245,7 @@ class CDetrDetectorSpatioTemporal(nn.Module):
         if self.aux_loss:
             out["aux_outputs"] = [{"pred_logits": a, "pred_boxes": b} for a, b in zip(logits[:-1], boxes[:-1])]
         out["_stacked"] = (logits, boxes)          # all levels, final level last (private fast path)
-        return out
+        return out, hs[-1]
 
 
 class JointEncoder(nn.Module):
@@ -308,12 +329,16 @@ class FuturePredCore(nn.Module):
             pos_at = lambda l: spatial
         pos_last = lambda: pos_at(keep - 1)
         if isinstance(self.joint_encoder, JointEncoderSequential):
-            ego = _ego.view(keep, B, D) if _ego is not None else None
-            frames = self.joint_encoder(frames, pos_at, ego)
+            frames = self.joint_encoder(frames, pos_at, _ego.view(keep, B, D) if _ego is not None else None)
         elif self.joint_encoder is not None:
             pa = pos_all()
             joint = self.joint_encoder(torch.cat(frames, dim=1) if keep > 1 else frames[0], pa)  # [B, keep*N, D]
             frames = list(joint.view(B, keep, N, D).unbind(1))
-        out = self.detector(frames, pos_all() if all_at_once else pos_last(), num_frames_total=past)
+        ego = _ego.view(keep, B, D) if _ego is not None else None
+        if self.detector.use_slotstates and not all_at_once:
+            out = self.detector.forward_recurrent(frames, pos_at, ego)
+        else:
+            out = self.detector(frames, pos_all() if all_at_once else pos_last(), num_frames_total=past,
+                                egodeep=ego[-1] if ego is not None else None)
         moods = [["model happy" for _ in range(L)] for _ in range(B)]
         return out, moods

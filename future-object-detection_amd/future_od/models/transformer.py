@@ -90,6 +90,17 @@ class SlotToSlotAttention(Attention):
         a = Fn.attention(q, k, v, 1.0 / math.sqrt(self.D // self.Nhead), drop_p=self.droprate, training=self.training)
         return _lin(a, self.fun.out_proj)
 
+    def forward_cross(self, x, qpos, other):
+        """Queries attend to another query set `other` [B,M,D] that shares their positions (the previous frame's
+        final queries, reference transformer.py:288-296 with key_pos = query_pos, :368)."""
+        M = qpos.shape[0]
+        qc = _lin(x, self.query_content)
+        kc, v = Fn.group_linear(other, [self.key_content, self.value])
+        q = Fn.add(qc, _lin(qpos, self.query_pos), b_row_mod=M)
+        k = Fn.add(kc, _lin(qpos, self.key_pos), b_row_mod=M)
+        a = Fn.attention(q, k, v, 1.0 / math.sqrt(self.D // self.Nhead), drop_p=self.droprate, training=self.training)
+        return _lin(a, self.fun.out_proj)
+
 
 class EgodeepAttention(nn.Module):
     """Attention to the per-frame IMU token(s) (reference transformer.py:85-119).
@@ -185,23 +196,29 @@ class TransformerDecoderLayer(nn.Module):
 
     def __init__(self, D, Nhead, Dff=2048, dropout=0.1, num_images=1, use_slotstates=False, use_egodeep=False):
         super().__init__()
-        if use_slotstates or use_egodeep:
-            raise NotImplementedError("slot-state recurrence / decoder-side IMU attention are never "
-                                      "instantiated by the reference's runs/ (SURVEY.md 8a a24)")
         self.self_attend = SlotToSlotAttention(D, Nhead, dropout)
         self.norm_sa = nn.LayerNorm(D)
         self.image_attend = nn.ModuleList([SlotToImageAttention(D, Nhead, dropout) for _ in range(num_images)])
         self.norm_ia = nn.ModuleList([nn.LayerNorm(D) for _ in range(num_images)])
-        self.slotstates_attend = None
-        self.egodeep_attend = None
+        if use_slotstates:                 # attention to the previous frame's final queries (reference :210-215)
+            self.slotstates_attend = SlotToSlotAttention(D, Nhead, dropout)
+            self.norm_ssa = nn.LayerNorm(D)
+        else:
+            self.slotstates_attend = None
+        if use_egodeep:                    # attention to the frame's IMU token, no MLP (reference :217-222)
+            self.egodeep_attend = EgodeepAttention(D, Nhead, droprate=dropout, Dff=None)
+            self.norm_eda = nn.LayerNorm(D)
+        else:
+            self.egodeep_attend = None
         self.feedforward = nn.Sequential(nn.Linear(D, Dff), nn.ReLU(inplace=True), nn.Dropout(dropout),
                                          nn.Linear(Dff, D))
         self.norm_out = nn.LayerNorm(D)
         self.Nhead, self.D = Nhead, D
         self.droprate = dropout            # dropout_sa / dropout_ia / dropout_out and the feed-forward's (reference :201-234)
 
-    def forward(self, x, qpos, query_sine, side, layer, is_first=False, pos_proj=None):
-        """`pos_proj` (from TransformerDecoder): {"sa": (query_pos(qpos), key_pos(qpos)), "ca": [query_pos_i(qpos)]}."""
+    def forward(self, x, qpos, query_sine, side, layer, is_first=False, pos_proj=None, slotstates=None, egodeep=None):
+        """`pos_proj` (from TransformerDecoder): {"sa": (query_pos(qpos), key_pos(qpos)), "ca": [query_pos_i(qpos)]};
+        slotstates [B,M,D] or None; egodeep [B,D] (ONE IMU token per sample) or None."""
         t, p = self.training, self.droprate
         o = self.self_attend(x, qpos, pos_proj["sa"] if pos_proj else None)
         x = Fn.layer_norm(x, self.norm_sa.weight, self.norm_sa.bias, residual=Fn.dropout(o, p, t))
@@ -211,6 +228,15 @@ class TransformerDecoderLayer(nn.Module):
             o = self.image_attend[i](x, qpos, query_sine, side, layer, i, is_first, qs=qs_all[i],
                                      qpos_proj=pos_proj["ca"][i] if (pos_proj and is_first) else None)
             x = Fn.layer_norm(x, self.norm_ia[i].weight, self.norm_ia[i].bias, residual=Fn.dropout(o, p, t))
+        if self.slotstates_attend is not None and slotstates is not None:
+            o = self.slotstates_attend.forward_cross(x, qpos, slotstates)
+            x = Fn.layer_norm(x, self.norm_ssa.weight, self.norm_ssa.bias, residual=Fn.dropout(o, p, t))
+        if self.egodeep_attend is not None and egodeep is not None:
+            # one key: the attention output is the same row for every query of a sample (see EgodeepAttention)
+            e = Fn.dropout(self.egodeep_attend.forward_single_key(egodeep), p, t)
+            x = Fn.layer_norm(x, self.norm_eda.weight, self.norm_eda.bias, residual=e, res_row_div=x.shape[1])
+            if torch.is_grad_enabled():
+                x = Fn.ZeroGradAnchor.apply(x, *self.egodeep_attend.dead_parameters())
         h = Fn.dropout(_lin(x, self.feedforward[0], relu=True), p, t)
         return Fn.layer_norm(x, self.norm_out.weight, self.norm_out.bias,
                              residual=Fn.dropout(_lin(h, self.feedforward[3]), p, t))
@@ -233,8 +259,9 @@ class TransformerDecoder(nn.Module):
         self.ref_point_head = MLP(D, D, 2, 2)
         _reset_parameters(self.parameters())
 
-    def forward(self, x, qpos, mems, mem_poss, first_layer_special=True):
-        """x [B,M,D] query content; qpos [M,D] learned query positions (shared by the batch)."""
+    def forward(self, x, qpos, mems, mem_poss, first_layer_special=True, slotstates=None, egodeep=None):
+        """x [B,M,D] query content; qpos [M,D] learned query positions (shared by the batch); slotstates [B,M,D]
+        (previous frame's final queries) or None; egodeep [B,D] or None."""
         B, M, D = x.shape
         ref, sine0 = Fn.RefPointSineFn.apply(self.ref_point_head(qpos), D)     # [M,2] f32, [M,D]
         # memory side, hoisted out of the layer loop: one GEMM per image for every layer's value /
@@ -260,7 +287,8 @@ class TransformerDecoder(nn.Module):
                 q_sine = sine0
             else:
                 q_sine = Fn.mul(self.query_scale(x).view(B * M, D), sine0, b_row_mod=M).view(B, M, D)
-            x = layer(x, qpos, q_sine, side, lid, is_first=special, pos_proj=pos_proj)
+            x = layer(x, qpos, q_sine, side, lid, is_first=special, pos_proj=pos_proj, slotstates=slotstates,
+                      egodeep=egodeep)
             if self.return_intermediate:
                 inter.append(Fn.layer_norm(x, self.norm.weight, self.norm.bias))
         if not self.return_intermediate:

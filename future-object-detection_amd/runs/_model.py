@@ -62,7 +62,9 @@ def build_model(args, detr_args: SpatioTemporalDETRArgs):
                 layers=nn.ModuleList([
                     transformer.TransformerDecoderLayer(D=detr_args.hidden_dim, Nhead=detr_args.nheads,
                                                         Dff=detr_args.dim_feedforward, dropout=0.1,
-                                                        num_images=num_images, use_slotstates=False)
+                                                        num_images=num_images,
+                                                        use_slotstates=bool(getattr(args, "dec_slotstates", False)),
+                                                        use_egodeep=bool(getattr(args, "dec_egodeep", False)))
                     for _ in range(detr_args.dec_layers)]),
                 norm=nn.LayerNorm(detr_args.hidden_dim), return_intermediate=True, D=detr_args.hidden_dim),
             num_classes=detr_args.num_classes, hidden_dim=detr_args.hidden_dim,

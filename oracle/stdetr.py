@@ -51,6 +51,8 @@ class Config:
     joint_previmages: int = 0           # sequential only: transformer.py:439-441 previmage_attn blocks per layer
     joint_prevout: bool = False         # sequential only: transformer.py:435-438 prevout_attn
     joint_egodeep: bool = False         # sequential only: transformer.py:442-447 IMU attention in the joint layers
+    dec_slotstates: bool = False        # transformer.py:210-215 decoder layers attend to the previous frame's final queries
+    dec_egodeep: bool = False           # transformer.py:217-222 decoder layers attend to the frame's IMU token
     train_backbone: bool = True         # runs/_model.py:21 (lr_backbone > 0)
     # matcher / loss (st_detr.py:41-51)
     set_cost_class: float = 2.0
@@ -180,6 +182,14 @@ def param_spec(cfg: Config) -> Dict[str, tuple]:
             for n in names:
                 _lin(spec, q + n, D, D)
             _ln(spec, f"{p}norm_ia.{j}", D)
+        if cfg.dec_slotstates:                                                       # transformer.py:210-213
+            for n in ("query_content", "query_pos", "key_content", "key_pos", "value", "fun.out_proj"):
+                _lin(spec, p + "slotstates_attend." + n, D, D)
+            _ln(spec, p + "norm_ssa", D)
+        if cfg.dec_egodeep:                                                          # transformer.py:217-220 (Dff=None)
+            for n in ("query_content", "query_pos", "key", "value", "fun.out_proj"):
+                _lin(spec, p + "egodeep_attend." + n, D, D)
+            _ln(spec, p + "norm_eda", D)
         _lin(spec, p + "feedforward.0", Dff, D)
         _lin(spec, p + "feedforward.3", D, Dff)
         _ln(spec, p + "norm_out", D)
@@ -448,8 +458,8 @@ def slot_to_image(sd, key, cfg, q_content, q_pos, q_sine, mem, mem_pos, is_first
                                sd[key + ".fun.out_proj.bias"])
 
 
-def decoder_layer(sd, cfg, i, x, q_pos, q_sine, mems, mem_poss, is_first, attn_out=None):
-    """transformer.py:242-312 (slot-state and decoder-side egodeep branches are never built)."""
+def decoder_layer(sd, cfg, i, x, q_pos, q_sine, mems, mem_poss, is_first, attn_out=None, slotstates=None, ego=None):
+    """transformer.py:242-312.  slotstates (M,B,D): the previous frame's final queries; ego (1,B,D)."""
     p = f"{P_DEC}layers.{i}."
     x = _lnorm(sd, p + "norm_sa", x + slot_to_slot(sd, p + "self_attend", cfg, x, q_pos, x, q_pos))
     for j, (mem, mpos) in enumerate(zip(mems, mem_poss)):
@@ -457,6 +467,10 @@ def decoder_layer(sd, cfg, i, x, q_pos, q_sine, mems, mem_poss, is_first, attn_o
         if attn_out is not None:
             attn_out.append(w)
         x = _lnorm(sd, f"{p}norm_ia.{j}", x + o)
+    if cfg.dec_slotstates and slotstates is not None:                 # transformer.py:288-298 (key_pos = query_pos, :368)
+        x = _lnorm(sd, p + "norm_ssa", x + slot_to_slot(sd, p + "slotstates_attend", cfg, x, q_pos, slotstates, q_pos))
+    if cfg.dec_egodeep and ego is not None:                           # transformer.py:300-307
+        x = _lnorm(sd, p + "norm_eda", x + egodeep_attention(sd, p + "egodeep_attend", cfg, x, q_pos, ego, with_mlp=False))
     h = F.relu(_linear(sd, p + "feedforward.0", x))
     return _lnorm(sd, p + "norm_out", x + _linear(sd, p + "feedforward.3", h))
 
@@ -469,7 +483,8 @@ def _mlp(sd, key, x, n):
     return x
 
 
-def decoder_forward(sd, cfg, q_content, q_pos, mems, mem_poss, first_layer_special, attn_out=None):
+def decoder_forward(sd, cfg, q_content, q_pos, mems, mem_poss, first_layer_special, attn_out=None, slotstates=None,
+                    ego=None):
     """-> (hs (layers,B,M,D), reference (B,M,2)).  transformer.py:332-398."""
     ref = _mlp(sd, P_DEC + "ref_point_head", q_pos, 2).sigmoid().transpose(0, 1)   # (B,M,2)
     sine0 = query_sine_embed(ref.transpose(0, 1), cfg.hidden_dim)
@@ -478,16 +493,20 @@ def decoder_forward(sd, cfg, q_content, q_pos, mems, mem_poss, first_layer_speci
     for i in range(cfg.dec_layers):
         special = (i == 0) and first_layer_special
         q_sine = sine0 if special else _mlp(sd, P_DEC + "query_scale", x, 2) * sine0
-        x = decoder_layer(sd, cfg, i, x, q_pos, q_sine, mems, mem_poss, special, attn_out)
+        x = decoder_layer(sd, cfg, i, x, q_pos, q_sine, mems, mem_poss, special, attn_out, slotstates, ego)
         inter.append(_lnorm(sd, P_DEC + "norm", x))
     return torch.stack(inter).transpose(1, 2), ref
 
 
-def detect(sd, cfg, frame_feat, pos, first_frame, state, attn_out=None):
-    """frame_feat,pos (N,B,D).  paper.py:352-419."""
+def detect(sd, cfg, frame_feat, pos, first_frame, state, attn_out=None, ego=None):
+    """frame_feat,pos (N,B,D); state = (earlier frames' features, slot states) or a plain list of features;
+    ego (1,B,D) or None.  paper.py:352-419."""
     B = frame_feat.shape[1]
     q_pos = sd[P_DET + "query_embed.weight"].unsqueeze(1).repeat(1, B, 1)
     q_content = torch.zeros_like(q_pos)
+    slot = None
+    if isinstance(state, tuple):
+        state, slot = state
     mems = [frame_feat] + (state if state is not None else [])
     if cfg.image_memory_mode == "attend one at a time":
         mposs = [pos for _ in mems]
@@ -495,8 +514,10 @@ def detect(sd, cfg, frame_feat, pos, first_frame, state, attn_out=None):
         mposs = [pos]
     special = (first_frame and cfg.first_layer_special_when == "first frame") or \
         cfg.first_layer_special_when == "always"
-    hs, ref = decoder_forward(sd, cfg, q_content, q_pos, mems, mposs, special, attn_out)
+    hs, ref = decoder_forward(sd, cfg, q_content, q_pos, mems, mposs, special, attn_out, slot, ego)
     new_state = mems[: cfg.num_images - 1]
+    if cfg.dec_slotstates:                                            # paper.py:396-399
+        new_state = (new_state, hs[-1].transpose(0, 1))
     ref_logit = inverse_sigmoid(ref)
     coords = []
     for lvl in range(hs.shape[0]):
@@ -511,7 +532,7 @@ def detect(sd, cfg, frame_feat, pos, first_frame, state, attn_out=None):
     return out, new_state
 
 
-def detector_forward(sd, cfg, features, pos_enc, skip_dead=False, attn_out=None):
+def detector_forward(sd, cfg, features, pos_enc, skip_dead=False, attn_out=None, ego=None):
     """features,pos_enc (B,L',D,h,w).  paper.py:331-350.
 
     skip_dead=False replays the reference loop over every frame (only the last `out`
@@ -521,16 +542,18 @@ def detector_forward(sd, cfg, features, pos_enc, skip_dead=False, attn_out=None)
     if cfg.image_memory_mode == "attend all at once":                 # paper.py:334-339
         f = features.permute(1, 3, 4, 0, 2).flatten(0, 2)
         p = pos_enc.permute(1, 3, 4, 0, 2).flatten(0, 2)
-        return detect(sd, cfg, f, p, True, None, attn_out)[0]
+        e = ego.transpose(0, 1) if (ego is not None and cfg.dec_egodeep) else None       # l b c (paper.py:337-338)
+        return detect(sd, cfg, f, p, True, None, attn_out, e)[0]
     f = features.flatten(3).permute(1, 3, 0, 2)                       # l (h w) b c
     p = pos_enc.flatten(3).permute(1, 3, 0, 2)
-    if skip_dead:
+    egos = [ego[:, l][None] if (ego is not None and cfg.dec_egodeep) else None for l in range(L)]   # paper.py:343-346
+    if skip_dead and not cfg.dec_slotstates:                          # slot states make every frame's pass live
         state = [f[l] for l in range(L - 2, max(L - 1 - cfg.num_images, -1), -1)]
-        return detect(sd, cfg, f[L - 1], p[L - 1], L == 1, state if L > 1 else None, attn_out)[0]
+        return detect(sd, cfg, f[L - 1], p[L - 1], L == 1, state if L > 1 else None, attn_out, egos[L - 1])[0]
     state, out = None, None
     for l in range(L):
         out, state = detect(sd, cfg, f[l], p[l], l == 0, state,
-                            attn_out if l == L - 1 else None)
+                            attn_out if l == L - 1 else None, egos[l])
     return out
 
 
@@ -541,7 +564,7 @@ def core_forward(sd, cfg, images, imu=None, temporal_offsets=None, skip_dead=Fal
     imu = imu[:, :-1] if imu is not None else None
     if temporal_offsets is not None:
         temporal_offsets = temporal_offsets[:, :-1]
-    if skip_dead and cfg.image_memory_mode == "attend one at a time" and not cfg.joint_layers:
+    if skip_dead and cfg.image_memory_mode == "attend one at a time" and not cfg.joint_layers and not cfg.dec_slotstates:
         keep = min(cfg.num_images, images.shape[1])
         images = images[:, -keep:]
         imu = imu[:, -keep:] if imu is not None else None
@@ -574,7 +597,7 @@ def core_forward(sd, cfg, images, imu=None, temporal_offsets=None, skip_dead=Fal
         for i in range(cfg.joint_layers):
             x = encoder_layer(sd, cfg, i, x, pj, None, prefix=P_JOINT)
         feat = x.view(h, w, L, B, D).permute(3, 2, 4, 0, 1)
-    return detector_forward(sd, cfg, feat, pos, skip_dead, attn_out)
+    return detector_forward(sd, cfg, feat, pos, skip_dead, attn_out, _ego)
 
 
 def imu_from_data(data, with_speed=True):

@@ -91,7 +91,8 @@ def build_reference(cfg: Config, paper, transformer, st_detr):
                 layers=nn.ModuleList([
                     transformer.TransformerDecoderLayer(D=cfg.hidden_dim, Nhead=cfg.nheads,
                                                         Dff=cfg.dim_feedforward, dropout=0.1,
-                                                        num_images=cfg.num_images, use_slotstates=False)
+                                                        num_images=cfg.num_images,
+                                                        use_slotstates=cfg.dec_slotstates, use_egodeep=cfg.dec_egodeep)
                     for _ in range(cfg.dec_layers)]),
                 norm=nn.LayerNorm(cfg.hidden_dim), return_intermediate=True, D=cfg.hidden_dim),
             num_classes=cfg.num_classes, hidden_dim=cfg.hidden_dim,
@@ -188,6 +189,11 @@ def main():
         "g14_joint_sequential": (Config(backbone="resnet18", enc_layers=1, joint_layers=2, joint_mode="sequential",
                                         joint_previmages=2, joint_prevout=True, joint_egodeep=True, dec_layers=1,
                                         num_images=2, no_temporal=False), 2, 5, 64, 96, 17),
+        # the recurrent detector: decoder layers attend to the previous frame's final queries (slot states) and to
+        # the frame's IMU token (transformer.py:288-307, paper.py:396-399); every past frame's pass is live
+        "g15_slotstates_egodeep": (Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2,
+                                          dec_slotstates=True, dec_egodeep=True, no_temporal=False,
+                                          first_layer_special_when="first frame"), 2, 4, 64, 96, 18),
     }
     for name, (cfg, B, L, H, W, seed) in cases.items():
         if ONLY and name not in ONLY:

@@ -55,7 +55,8 @@ def build_product(cfg: Config, dtype, seed):
         joint_encoder=build_joint(cfg),
         detector=CDetrDetectorSpatioTemporal(
             decoder=T.TransformerDecoder(nn.ModuleList(
-                [T.TransformerDecoderLayer(cfg.hidden_dim, cfg.nheads, cfg.dim_feedforward, 0.1, cfg.num_images)
+                [T.TransformerDecoderLayer(cfg.hidden_dim, cfg.nheads, cfg.dim_feedforward, 0.1, cfg.num_images,
+                                           use_slotstates=cfg.dec_slotstates, use_egodeep=cfg.dec_egodeep)
                  for _ in range(cfg.dec_layers)]), norm=nn.LayerNorm(cfg.hidden_dim), return_intermediate=True,
                 D=cfg.hidden_dim),
             num_classes=cfg.num_classes, hidden_dim=cfg.hidden_dim,
@@ -85,6 +86,8 @@ CASES = {
     "g14_joint_sequential": Config(backbone="resnet18", enc_layers=1, joint_layers=2, joint_mode="sequential",
                                    joint_previmages=2, joint_prevout=True, joint_egodeep=True, dec_layers=1,
                                    num_images=2, no_temporal=False),
+    "g15_slotstates_egodeep": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2, dec_slotstates=True,
+                                     dec_egodeep=True, no_temporal=False, first_layer_special_when="first frame"),
 }
 
 

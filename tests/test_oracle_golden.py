@@ -77,6 +77,8 @@ CASES = {
     "g14_joint_sequential": Config(backbone="resnet18", enc_layers=1, joint_layers=2, joint_mode="sequential",
                                    joint_previmages=2, joint_prevout=True, joint_egodeep=True, dec_layers=1,
                                    num_images=2, no_temporal=False),
+    "g15_slotstates_egodeep": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2, dec_slotstates=True,
+                                     dec_egodeep=True, no_temporal=False, first_layer_special_when="first frame"),
 }
 
 
@@ -117,8 +119,8 @@ def test_g5_full_model_loss_and_grads(golden, name):
             n = k[5:]
             close(sd[n].grad.reshape(-1)[g[k]], g["gval:" + n], atol=1e-5, rtol=2e-4)
     # G10: dead-work equivalence -- both in the reference (fixture) and in the oracle.  With one memory of all past
-    # frames nothing is dead (the fixture's truncated run then differs, as it must).
-    if cfg.image_memory_mode == "attend all at once" or cfg.joint_layers:
+    # frames, a joint encoder or slot states nothing is dead (the fixture's truncated run then differs, as it must).
+    if cfg.image_memory_mode == "attend all at once" or cfg.joint_layers or cfg.dec_slotstates:
         assert float(np.abs(g["dead_pred_logits"] - g["pred_logits"]).max()) > 1e-3
         return
     close(g["dead_pred_logits"], g["pred_logits"])   # different frame count => different conv blocking => fp32 rounding only
