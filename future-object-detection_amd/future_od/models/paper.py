@@ -189,9 +189,6 @@ class CDetrDetectorSpatioTemporal(nn.Module):
         self.use_slotstates = self.decoder.layers[0].slotstates_attend is not None
         assert all(self.use_slotstates == (layer.slotstates_attend is not None) for layer in self.decoder.layers)
         self.use_egodeep = self.decoder.layers[0].egodeep_attend is not None
-        if self.use_egodeep and image_memory_mode == "attend all at once":
-            raise NotImplementedError("decoder-side IMU attention over the tokens of ALL frames (only the "
-                                      "one-token-per-frame form is built)")
 
     def frames_needed(self, L):
         """Past frames that can reach the output: all of them when they form one memory or when slot states carry
@@ -221,7 +218,7 @@ class CDetrDetectorSpatioTemporal(nn.Module):
         if self.image_memory_mode == "attend all at once":
             assert K == num_frames_total, "every past frame is part of the memory"
             mem = torch.cat(frame_tokens, dim=1) if K > 1 else frame_tokens[0]
-            return self.detect([mem], pos, True)[0]
+            return self.detect([mem], pos, True, None, egodeep if self.use_egodeep else None)[0]   # egodeep [B,L,D]
         first_frame = num_frames_total == 1
         mems = [frame_tokens[K - 1 - j] for j in range(min(K, self.num_images))]   # current, then previous
         return self.detect(mems, pos, first_frame, None, egodeep if self.use_egodeep else None)[0]
@@ -251,19 +248,16 @@ class CDetrDetectorSpatioTemporal(nn.Module):
 class JointEncoder(nn.Module):
     """Self-attention over the tokens of ALL past frames at once (reference paper.py:180-203).  The reference orders
     them (h w l); every operation of an encoder layer is equivariant under token permutations, so they stay
-    frame-major here ([B, L*N, D], the layout the detector's 'attend all at once' memory uses too).  Layers with
-    the IMU attention are not supported (no configuration of the reference builds a joint encoder at all)."""
+    frame-major here ([B, L*N, D], the layout the detector's 'attend all at once' memory uses too)."""
 
     def __init__(self, transformer: TransformerEncoder):
         super().__init__()
-        for layer in transformer.layers:
-            if getattr(layer, "egodeep_attend", None) is not None:
-                raise NotImplementedError("JointEncoder layers with IMU attention (use_egodeep=True)")
         self.transformer = transformer
 
-    def forward(self, tokens, pos):
-        """tokens [B, L*N, D]; pos [L*N, D] table or [B, L*N, D]."""
-        return self.transformer(tokens, pos, None)
+    def forward(self, tokens, pos, egodeep=None):
+        """tokens [B, L*N, D]; pos [L*N, D] table or [B, L*N, D]; egodeep [B, L, D] (the IMU tokens of all frames
+        are the keys of the layers' IMU attention, reference paper.py:196-198) or None."""
+        return self.transformer(tokens, pos, egodeep)
 
 
 class JointEncoderSequential(nn.Module):
@@ -332,13 +326,14 @@ class FuturePredCore(nn.Module):
             frames = self.joint_encoder(frames, pos_at, _ego.view(keep, B, D) if _ego is not None else None)
         elif self.joint_encoder is not None:
             pa = pos_all()
-            joint = self.joint_encoder(torch.cat(frames, dim=1) if keep > 1 else frames[0], pa)  # [B, keep*N, D]
+            keys = _ego.view(keep, B, D).transpose(0, 1).contiguous() if _ego is not None else None       # [B, keep, D]
+            joint = self.joint_encoder(torch.cat(frames, dim=1) if keep > 1 else frames[0], pa, keys)  # [B, keep*N, D]
             frames = list(joint.view(B, keep, N, D).unbind(1))
         ego = _ego.view(keep, B, D) if _ego is not None else None
         if self.detector.use_slotstates and not all_at_once:
             out = self.detector.forward_recurrent(frames, pos_at, ego)
         else:
-            out = self.detector(frames, pos_all() if all_at_once else pos_last(), num_frames_total=past,
-                                egodeep=ego[-1] if ego is not None else None)
+            e = None if ego is None else (ego.transpose(0, 1).contiguous() if all_at_once else ego[-1])
+            out = self.detector(frames, pos_all() if all_at_once else pos_last(), num_frames_total=past, egodeep=e)
         moods = [["model happy" for _ in range(L)] for _ in range(B)]
         return out, moods

@@ -119,6 +119,7 @@ class EgodeepAttention(nn.Module):
         self.fun = OutProj(D)
         self.use_mlp = Dff is not None
         self.droprate = droprate
+        self.Nhead = Nhead
         if self.use_mlp:
             self.norm1 = nn.LayerNorm(D)
             self.mlp = nn.Sequential(nn.Linear(D, Dff), nn.ReLU(inplace=True), nn.Dropout(droprate),
@@ -128,9 +129,22 @@ class EgodeepAttention(nn.Module):
     def dead_parameters(self):
         return [p for m in (self.query_content, self.query_pos, self.key) for p in m.parameters()]
 
+    def forward_keys(self, x, pos, keys):
+        """The general form: x [B,T,D] attends to `keys` [B,S,D] (the IMU tokens of S frames; reference :108-119 with
+        S > 1, which only JointEncoder / the all-at-once detector produce).  pos: [T,D] table or [B,T,D]."""
+        T_, D = x.shape[-2], x.shape[-1]
+        qc = _lin(x, self.query_content)
+        qp = _lin(pos, self.query_pos)
+        q = Fn.add(qc, qp, b_row_mod=T_) if pos.dim() == 2 else Fn.add(qc, qp)
+        k, v = Fn.group_linear(keys.contiguous(), [self.key, self.value])
+        a = Fn.attention(q, k, v, 1.0 / math.sqrt(D // self.Nhead), drop_p=self.droprate, training=self.training)
+        return self._tail(_lin(a, self.fun.out_proj))
+
     def forward_single_key(self, ego):
         """ego [frames, D] -> [frames, D]."""
-        out = _lin(_lin(ego, self.value), self.fun.out_proj)
+        return self._tail(_lin(_lin(ego, self.value), self.fun.out_proj))
+
+    def _tail(self, out):
         if self.use_mlp:
             # train mode: the reference drops per token; on the collapsed rows the masks are per frame
             t, p = self.training, self.droprate
@@ -231,7 +245,10 @@ class TransformerDecoderLayer(nn.Module):
         if self.slotstates_attend is not None and slotstates is not None:
             o = self.slotstates_attend.forward_cross(x, qpos, slotstates)
             x = Fn.layer_norm(x, self.norm_ssa.weight, self.norm_ssa.bias, residual=Fn.dropout(o, p, t))
-        if self.egodeep_attend is not None and egodeep is not None:
+        if self.egodeep_attend is not None and egodeep is not None and egodeep.dim() == 3:     # [B,S,D]: several keys
+            e = Fn.dropout(self.egodeep_attend.forward_keys(x, qpos, egodeep), p, t)
+            x = Fn.layer_norm(x, self.norm_eda.weight, self.norm_eda.bias, residual=e)
+        elif self.egodeep_attend is not None and egodeep is not None:
             # one key: the attention output is the same row for every query of a sample (see EgodeepAttention)
             e = Fn.dropout(self.egodeep_attend.forward_single_key(egodeep), p, t)
             x = Fn.layer_norm(x, self.norm_eda.weight, self.norm_eda.bias, residual=e, res_row_div=x.shape[1])
@@ -359,15 +376,19 @@ class TransformerEncoderLayer(nn.Module):
             self.egodeep_attend = None
 
     def forward(self, x, pos, egodeep: Optional[Tensor] = None, prevout: Optional[Tensor] = None, memory=None):
-        """x [F,N,D]; pos table [N,D] or [F,N,D]; egodeep [F,D] (one IMU token per frame) or None; prevout [F,N,D]
-        or None; memory: list of [F,N,D] (most recent first) or None."""
+        """x [F,N,D]; pos table [N,D] or [F,N,D]; egodeep [F,D] (one IMU token per frame), [F,S,D] (S tokens) or
+        None; prevout [F,N,D] or None; memory: list of [F,N,D] (most recent first) or None."""
         x = self.self_attn(x, pos)
         if prevout is not None and self.prevout_attn is not None:
             x = self.prevout_attn(x, pos, other=prevout)
         if memory is not None:
             for prev, attn in zip(memory, self.previmage_attn):
                 x = attn(x, pos, other=prev)
-        if egodeep is not None and self.egodeep_attend is not None:
+        if egodeep is not None and self.egodeep_attend is not None and egodeep.dim() == 3:   # [F,S,D]: several keys
+            e = self.egodeep_attend.forward_keys(x, pos, egodeep)
+            e = Fn.dropout(e, self.egodeep_attend.droprate, self.training)
+            x = Fn.layer_norm(x, self.norm_eda.weight, self.norm_eda.bias, residual=e)
+        elif egodeep is not None and self.egodeep_attend is not None:
             N = x.shape[1]
             e = self.egodeep_attend.forward_single_key(egodeep)
             e = Fn.dropout(e, self.egodeep_attend.droprate, self.training)          # dropout_eda (reference :444,485)

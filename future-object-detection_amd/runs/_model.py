@@ -36,7 +36,7 @@ def _joint_encoder(args, detr_args):
             D=detr_args.hidden_dim, Nhead=detr_args.enc_nheads, Dff=detr_args.dim_feedforward,
             num_previmages=getattr(args, "joint_previmages", 0) if sequential else 0,
             use_prevout=bool(getattr(args, "joint_prevout", False)) and sequential,
-            use_egodeep=bool(getattr(args, "joint_egodeep", False)) and sequential)
+            use_egodeep=bool(getattr(args, "joint_egodeep", False)))
         for _ in range(n))
     enc = transformer.TransformerEncoder(layers=layers)
     return JointEncoderSequential(enc) if sequential else JointEncoder(enc)

@@ -50,7 +50,7 @@ class Config:
     joint_mode: str = "joint"           # "joint" = JointEncoder (paper.py:180-203), "sequential" = JointEncoderSequential (:206-234)
     joint_previmages: int = 0           # sequential only: transformer.py:439-441 previmage_attn blocks per layer
     joint_prevout: bool = False         # sequential only: transformer.py:435-438 prevout_attn
-    joint_egodeep: bool = False         # sequential only: transformer.py:442-447 IMU attention in the joint layers
+    joint_egodeep: bool = False         # transformer.py:442-447 IMU attention in the joint layers (keys: 1 token sequential, L tokens joint)
     dec_slotstates: bool = False        # transformer.py:210-215 decoder layers attend to the previous frame's final queries
     dec_egodeep: bool = False           # transformer.py:217-222 decoder layers attend to the frame's IMU token
     train_backbone: bool = True         # runs/_model.py:21 (lr_backbone > 0)
@@ -161,7 +161,7 @@ def param_spec(cfg: Config) -> Dict[str, tuple]:
             enc_attention(p + "prevout_attn.")
         for j in range(cfg.joint_previmages if seq else 0):                         # transformer.py:439-441
             enc_attention(p + f"previmage_attn.{j}.")
-        if seq and cfg.joint_egodeep:                                               # transformer.py:442-445
+        if cfg.joint_egodeep:                                                       # transformer.py:442-445
             for nm in ("query_content", "query_pos", "key", "value", "fun.out_proj"):
                 _lin(spec, p + "egodeep_attend." + nm, D, D)
             _ln(spec, p + "egodeep_attend.norm1", D)
@@ -594,8 +594,9 @@ def core_forward(sd, cfg, images, imu=None, temporal_offsets=None, skip_dead=Fal
     elif cfg.joint_layers:                                             # paper.py:193-198, layers without IMU attention
         x = feat.permute(3, 4, 1, 0, 2).flatten(0, 2)                 # (h w l) b c
         pj = pos.permute(3, 4, 1, 0, 2).flatten(0, 2)
+        ej = _ego.transpose(0, 1) if (_ego is not None and cfg.joint_egodeep) else None    # l b c (paper.py:196-197)
         for i in range(cfg.joint_layers):
-            x = encoder_layer(sd, cfg, i, x, pj, None, prefix=P_JOINT)
+            x = encoder_layer(sd, cfg, i, x, pj, ej, prefix=P_JOINT)
         feat = x.view(h, w, L, B, D).permute(3, 2, 4, 0, 1)
     return detector_forward(sd, cfg, feat, pos, skip_dead, attn_out, _ego)
 

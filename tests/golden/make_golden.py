@@ -62,7 +62,7 @@ def joint_encoder(cfg: Config, paper, transformer):
         transformer.TransformerEncoderLayer(D=cfg.hidden_dim, Nhead=cfg.nheads, Dff=cfg.dim_feedforward,
                                             num_previmages=cfg.joint_previmages if seq else 0,
                                             use_prevout=cfg.joint_prevout and seq,
-                                            use_egodeep=cfg.joint_egodeep and seq)
+                                            use_egodeep=cfg.joint_egodeep)
         for _ in range(cfg.joint_layers)))
     return paper.JointEncoderSequential(enc) if seq else paper.JointEncoder(enc)
 
@@ -194,6 +194,11 @@ def main():
         "g15_slotstates_egodeep": (Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2,
                                           dec_slotstates=True, dec_egodeep=True, no_temporal=False,
                                           first_layer_special_when="first frame"), 2, 4, 64, 96, 18),
+        # IMU attention with SEVERAL keys: the joint encoder's layers and the all-at-once detector attend to the IMU
+        # tokens of all past frames (paper.py:196-198, 337-339)
+        "g16_multikey_egodeep": (Config(backbone="resnet18", enc_layers=1, joint_layers=1, joint_egodeep=True,
+                                        dec_layers=2, num_images=1, image_memory_mode="attend all at once",
+                                        dec_egodeep=True, no_temporal=False), 2, 4, 64, 96, 19),
     }
     for name, (cfg, B, L, H, W, seed) in cases.items():
         if ONLY and name not in ONLY:

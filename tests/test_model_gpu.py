@@ -32,7 +32,7 @@ def build_joint(cfg: Config):
     enc = T.TransformerEncoder(nn.ModuleList(
         T.TransformerEncoderLayer(cfg.hidden_dim, cfg.nheads, cfg.dim_feedforward,
                                   num_previmages=cfg.joint_previmages if seq else 0,
-                                  use_prevout=cfg.joint_prevout and seq, use_egodeep=cfg.joint_egodeep and seq)
+                                  use_prevout=cfg.joint_prevout and seq, use_egodeep=cfg.joint_egodeep)
         for _ in range(cfg.joint_layers)))
     return JointEncoderSequential(enc) if seq else JointEncoder(enc)
 
@@ -88,6 +88,9 @@ CASES = {
                                    num_images=2, no_temporal=False),
     "g15_slotstates_egodeep": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2, dec_slotstates=True,
                                      dec_egodeep=True, no_temporal=False, first_layer_special_when="first frame"),
+    "g16_multikey_egodeep": Config(backbone="resnet18", enc_layers=1, joint_layers=1, joint_egodeep=True, dec_layers=2,
+                                   num_images=1, image_memory_mode="attend all at once", dec_egodeep=True,
+                                   no_temporal=False),
 }
 
 

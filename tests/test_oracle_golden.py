@@ -79,6 +79,9 @@ CASES = {
                                    num_images=2, no_temporal=False),
     "g15_slotstates_egodeep": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2, dec_slotstates=True,
                                      dec_egodeep=True, no_temporal=False, first_layer_special_when="first frame"),
+    "g16_multikey_egodeep": Config(backbone="resnet18", enc_layers=1, joint_layers=1, joint_egodeep=True, dec_layers=2,
+                                   num_images=1, image_memory_mode="attend all at once", dec_egodeep=True,
+                                   no_temporal=False),
 }
 
 
