@@ -25,12 +25,22 @@ import torch.distributed as dist                                    # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 T_FRAMES, HEIGHT, WIDTH, BATCH_PER_GPU = 6, 900, 1600, 2
+# --workload: the headline (default; the configuration BASELINE.json's metric is quoted on) and, for the record in
+# DESIGN.md, the other BASELINE.json configs that fit one GPU: (T, H, W, batch / GPU, num_images K, live TFLOP per
+# frame-sequence forward + backward from SURVEY.md 8d, or None)
+WORKLOADS = {
+    "headline": (6, 900, 1600, 2, 5, 4.082e12),
+    "headline-k2": (6, 900, 1600, 2, 2, 1.638e12),      # the shipped num_images = 2: 3 of 5 past frames are dead work
+    "cfg2": (4, 800, 1333, 2, 2, 1.187e12),             # configs[1]: T=4, 800x1333
+    "nusc500-stage1": (3, 448, 800, 4, 2, 0.395e12),    # configs[3], runs/nusc_spatiotemporal_imu_500ms.py: 32 / 8 GPUs
+    "nusc500-stage2": (3, 896, 1600, 2, 2, 1.601e12),   # configs[3], second stage: 16 / 8 GPUs
+}
+LIVE_FLOPS = WORKLOADS["headline"][5]
 
 
 def live_flops_per_sequence(num_images):
-    """Algorithmic FLOPs of one frame-sequence, forward + backward, live work only (SURVEY.md 8d table:
-    900x1600, T=6; K=2 -> 1.638 TFLOP, K=5 -> 4.082 TFLOP)."""
-    return {2: 1.638e12, 5: 4.082e12}.get(num_images)
+    """Algorithmic FLOPs of one frame-sequence, forward + backward, live work only."""
+    return LIVE_FLOPS
 
 
 def build(args, device, distributed, num_images, dtype="bf16"):
@@ -93,8 +103,14 @@ def main():
     ap.add_argument("--force-ddp", action="store_true",
                     help="with --gpus 1: run the N>1 code path (RCCL process group of one rank, FodDataParallel, "
                          "distributed loss normalisation) to measure its overhead on a 1-GPU box")
+    ap.add_argument("--workload", default="headline", choices=sorted(WORKLOADS),
+                    help="default: the headline configuration; the others are for the record (DESIGN.md 5)")
     a = ap.parse_args()
-    global T_FRAMES, HEIGHT, WIDTH
+    global T_FRAMES, HEIGHT, WIDTH, BATCH_PER_GPU, LIVE_FLOPS
+    if a.workload != "headline":
+        T_FRAMES, HEIGHT, WIDTH, BATCH_PER_GPU, a.num_images, LIVE_FLOPS = WORKLOADS[a.workload]
+    elif a.num_images != 5:
+        LIVE_FLOPS = {2: 1.638e12}.get(a.num_images)
     if a.rehearse:
         T_FRAMES, HEIGHT, WIDTH = 4, 128, 192
         import faulthandler                       # a rehearsal that hangs says where
@@ -155,7 +171,8 @@ def main():
     value = seqs / dt
 
     result = {
-        "metric": "frame-sequences/sec fwd+bwd, T=6 900x1600", "value": value, "unit": "frame-sequences/s",
+        "metric": f"frame-sequences/sec fwd+bwd, T={T_FRAMES} {HEIGHT}x{WIDTH}", "value": value,
+        "unit": "frame-sequences/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": f"spatiotemporal ConditionalDETR (ResNet-50, 6 enc + 6 dec layers, 128 queries), "

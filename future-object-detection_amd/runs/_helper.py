@@ -1,6 +1,8 @@
 """Optimizer / schedule / argument helpers with the reference's names (reference runs/_helper.py)."""
 import argparse
+import os
 
+import numpy as np
 import torch
 import torch.optim as optim
 
@@ -49,3 +51,19 @@ def build_base_parser():
     parser.add_argument("--compute_dtype", default="bf16", choices=["bf16", "fp32"])
     add_pytorch_args(parser)
     return parser
+
+
+def get_trainer(args, config, detr_args, lr_sched, model, optimizer, train_loader, val_loaders):
+    """The Trainer as the reference's run scripts build it (reference runs/_helper.py:15-66)."""
+    from future_od.trainer import Trainer
+    from future_od.utils.wandb import WandBConfig
+    from runs._loader import CATEGORY_DICT
+    return Trainer(
+        model=model, optimizer=optimizer, lr_sched=lr_sched, train_loader=train_loader, val_loaders=val_loaders,
+        checkpoint_path=config["checkpoint_path"],
+        visualization_path=os.path.join(config["visualization_path"], args.experiment_idf),
+        save_name=args.experiment_idf, device=args.device, checkpoint_epochs=not args.no_checkpoints,
+        print_interval=25, visualization_epochs=set(int(i) for i in np.linspace(1, args.epochs, 10)),
+        visualization_iterations=[0], category_dict=CATEGORY_DICT, distributed=args.distributed,
+        is_master=(args.world_rank == 0),
+        wandb_config=WandBConfig(enabled=False), max_norm=detr_args.max_norm)

@@ -1,0 +1,61 @@
+"""Loaders with the reference's call shape (reference runs/_loader.py:78-124 `get_nusc_loaders(size, offsets, config,
+args, train_batch_size)`), drawing SYNTHETIC NuScenes-shaped batches: there is no dataset and no network on the
+build / GPU boxes (BASELINE.json configs[3]: "random-init weights, synthetic NuScenes-shaped batches").
+
+Sharding follows the reference (`runs/_loader.py:110-112`): the per-GPU batch is the global batch divided by the world
+size, and every rank draws different samples (seed = base + epoch-independent sample id, DistributedSampler-like).
+A clip has one frame per offset (`offsets=[-1.0, -0.5, 0]` -> L = 3: two past frames and the annotated one)."""
+import torch
+
+from future_od.datasets.synthetic import make_batch
+
+# future_od/datasets/nu_scenes.py:29-38
+CATEGORY_DICT = {0: "Vehicle", 1: "Truck", 2: "Trailer", 3: "Pedestrian", 4: "Bus", 5: "Motorcyclist", 6: "Bicyclist",
+                 7: "ConstructionVehicle"}
+
+
+class SyntheticNuScenes:
+    """Stands where the reference's NuScenesDataset stands (`loader.dataset`)."""
+
+    def __init__(self, size, offsets, length):
+        self.size, self.offsets, self.length = tuple(size), list(offsets), int(length)
+
+    def __len__(self):
+        return self.length
+
+
+class SyntheticLoader:
+    """Iterable of `steps` batches of `batch_size` clips; batch i of rank r is seeded by (seed, i, r), so a loader
+    yields the same data every epoch (like a dataset without augmentation) and ranks never share samples."""
+
+    def __init__(self, size, offsets, batch_size, steps, rank=0, world=1, seed=1234, uint8=False, max_boxes=40):
+        self.dataset = SyntheticNuScenes(size, offsets, steps * batch_size * world)
+        self.batch_size, self.steps = int(batch_size), int(steps)
+        self.rank, self.world, self.seed = rank, world, seed
+        self.uint8, self.max_boxes = uint8, max_boxes
+
+    def __len__(self):
+        return self.steps
+
+    def __iter__(self):
+        H, W = self.dataset.size
+        L = len(self.dataset.offsets)
+        for i in range(self.steps):
+            b = make_batch(self.batch_size, L, H, W, seed=self.seed + 7919 * (i * self.world + self.rank),
+                           max_boxes=self.max_boxes, video_dtype=torch.uint8 if self.uint8 else torch.float32)
+            b["temporal_offsets"] = torch.tensor(self.dataset.offsets, dtype=torch.float32).repeat(self.batch_size, 1)
+            yield b
+
+
+def get_nusc_loaders(size, offsets, config, args, train_batch_size, val_batch_size=None, steps_per_epoch=None,
+                     val_steps=None):
+    """-> (train_loader, {"val": val_loader}); `train_batch_size` is GLOBAL (reference :110-112)."""
+    world = getattr(args, "world_size", 1) if getattr(args, "distributed", False) else 1
+    rank = getattr(args, "world_rank", 0)
+    assert train_batch_size % world == 0, "global batch must divide over the ranks"
+    per_gpu = train_batch_size // world
+    steps = steps_per_epoch or getattr(args, "steps_per_epoch", 8)
+    vsteps = val_steps or getattr(args, "val_steps", 2)
+    train = SyntheticLoader(size, offsets, per_gpu, steps, rank, world, seed=1234)
+    val = SyntheticLoader(size, offsets, val_batch_size or per_gpu, vsteps, rank, world, seed=99991)
+    return train, {"val": val}

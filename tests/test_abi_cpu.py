@@ -102,3 +102,23 @@ def test_device_prefetcher_cpu_passthrough():
     assert len(out) == 3 and len(DevicePrefetcher(batches, "cpu")) == 3
     for src, dst in zip(batches, out):
         assert torch.equal(src["video"], dst["video"]) and dst["_host_annotations"]["active"] is src["active"]
+
+
+def test_synthetic_loaders_shard_like_the_reference():
+    """Global batch / world size per rank, different samples per rank, same data every epoch
+    (reference runs/_loader.py:106-115)."""
+    from types import SimpleNamespace
+    import torch
+    from runs._loader import get_nusc_loaders
+    loaders = []
+    for rank in range(2):
+        args = SimpleNamespace(distributed=True, world_size=2, world_rank=rank)
+        tr, val = get_nusc_loaders((32, 48), offsets=[-1.0, -0.5, 0], config={}, args=args, train_batch_size=8,
+                                   steps_per_epoch=3, val_steps=1)
+        loaders.append(tr)
+        assert len(tr) == 3 and tr.batch_size == 4 and len(tr.dataset) == 24 and list(val) and len(val["val"]) == 1
+    a0, a1 = list(loaders[0]), list(loaders[1])
+    assert a0[0]["video"].shape == (4, 3, 3, 32, 48)
+    assert torch.equal(a0[0]["temporal_offsets"][0], torch.tensor([-1.0, -0.5, 0.0]))
+    assert not torch.equal(a0[0]["video"], a1[0]["video"]) and not torch.equal(a0[0]["video"], a0[1]["video"])
+    assert torch.equal(list(loaders[0])[2]["boxes"], a0[2]["boxes"])          # an epoch repeats
