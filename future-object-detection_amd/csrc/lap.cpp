@@ -12,6 +12,8 @@
 #include <thread>
 #include <vector>
 
+#include <hip/hip_runtime.h>
+
 #include "../../include/fod.h"
 
 void fod_set_error(const char* fmt, ...);
@@ -133,4 +135,69 @@ extern "C" int fod_lap_solve_batch_host(const float* cost_host, int nprob, int M
     return FOD_ERR_RUNTIME;
   }
   return FOD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Asynchronous matcher: the stream parks on a host flag (hipStreamWaitValue32) while a host worker solves the
+// assignment problems, so the launching thread never waits for the forward pass to finish.
+extern "C" int fod_host_flag_create(void** flag) {
+  if (!flag) return FOD_ERR_ARG;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, 8, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+    fod_set_error("host flag: hipHostMalloc failed");
+    return FOD_ERR_RUNTIME;
+  }
+  *reinterpret_cast<volatile uint32_t*>(p) = 0;
+  *flag = p;
+  return FOD_OK;
+}
+
+extern "C" int fod_host_flag_destroy(void* flag) {
+  return (!flag || hipHostFree(flag) == hipSuccess) ? FOD_OK : FOD_ERR_RUNTIME;
+}
+
+extern "C" int fod_host_flag_set(void* flag, uint32_t value) {
+  if (!flag) return FOD_ERR_ARG;
+  __atomic_store_n(reinterpret_cast<uint32_t*>(flag), value, __ATOMIC_RELEASE);
+  return FOD_OK;
+}
+
+extern "C" int fod_stream_wait_flag(void* flag, uint32_t value, fod_stream_t stream) {
+  if (!flag) return FOD_ERR_ARG;
+  const hipError_t e = hipStreamWaitValue32(reinterpret_cast<hipStream_t>(stream), flag, value, hipStreamWaitValueGte, 0xFFFFFFFFu);
+  if (e != hipSuccess) {
+    fod_set_error("hipStreamWaitValue32: %s", hipGetErrorString(e));
+    return FOD_ERR_RUNTIME;
+  }
+  return FOD_OK;
+}
+
+extern "C" int fod_match_after_event(int device, void* event, const float* cost_host, int nprob, int M, int ld_n,
+                                     const int32_t* n_cols, const int32_t* col_offset, int32_t* match_out, void* flag,
+                                     uint32_t ticket, int threads) {
+  int rc = FOD_OK;
+  if (!cost_host || !n_cols || !col_offset || !match_out || !flag) {
+    fod_set_error("match_after_event: bad args");
+    rc = FOD_ERR_ARG;
+  }
+  if (rc == FOD_OK && event) {
+    if (hipSetDevice(device) != hipSuccess || hipEventSynchronize(reinterpret_cast<hipEvent_t>(event)) != hipSuccess) {
+      fod_set_error("match_after_event: waiting for the cost matrix failed");
+      rc = FOD_ERR_RUNTIME;
+    }
+  }
+  if (rc == FOD_OK) rc = fod_lap_solve_batch_host(cost_host, nprob, M, ld_n, n_cols, match_out, threads);
+  if (match_out) {
+    if (rc == FOD_OK) {
+      for (int p = 0; p < nprob; ++p)
+        for (int m = 0; m < M; ++m) {
+          int32_t& v = match_out[(size_t)p * M + m];
+          if (v >= 0) v += col_offset[p];
+        }
+    } else {
+      for (size_t i = 0; i < (size_t)nprob * M; ++i) match_out[i] = -1;      // the parked stream must be released
+    }
+  }
+  if (flag) __atomic_store_n(reinterpret_cast<uint32_t*>(flag), ticket, __ATOMIC_RELEASE);
+  return rc;
 }

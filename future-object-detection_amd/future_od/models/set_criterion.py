@@ -47,6 +47,19 @@ class HungarianMatcher(nn.Module):
         return _to_device_async(glob, logits.device), local
 
     @torch.no_grad()
+    def match_levels_async(self, logits, boxes, packed, threads=8):
+        """match_levels() without the host stall: the stream parks on a host flag while a worker thread waits for the
+        cost matrices, solves the assignment problems and writes the matches into pinned memory; this thread goes on
+        queueing the loss and the backward pass while the GPU is still in the forward pass (include/fod.h,
+        fod_match_after_event).  Returns the device match tensor only."""
+        Lv, B, M, _ = logits.shape
+        sizes = packed["sizes"]
+        ld = max(max(sizes), 1)
+        cost = ops.match_cost(logits, boxes, packed["labels"], packed["boxes"], packed["offset"], ld,
+                              self.cost_class, self.cost_bbox, self.cost_giou)
+        return _async_lap(cost.device).submit(cost, sizes * Lv, packed["offset_cpu"][:B].repeat(Lv), threads)
+
+    @torch.no_grad()
     def forward(self, outputs, targets):
         """Reference-shaped API: list of (idx_pred int64 ascending, idx_tgt int64) per sample."""
         packed = pack_targets(targets, outputs["pred_logits"].device)
@@ -58,6 +71,74 @@ class HungarianMatcher(nn.Module):
             i = torch.nonzero(m >= 0).flatten()
             out.append((i.to(torch.int64), m[i].to(torch.int64)))
         return out
+
+
+class _AsyncLap:
+    """One worker thread + one host flag per device.  Tickets increase by one per submission; the stream waits for
+    flag >= ticket.  The host may run at most one step ahead of the GPU: submit() first joins the previous job (which
+    also surfaces its errors), so pinned buffers and the optimizer's pointer tables are never reused while in flight."""
+
+    def __init__(self, device):
+        import concurrent.futures
+        import ctypes as C
+        from future_od.native import lib as L
+        self.L, self.C = L, C
+        self.device = device
+        flag = C.c_void_p()
+        L._plain_call("fod_host_flag_create", C.byref(flag))
+        self.flag = flag
+        self.ticket = 0
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="fod-matcher")
+        self.prev = None
+
+    def _job(self, event, cost_h, n_cols, col_off, match_h, ticket, threads):
+        L, C = self.L, self.C
+        P, M, ld = cost_h.shape
+        # one foreign call (the GIL is released for all of it): event wait, assignment, offsets, flag
+        L._plain_call("fod_match_after_event", self.device.index or 0, C.c_void_p(event.cuda_event),
+                      C.c_void_p(cost_h.data_ptr()), P, M, ld, C.c_void_p(n_cols.data_ptr()),
+                      C.c_void_p(col_off.data_ptr()), C.c_void_p(match_h.data_ptr()), self.flag, ticket, threads)
+
+    def join(self):
+        prev, self.prev = self.prev, None
+        if prev is not None:
+            prev.result()                      # raises the worker's FodError, one step late
+
+    def submit(self, cost, n_cols, col_off, threads):
+        Lv, B, M, ld = cost.shape
+        self.join()
+        cost_h = torch.empty((Lv * B, M, ld), dtype=cost.dtype, pin_memory=True)
+        cost_h.copy_(cost.view(Lv * B, M, ld), non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        match_h = torch.empty((Lv, B, M), dtype=torch.int32, pin_memory=True)
+        n_cols = torch.tensor(n_cols, dtype=torch.int32)
+        col_off = col_off.to(torch.int32).contiguous()
+        self.ticket += 1
+        try:
+            self.prev = self.pool.submit(self._job, event, cost_h, n_cols, col_off, match_h, self.ticket, threads)
+        except BaseException:
+            self.L._plain_call("fod_host_flag_set", self.flag, self.ticket)     # nothing may stay parked
+            raise
+        self.L._plain_call("fod_stream_wait_flag", self.flag, self.ticket,
+                           self.C.c_void_p(torch.cuda.current_stream(cost.device).cuda_stream))
+        return match_h.to(cost.device, non_blocking=True)
+
+
+_ASYNC_LAP = {}
+
+
+def _async_lap(device):
+    key = (device.type, device.index)
+    if key not in _ASYNC_LAP:
+        _ASYNC_LAP[key] = _AsyncLap(device)
+    return _ASYNC_LAP[key]
+
+
+def async_matching_enabled(device):
+    """The asynchronous matcher needs a GPU stream to park; FOD_ASYNC_MATCH=0 restores the host sync."""
+    import os
+    return torch.device(device).type == "cuda" and os.environ.get("FOD_ASYNC_MATCH", "1") != "0"
 
 
 def build_matcher(args):
@@ -110,12 +191,15 @@ class _SetLossFn(Function):
         return dl, db, None, None, None, None
 
 
-class _PendingNumBoxes:
-    def __init__(self, t, world):
-        self.t, self.world = t, world
+_HOST_GROUP = []
 
-    def resolve(self):
-        return max(float(self.t.item()) / self.world, 1.0)
+
+def _host_group():
+    """Process group for host-side scalar collectives: the default group when it is gloo (CPU tests, rehearsal),
+    else a gloo group created once next to the RCCL one (every rank reaches this at its first forward)."""
+    if not _HOST_GROUP:
+        _HOST_GROUP.append(None if dist.get_backend() == "gloo" else dist.new_group(backend="gloo"))
+    return _HOST_GROUP[0]
 
 
 class LossDict(dict):
@@ -142,16 +226,15 @@ class SetCriterion(nn.Module):
     def global_num_boxes(self, targets, device, distributed, lazy=False):
         """set_criterion.py:185-193: mean number of boxes per rank, clamped to >= 1.
 
-        `lazy=True` (distributed only) queues the all-reduce now and returns a handle whose `resolve()` reads the
-        value back later: forward() resolves it right after the matcher's host sync, when the result has long
-        arrived, instead of stalling the host on the previous step's backward at the start of the step."""
+        The count is known on the host before the forward pass, so the all-reduce is a HOST collective (a gloo group
+        beside the RCCL one): a device all-reduce would have to be read back, and that read-back is a host stall on
+        the whole forward pass now that the matcher no longer stalls the host.  Costs ~0.1 ms of host time."""
         n = float(sum(int(t["labels"].shape[0]) for t in targets))
         if not distributed:
             return max(n, 1.0)
-        t = _to_device_async(torch.tensor([n], dtype=torch.float), torch.device(device))
-        dist.all_reduce(t)
-        pending = _PendingNumBoxes(t, dist.get_world_size())
-        return pending if lazy else pending.resolve()
+        t = torch.tensor([n], dtype=torch.float64)
+        dist.all_reduce(t, group=_host_group())
+        return max(float(t.item()) / dist.get_world_size(), 1.0)
 
     def forward(self, outputs, targets, distributed, packed=None, num_boxes=None):
         if "_stacked" in outputs:
@@ -166,13 +249,15 @@ class SetCriterion(nn.Module):
             packed = pack_targets(targets, logits.device)
         if num_boxes is None:
             num_boxes = self.global_num_boxes(targets, logits.device, distributed)
-        if self._matching_mode == "per level":
+        if async_matching_enabled(logits.device):
+            levels = (lambda t: t.detach()) if self._matching_mode == "per level" else (lambda t: t.detach()[-1:])
+            match = self.matcher.match_levels_async(levels(logits), levels(boxes), packed)
+        elif self._matching_mode == "per level":
             match, _ = self.matcher.match_levels(logits.detach(), boxes.detach(), packed)
         else:
             match, _ = self.matcher.match_levels(logits.detach()[-1:], boxes.detach()[-1:], packed)
+        if match.shape[0] != Lv:
             match = match.expand(Lv, -1, -1).contiguous()
-        if isinstance(num_boxes, _PendingNumBoxes):
-            num_boxes = num_boxes.resolve()
         table = _SetLossFn.apply(logits, boxes, match, packed, num_boxes, self.focal_alpha)
         out = LossDict()
         out.table = table

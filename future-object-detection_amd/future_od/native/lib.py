@@ -84,6 +84,11 @@ SIGNATURES = {
     "fod_box_finish_bwd": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "fod_match_cost": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _p],
     "fod_lap_solve_batch_host": [_p, _i, _i, _i, _p, _p, _i],
+    "fod_host_flag_create": [C.POINTER(C.c_void_p)],
+    "fod_host_flag_destroy": [_p],
+    "fod_host_flag_set": [_p, C.c_uint32],
+    "fod_stream_wait_flag": [_p, C.c_uint32, _p],
+    "fod_match_after_event": [_i, _p, _p, _i, _i, _i, _p, _p, _p, _p, C.c_uint32, _i],
     "fod_set_loss_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "fod_set_loss_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "fod_od_map": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p],

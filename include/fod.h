@@ -251,6 +251,22 @@ int fod_match_cost(const float* logits, const float* boxes, const int64_t* tgt_l
 int fod_lap_solve_batch_host(const float* cost_host, int nprob, int M, int ld_n, const int32_t* n_cols,
                              int32_t* match_out, int threads);
 
+/* HOST + stream.  The matcher without a host stall (the reference blocks the host on `C.cpu()` inside
+ * HungarianMatcher.forward, called from future_od/models/set_criterion.py:182,204): the launching thread queues
+ *   cost -> pinned host copy -> event;  fod_stream_wait_flag(flag, ticket);  pinned match -> device copy;  loss ...
+ * and goes on queueing the backward pass, while a worker thread runs fod_match_after_event(): wait for the event,
+ * solve the nprob assignment problems (as fod_lap_solve_batch_host), add col_offset[p] to every matched column of
+ * problem p (GLOBAL target index), write match_out (pinned host memory, [nprob, M]) and store `ticket` to the flag
+ * with release order.  The flag is ALWAYS stored, also on failure (match_out = -1), so the stream cannot stay parked.
+ * A flag is 8 bytes of coherent pinned host memory; tickets must increase (the stream waits for *flag >= ticket). */
+int fod_host_flag_create(void** flag);
+int fod_host_flag_destroy(void* flag);
+int fod_host_flag_set(void* flag, uint32_t value);
+int fod_stream_wait_flag(void* flag, uint32_t value, fod_stream_t stream);
+int fod_match_after_event(int device, void* event, const float* cost_host, int nprob, int M, int ld_n,
+                          const int32_t* n_cols, const int32_t* col_offset, int32_t* match_out, void* flag,
+                          uint32_t ticket, int threads);
+
 /* Set losses (future_od/models/set_criterion.py:36-115) for all L levels at once.
  * match i32 [L,B,M]: matched GLOBAL target index or -1.  out f32 [L,5]:
  *   loss_ce, loss_bbox, loss_giou, cardinality_error, class_error.   (overwritten, not accumulated) */

@@ -197,3 +197,59 @@ def test_dropout_is_stateless_and_self_consistent():
     mask = (y.detach() != 0).float() / 0.75
     assert torch.allclose(x.grad, mask, rtol=1e-6, atol=0) and torch.allclose(y.detach(), x.detach() * mask, rtol=1e-6)
     assert Fn.dropout(x, 0.25, training=False) is x and Fn.dropout(x, 0.0, training=True) is x
+
+
+def _criterion_inputs(seed=0, B=3, M=32, Lv=3, C=8):
+    g = torch.Generator().manual_seed(seed)
+    logits = (torch.randn(Lv, B, M, C, generator=g) * 2 - 2).to(DEV).requires_grad_(True)
+    boxes = (torch.rand(Lv, B, M, 4, generator=g) * 0.5 + 0.2).to(DEV).requires_grad_(True)
+    targets = []
+    for b, nb in enumerate([5, 0, 17][:B]):
+        xy = torch.rand(nb, 2, generator=g) * 0.5 + 0.2
+        targets.append({"labels": torch.randint(0, C, (nb,), generator=g),
+                        "boxes": torch.cat([xy, torch.rand(nb, 2, generator=g) * 0.2 + 0.05], 1)})
+    return logits, boxes, targets
+
+
+def test_async_matcher_equals_host_synchronous_matcher(monkeypatch):
+    """The stream-parking matcher (fod_stream_wait_flag + fod_match_after_event on a worker thread) must produce
+    exactly the matches, losses and gradients of the path that blocks the host on the cost matrix."""
+    from future_od.models.set_criterion import SetCriterion, build_matcher, _async_lap
+    from future_od.models.st_detr import SpatioTemporalDETRArgs
+    crit = SetCriterion(8, build_matcher(SpatioTemporalDETRArgs(num_classes=8)), {}, 0.25,
+                        ["labels", "boxes", "cardinality"], "per level")
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FOD_ASYNC_MATCH", mode)
+        tables = []
+        for it in range(3):                                   # several tickets in flight one after the other
+            logits, boxes, targets = _criterion_inputs(seed=it)
+            out = crit({"_stacked": (logits, boxes)}, targets, distributed=False)
+            out.table[:, :3].sum().backward()
+            tables.append((out.table.detach().cpu(), logits.grad.cpu(), boxes.grad.cpu()))
+        res[mode] = tables
+    _async_lap(torch.device(DEV)).join()
+    for (t0, gl0, gb0), (t1, gl1, gb1) in zip(res["0"], res["1"]):
+        assert torch.equal(t0, t1) and torch.equal(gl0, gl1) and torch.equal(gb0, gb1)
+
+
+def test_async_matcher_failure_releases_the_stream_and_raises_late(monkeypatch):
+    """A cost matrix the assignment solver rejects (non-finite) must not leave the stream parked: the worker writes
+    'no match' and sets the flag; the error surfaces at the next join."""
+    from future_od.models.set_criterion import SetCriterion, build_matcher, _async_lap
+    from future_od.models.st_detr import SpatioTemporalDETRArgs
+    from future_od.native.lib import FodError
+    monkeypatch.setenv("FOD_ASYNC_MATCH", "1")
+    crit = SetCriterion(8, build_matcher(SpatioTemporalDETRArgs(num_classes=8)), {}, 0.25,
+                        ["labels", "boxes", "cardinality"], "per level")
+    logits, boxes, targets = _criterion_inputs(seed=5)
+    with torch.no_grad():
+        bad = boxes.detach().clone()
+        bad[0, 0, 0, 0] = float("nan")
+    out = crit({"_stacked": (logits.detach(), bad)}, targets, distributed=False)
+    torch.cuda.synchronize()                                   # returns: the stream was released
+    with pytest.raises(FodError):
+        _async_lap(torch.device(DEV)).join()
+    logits2, boxes2, targets2 = _criterion_inputs(seed=6)      # and the next submission works
+    out2 = crit({"_stacked": (logits2, boxes2)}, targets2, distributed=False)
+    assert torch.isfinite(out2.table[:, :3]).all()
