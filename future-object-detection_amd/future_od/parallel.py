@@ -51,21 +51,42 @@ class GradientReducer:
         self.enabled = True
         self.stats = {"arena_flushes": 0, "arena_elems": 0, "stragglers": 0}      # of the last backward
         self._checks_left = 3
+        self._verdict = None
         self._stats = dict(self.stats)
         self._reset()
 
     def _check_layout(self):
         """In-place averaging of arena regions assumes that every rank allocated the same gradients in the same
-        order.  Verified (blocking) in the first steps: the flush counts and sizes must agree across ranks."""
+        order.  Verified in the first steps: the flush counts and sizes must agree across ranks.  The verdict of a
+        step is read at the end of the NEXT backward (through pinned memory and an event), so the check never stalls
+        the launching thread on the GPU."""
+        self._read_layout_verdict()
         s = self.stats
         mine = torch.tensor([s["arena_flushes"], s["arena_elems"], s["stragglers"]], dtype=torch.int64)
         dev = self.comm.device if self.comm is not None else torch.device("cpu")
         lo, hi = mine.to(dev), mine.to(dev)
         dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
-        if not torch.equal(lo.cpu(), hi.cpu()):
+        if dev.type == "cuda":
+            both = torch.empty((2, 3), dtype=torch.int64, pin_memory=True)
+            both.copy_(torch.stack([lo, hi]), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            both, ev = torch.stack([lo, hi]), None
+        self._verdict = (mine, both, ev)
+        if ev is None:
+            self._read_layout_verdict()          # CPU tensors: nothing to wait for
+
+    def _read_layout_verdict(self):
+        if self._verdict is None:
+            return
+        (mine, both, ev), self._verdict = self._verdict, None
+        if ev is not None:
+            ev.synchronize()
+        if not torch.equal(both[0], both[1]):
             raise RuntimeError(f"FodDataParallel: ranks disagree on the gradient layout (this rank {mine.tolist()}, "
-                               f"min {lo.tolist()}, max {hi.tolist()}): the autograd graphs differ between ranks")
+                               f"min {both[0].tolist()}, max {both[1].tolist()}): the autograd graphs differ between ranks")
 
     def _reset(self):
         self.flushed = 0                 # arena elements already queued for reduction in this backward
@@ -165,6 +186,8 @@ class GradientReducer:
             if self._checks_left > 0:
                 self._checks_left -= 1
                 self._check_layout()
+            else:
+                self._read_layout_verdict()      # of the last checked step
         finally:
             self._reset()
 
