@@ -156,6 +156,36 @@ extern "C" int fod_host_flag_destroy(void* flag) {
   return (!flag || hipHostFree(flag) == hipSuccess) ? FOD_OK : FOD_ERR_RUNTIME;
 }
 
+extern "C" int fod_host_alloc(void** p, size_t bytes) {
+  if (!p || !bytes) return FOD_ERR_ARG;
+  void* q = nullptr;
+  if (hipHostMalloc(&q, bytes, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+    fod_set_error("host alloc: hipHostMalloc(%zu) failed", bytes);
+    return FOD_ERR_RUNTIME;
+  }
+  *p = q;
+  return FOD_OK;
+}
+
+extern "C" int fod_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? FOD_OK : FOD_ERR_RUNTIME; }
+
+namespace {
+__global__ void copy_words_kernel(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    dst[i] = __builtin_nontemporal_load(src + i);      // host memory, read when the kernel RUNS
+}
+}  // namespace
+
+extern "C" int fod_copy_from_host_i32(const int32_t* src_host, int32_t* dst, int n, fod_stream_t stream) {
+  if (!src_host || !dst || n <= 0) {
+    fod_set_error("copy_from_host_i32: bad args");
+    return FOD_ERR_ARG;
+  }
+  const int blocks = std::min((n + 255) / 256, 64);
+  hipLaunchKernelGGL(copy_words_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src_host, dst, n);
+  return hipGetLastError() == hipSuccess ? FOD_OK : FOD_ERR_RUNTIME;
+}
+
 extern "C" int fod_host_flag_set(void* flag, uint32_t value) {
   if (!flag) return FOD_ERR_ARG;
   __atomic_store_n(reinterpret_cast<uint32_t*>(flag), value, __ATOMIC_RELEASE);

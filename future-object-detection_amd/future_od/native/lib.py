@@ -86,6 +86,9 @@ SIGNATURES = {
     "fod_lap_solve_batch_host": [_p, _i, _i, _i, _p, _p, _i],
     "fod_host_flag_create": [C.POINTER(C.c_void_p)],
     "fod_host_flag_destroy": [_p],
+    "fod_host_alloc": [C.POINTER(C.c_void_p), C.c_size_t],
+    "fod_host_free": [_p],
+    "fod_copy_from_host_i32": [_p, _p, _i, _p],
     "fod_host_flag_set": [_p, C.c_uint32],
     "fod_stream_wait_flag": [_p, C.c_uint32, _p],
     "fod_match_after_event": [_i, _p, _p, _i, _i, _i, _p, _p, _p, _p, C.c_uint32, _i],

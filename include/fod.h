@@ -260,6 +260,13 @@ int fod_lap_solve_batch_host(const float* cost_host, int nprob, int M, int ld_n,
  * with release order.  The flag is ALWAYS stored, also on failure (match_out = -1), so the stream cannot stay parked.
  * A flag is 8 bytes of coherent pinned host memory; tickets must increase (the stream waits for *flag >= ticket). */
 int fod_host_flag_create(void** flag);
+/* Coherent, device-mapped pinned host memory (the worker's match_out) and a kernel that copies it to device memory:
+ * the source is read when the kernel RUNS, after the parked stream has been released, by construction.
+ * (hipMemcpyAsync from pinned memory was measured to behave the same on this stack for 256 B .. 256 KB,
+ * tools/probe_pinned_copy_capture.py; the kernel removes the dependency on that.) */
+int fod_host_alloc(void** p, size_t bytes);
+int fod_host_free(void* p);
+int fod_copy_from_host_i32(const int32_t* src_host, int32_t* dst, int n, fod_stream_t stream);
 int fod_host_flag_destroy(void* flag);
 int fod_host_flag_set(void* flag, uint32_t value);
 int fod_stream_wait_flag(void* flag, uint32_t value, fod_stream_t stream);

@@ -219,7 +219,7 @@ def test_async_matcher_equals_host_synchronous_matcher(monkeypatch):
     crit = SetCriterion(8, build_matcher(SpatioTemporalDETRArgs(num_classes=8)), {}, 0.25,
                         ["labels", "boxes", "cardinality"], "per level")
     res = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):                              # host sync / adaptive / always through the worker
         monkeypatch.setenv("FOD_ASYNC_MATCH", mode)
         tables = []
         for it in range(3):                                   # several tickets in flight one after the other
@@ -229,8 +229,9 @@ def test_async_matcher_equals_host_synchronous_matcher(monkeypatch):
             tables.append((out.table.detach().cpu(), logits.grad.cpu(), boxes.grad.cpu()))
         res[mode] = tables
     _async_lap(torch.device(DEV)).join()
-    for (t0, gl0, gb0), (t1, gl1, gb1) in zip(res["0"], res["1"]):
-        assert torch.equal(t0, t1) and torch.equal(gl0, gl1) and torch.equal(gb0, gb1)
+    for mode in ("1", "2"):
+        for (t0, gl0, gb0), (t1, gl1, gb1) in zip(res["0"], res[mode]):
+            assert torch.equal(t0, t1) and torch.equal(gl0, gl1) and torch.equal(gb0, gb1), mode
 
 
 def test_async_matcher_failure_releases_the_stream_and_raises_late(monkeypatch):
@@ -239,7 +240,7 @@ def test_async_matcher_failure_releases_the_stream_and_raises_late(monkeypatch):
     from future_od.models.set_criterion import SetCriterion, build_matcher, _async_lap
     from future_od.models.st_detr import SpatioTemporalDETRArgs
     from future_od.native.lib import FodError
-    monkeypatch.setenv("FOD_ASYNC_MATCH", "1")
+    monkeypatch.setenv("FOD_ASYNC_MATCH", "2")                 # through the worker thread
     crit = SetCriterion(8, build_matcher(SpatioTemporalDETRArgs(num_classes=8)), {}, 0.25,
                         ["labels", "boxes", "cardinality"], "per level")
     logits, boxes, targets = _criterion_inputs(seed=5)

@@ -11,6 +11,9 @@ from future_od.datasets.synthetic import make_batch
 from future_od.optim import FusedAdamW
 
 ddp = len(sys.argv) > 1 and sys.argv[1] == "ddp"
+if os.environ.get("NOGC"):
+    import gc
+    gc.disable()
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 if ddp:
