@@ -85,8 +85,8 @@ class _AsyncLap:
         self.L, self.C = L, C
         self.device = device
         flag = C.c_void_p()
-        L._plain_call("fod_host_flag_create", C.byref(flag))
-        self.flag = flag
+        L._plain_call("fod_host_flag_create", C.addressof(flag))
+        self.flag = flag.value
         self.ticket = 0
         self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix="fod-matcher")
         self.prev = None
@@ -103,8 +103,8 @@ class _AsyncLap:
                 L._plain_call("fod_host_free", self.slots[i][0])
             p = C.c_void_p()
             cap = max(words, 4096)
-            L._plain_call("fod_host_alloc", C.byref(p), cap * 4)
-            self.slots[i] = (p, cap)
+            L._plain_call("fod_host_alloc", C.addressof(p), cap * 4)
+            self.slots[i] = (p.value, cap)
         return self.slots[i][0]
 
     def _job(self, event, cost_h, n_cols, col_off, match_host, ticket, threads):
@@ -112,9 +112,9 @@ class _AsyncLap:
         P, M, ld = cost_h.shape
         # one foreign call (the GIL is released for all of it): event wait, assignment, offsets, flag
         L._plain_call("fod_match_after_event", self.device.index or 0,
-                      C.c_void_p(event.cuda_event) if event is not None else None,
-                      C.c_void_p(cost_h.data_ptr()), P, M, ld, C.c_void_p(n_cols.data_ptr()),
-                      C.c_void_p(col_off.data_ptr()), match_host, self.flag, ticket, threads)
+                      event.cuda_event if event is not None else None,
+                      cost_h.data_ptr(), P, M, ld, n_cols.data_ptr(), col_off.data_ptr(), match_host, self.flag,
+                      ticket, threads)
 
     def join(self):
         prev, self.prev = self.prev, None
@@ -134,7 +134,7 @@ class _AsyncLap:
         self.ticket += 1
         match_host = self._slot(Lv * B * M)
         match = torch.empty((Lv, B, M), dtype=torch.int32, device=cost.device)
-        stream = C.c_void_p(torch.cuda.current_stream(cost.device).cuda_stream)
+        stream = torch.cuda.current_stream(cost.device).cuda_stream
         inline = False
         import os
         for _ in range(0 if os.environ.get("FOD_ASYNC_MATCH") == "2" else 8):      # "2": always park (tests)
@@ -153,7 +153,7 @@ class _AsyncLap:
                 raise
             L._plain_call("fod_stream_wait_flag", self.flag, self.ticket, stream)
         # the host block is read when this kernel RUNS, i.e. after the worker has released the stream
-        L._plain_call("fod_copy_from_host_i32", match_host, C.c_void_p(match.data_ptr()), Lv * B * M, stream)
+        L._plain_call("fod_copy_from_host_i32", match_host, match.data_ptr(), Lv * B * M, stream)
         return match
 
 

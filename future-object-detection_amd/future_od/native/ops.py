@@ -30,14 +30,24 @@ def stream():
     """hipStream_t of torch's current stream on the current device.  The raw getter is ~30x cheaper than
     building a torch.cuda.Stream object per launch (9 us -> 0.3 us; there are ~2500 launches per step)."""
     if _raw_stream is not None:
-        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return _raw_stream(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Addr(int):
+    """Address of a ctypes structure as an int that keeps the structure alive while it is an argument."""
+
+    def __new__(cls, struct):
+        self = super().__new__(cls, C.addressof(struct))
+        self.keep = struct
+        return self
 
 
 def ptr(t):
+    """Address as a plain int (None = NULL): what the fast-call wrappers and ctypes' c_void_p both accept."""
     if t is None:
         return None
-    return C.c_void_p(t.data_ptr())
+    return t.data_ptr()
 
 
 def _chk(t, name, dtype=None):
@@ -54,8 +64,9 @@ def _epi(scale=None, shift=None, residual=None, ld_residual=0, residual_row_mod=
          ld_mask=0, relu=False, out_f32=False):
     if scale is None and shift is None and residual is None and relu_mask is None and not relu and not out_f32:
         return None
-    return C.byref(Epilogue(ptr(scale), ptr(shift), ptr(residual), ld_residual, residual_row_mod,
-                            ptr(relu_mask), ld_mask, int(relu), int(out_f32)))
+    e = Epilogue(ptr(scale), ptr(shift), ptr(residual), ld_residual, residual_row_mod,
+                 ptr(relu_mask), ld_mask, int(relu), int(out_f32))
+    return _Addr(e)
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
@@ -186,7 +197,7 @@ def conv2d_fwd(x, w, geom, *, scale=None, shift=None, residual=None, relu=False)
             _chk(v, "scale/shift", torch.float32); assert v.numel() == geom.Cout
     if residual is not None:
         _chk(residual, "residual", x.dtype); assert residual.shape == y.shape
-    call("fod_conv2d_fwd", dt(x), ptr(x), ptr(w), ptr(y), C.byref(geom),
+    call("fod_conv2d_fwd", dt(x), ptr(x), ptr(w), ptr(y), _Addr(geom),
          _epi(scale, shift, residual, geom.Cout, 0, None, 0, relu), stream(), work=_conv_flops(geom))
     return y
 
@@ -200,7 +211,7 @@ def conv2d_dgrad(dy, w_t, geom, *, residual=None, relu_mask=None):
     for v in (residual, relu_mask):
         if v is not None:
             _chk(v, "residual/mask", dy.dtype); assert v.shape == dx.shape
-    call("fod_conv2d_dgrad", dt(dy), ptr(dy), ptr(w_t), ptr(dx), C.byref(geom),
+    call("fod_conv2d_dgrad", dt(dy), ptr(dy), ptr(w_t), ptr(dx), _Addr(geom),
          _epi(None, None, residual, geom.Cin, 0, relu_mask, geom.Cin, False), stream(), work=_conv_flops(geom))
     return dx
 
@@ -212,7 +223,7 @@ def conv2d_wgrad_acc(dy, x, dw, geom, row_scale=None, zeroed=False):
     assert dw.numel() == geom.Cout * geom.kh * geom.kw * geom.Cin
     if row_scale is not None:
         _chk(row_scale, "row_scale", torch.float32); assert row_scale.numel() == geom.Cout
-    call("fod_conv2d_wgrad_acc", dt(dy), ptr(dy), ptr(x), ptr(dw), C.byref(geom), ptr(row_scale),
+    call("fod_conv2d_wgrad_acc", dt(dy), ptr(dy), ptr(x), ptr(dw), _Addr(geom), ptr(row_scale),
          0 if zeroed else 1, stream(),
          work=_conv_flops(geom))
     return dw
@@ -325,7 +336,7 @@ def attn_fwd(q1, k1, v, scale, q2=None, k2=None, drop_p=0.0, drop_seed=0):
     lse2 = torch.empty((q1.shape[0], H, q1.shape[1]), dtype=torch.float32, device=q1.device)
     parts = 2 if q2 is not None else 1
     call("fod_attn_fwd", dt(q1), ptr(q1), ptr(k1), ptr(q2), ptr(k2), ptr(v), ptr(o), ptr(lse2),
-         C.byref(shp), stream(), work=2.0 * shp.B * H * shp.Tq * shp.S * 32 * (parts + 1))
+         _Addr(shp), stream(), work=2.0 * shp.B * H * shp.Tq * shp.S * 32 * (parts + 1))
     return o, lse2
 
 
@@ -354,7 +365,7 @@ def attn_bwd(q1, k1, v, o, dout, lse2, scale, q2=None, k2=None, dk1_out=None, dv
     assert lse2.shape == (q1.shape[0], H, q1.shape[1])
     delta = torch.empty_like(lse2)
     call("fod_attn_bwd", dt(q1), ptr(q1), ptr(k1), ptr(q2), ptr(k2), ptr(v), ptr(o), ptr(dout), ptr(lse2),
-         ptr(delta), ptr(dq1), ptr(dk1), ptr(dq2), ptr(dk2), ptr(dv), C.byref(shp), stream(),
+         ptr(delta), ptr(dq1), ptr(dk1), ptr(dq2), ptr(dk2), ptr(dv), _Addr(shp), stream(),
          work=2.0 * shp.B * H * shp.Tq * shp.S * 32 * (3 * (2 if q2 is not None else 1) + 2))
     return dq1, dk1, dq2, dk2, dv
 
@@ -425,7 +436,7 @@ def dropout(a, p, seed):
     """a * mask / (1 - p) with the stateless mask of call `seed` (the same call on a gradient is the backward)."""
     _chk(a, "a")
     out = torch.empty_like(a)
-    call("fod_dropout", dt(a), ptr(out), ptr(a), a.numel(), C.c_ulonglong(seed & 0xFFFFFFFFFFFFFFFF), float(p), stream())
+    call("fod_dropout", dt(a), ptr(out), ptr(a), a.numel(), seed & 0xFFFFFFFFFFFFFFFF, float(p), stream())
     return out
 
 
@@ -506,8 +517,7 @@ def lap_solve_batch_host(cost_cpu, n_cols, threads=8):
     nc = torch.tensor(n_cols, dtype=torch.int32)
     assert nc.numel() == P
     out = torch.empty((P, M), dtype=torch.int32)
-    call("fod_lap_solve_batch_host", C.c_void_p(cost_cpu.data_ptr()), P, M, ld, C.c_void_p(nc.data_ptr()),
-         C.c_void_p(out.data_ptr()), threads)
+    call("fod_lap_solve_batch_host", cost_cpu.data_ptr(), P, M, ld, nc.data_ptr(), out.data_ptr(), threads)
     return out
 
 

@@ -122,3 +122,18 @@ def test_synthetic_loaders_shard_like_the_reference():
     assert torch.equal(a0[0]["temporal_offsets"][0], torch.tensor([-1.0, -0.5, 0.0]))
     assert not torch.equal(a0[0]["video"], a1[0]["video"]) and not torch.equal(a0[0]["video"], a0[1]["video"])
     assert torch.equal(list(loaders[0])[2]["boxes"], a0[2]["boxes"])          # an epoch repeats
+
+
+def test_fastcall_wrappers_cover_every_entry_point_and_agree_with_ctypes():
+    """The generated CPython wrappers (csrc/fastcall.c -> lib/_fodfast.so) call the same library: one wrapper per
+    signature, same status codes and error text as the ctypes path on a call that fails its argument check."""
+    from future_od.native import lib as L
+    assert set(L.FAST) == set(L.SIGNATURES), sorted(set(L.SIGNATURES) ^ set(L.FAST))
+    args = (0, None, 0, 0, 0, 0, None, None)                       # fod_colsum_acc with null operands: rejected on the host
+    rc_fast = L.FAST["fod_colsum_acc"](*args)
+    msg_fast = L.last_error()
+    rc_ct = L.LIB.fod_colsum_acc(*args)
+    assert rc_fast == rc_ct != 0 and msg_fast == L.last_error()
+    assert L.FAST["fod_multi_permute_chunk"]() == L.LIB.fod_multi_permute_chunk()
+    with pytest.raises(TypeError):
+        L.FAST["fod_colsum_acc"](0, None)                          # wrong arity is a Python error, not a wild call

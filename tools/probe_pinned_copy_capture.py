@@ -7,13 +7,13 @@ import torch
 from future_od.native import lib as L
 
 dev = torch.device("cuda", 0)
-flag = C.c_void_p(); L._plain_call("fod_host_flag_create", C.byref(flag))
+_f = C.c_void_p(); L._plain_call("fod_host_flag_create", C.addressof(_f)); flag = _f.value
 ticket = 0
 for words in (64, 256, 1024, 1536, 4096, 65536):
     ticket += 1
     h = torch.zeros(words, dtype=torch.int32).pin_memory()
     torch.cuda.synchronize()
-    s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    s = torch.cuda.current_stream(dev).cuda_stream
     L._plain_call("fod_stream_wait_flag", flag, ticket, s)
     d = h.to(dev, non_blocking=True)            # queued behind the parked wait
     time.sleep(0.02)
