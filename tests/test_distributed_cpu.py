@@ -57,3 +57,52 @@ def test_world_size_two_gloo():
         assert r[2] == pytest.approx(max(sum(locals_) / world, 1.0))      # mean boxes per rank, same on all ranks
         assert r[3] == {"a": pytest.approx(15.0), "b": pytest.approx(1.5)}
         assert r[4] == [0.0, 1.0] and r[5] == [True, True] and r[6] == [0, 1]
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from future_od.parallel import FodDataParallel
+    torch.manual_seed(0)                                   # same initial weights; rank 0's are broadcast anyway
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    ddp = FodDataParallel(net)
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(4, 6, generator=g)
+    # reference: local gradients without communication, then averaged by hand
+    with ddp.no_sync():
+        ddp(x).pow(2).sum().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    want = []
+    for t in local:
+        bufs = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(bufs, t)
+        want.append(sum(bufs) / world)
+    for p in net.parameters():
+        p.grad = None
+    ddp(x).pow(2).sum().backward()                         # the product path: gradients averaged when backward returns
+    got = [p.grad.clone() for p in net.parameters()]
+    err = max(float((a - b).abs().max()) for a, b in zip(got, want))
+    differ = max(float((a - b).abs().max()) for a, b in zip(local, want))
+    q.put((rank, err, differ, dict(ddp.grad_reducer.stats)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_reducer_averages_over_two_gloo_ranks():
+    """FodDataParallel's own reducer (torch's is bypassed) on CPU tensors: gradients that do not live in the device
+    arena travel as one packed all-reduce per dtype and come back averaged, exactly as hand-averaged no_sync()
+    gradients; isinstance(DistributedDataParallel) and .module keep working for the reference's Trainer."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, err, differ, stats in res:
+        assert err < 1e-6, (rank, err)
+        assert differ > 1e-3                                # the ranks really had different gradients
+        assert stats["stragglers"] == 4 and stats["arena_flushes"] == 0
