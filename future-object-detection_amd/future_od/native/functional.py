@@ -100,7 +100,7 @@ class _Prepared:
                 [(j.src, j.dst, j.scale) for j in jobs])       # keep the operands alive while the table exists
 
     def clear(self):
-        self._store.clear()
+        self._store = {}                 # a NEW dict: per-parameter memos (prep_linear) compare its identity
         self._tables.clear()
 
 
@@ -120,6 +120,7 @@ class _ZeroArena:
         self.high = 0
         self.active = False
         self.extra = []
+        self.cap = 0
 
     def recycle(self, device):
         device = torch.device(device)
@@ -132,16 +133,29 @@ class _ZeroArena:
         self.high = 0
         self.extra = []
         self.active = True
+        self.cap = self.buf.numel()
 
     def zeros(self, shape, device):
-        n = 1
-        for d in shape:
-            n *= d
+        # ~800 calls per step: one aten call (as_strided) instead of slice + view, no torch.device() construction
+        nd = len(shape)
+        if nd == 1:
+            n = shape[0]
+            stride = (1,)
+        elif nd == 2:
+            n = shape[0] * shape[1]
+            stride = (shape[1], 1)
+        else:
+            n = 1
+            stride = [1] * nd
+            for i in range(nd - 1, -1, -1):
+                stride[i] = n
+                n *= shape[i]
         n_al = (n + 63) // 64 * 64           # keep every slice 256-byte aligned
         self.high += n_al
-        if not self.active or self.buf.device != torch.device(device) or self.off + n_al > self.buf.numel():
+        buf = self.buf
+        if not self.active or self.off + n_al > self.cap or (buf.device != device and buf.device != torch.device(device)):
             return torch.zeros(shape, dtype=torch.float32, device=device)
-        out = self.buf[self.off:self.off + n].view(shape)
+        out = buf.as_strided(shape, stride, self.off)
         self.off += n_al
         return out
 
@@ -172,6 +186,12 @@ def _wkey(p, kind, dtype, extra=()):
 
 def prep_linear(weight, dtype, transposed):
     """weight [N,K] f32 -> [Np,K] (rows zero-padded to the vector width) or its transpose [K,Np]."""
+    # fast path (~270 calls per step): the registry entry is remembered on the parameter object itself
+    memo = weight.__dict__.get("_fod_prep")
+    if memo is not None:
+        e = memo.get((transposed, dtype))
+        if e is not None and e[0] is PREP._store and e[2] == weight.data_ptr() and e[1].vers == (weight._version,):
+            return e[1].value
     N, K = weight.shape
     v = _VEC[dtype]
     assert K % v == 0, f"Linear in_features {K} must be a multiple of {v} (pad the input)"
@@ -186,7 +206,15 @@ def prep_linear(weight, dtype, transposed):
         out = torch.empty((K, Np), dtype=dtype, device=w.device)      # dst[1][k][n] = w[n][k], columns n >= N zero
         return out, [_Job(w, out, (1, K, Np), (0, sk, sn), valid2=N)]
 
-    return PREP.get(_wkey(weight, "lin_t" if transposed else "lin", dtype), [weight], build)
+    key = _wkey(weight, "lin_t" if transposed else "lin", dtype)
+    value = PREP.get(key, [weight], build)
+    if weight.__dict__.get("_fod_prep") is None:
+        try:
+            weight._fod_prep = {}
+        except Exception:            # not an attribute-capable tensor (should not happen for Parameters)
+            return value
+    weight._fod_prep[(transposed, dtype)] = (PREP._store, PREP._store[key], weight.data_ptr())
+    return value
 
 
 def prep_conv(weight, dtype, scale, transposed, cin_pad=None):
