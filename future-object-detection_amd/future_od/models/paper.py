@@ -296,9 +296,11 @@ class FuturePredCore(nn.Module):
         self.compute_dtype = torch.bfloat16
         self.skip_dead_frames = True
 
+    drop_future = True                     # the last frame of the clip is the one to predict, never an input
+
     def forward(self, images: Tensor, imu: Tensor = None, temporal_offsets: Tensor = None):
         B, L = images.shape[:2]
-        past = L - 1
+        past = L - 1 if self.drop_future else L
         assert past > 0
         all_at_once = self.detector.image_memory_mode == "attend all at once"
         keep = self.detector.frames_needed(past) if (self.skip_dead_frames or all_at_once) else past
@@ -337,3 +339,24 @@ class FuturePredCore(nn.Module):
             out = self.detector(frames, pos_all() if all_at_once else pos_last(), num_frames_total=past, egodeep=e)
         moods = [["model happy" for _ in range(L)] for _ in range(B)]
         return out, moods
+
+
+class SingleFrameCore(FuturePredCore):
+    """Detections for the LAST frame of the clip from the clip itself (reference paper.py:488-528): nothing is dropped,
+    there is no joint encoder; with the usual one-frame clips this is plain single-image ConditionalDETR, the paper's
+    single-frame baseline.  State-dict keys follow the reference: the SeparateEncoder is called `encoder`."""
+
+    drop_future = False
+
+    def __init__(self, encoder: SeparateEncoder, detector: CDetrDetectorSpatioTemporal, pos_encoder: PositionalEncoder):
+        nn.Module.__init__(self)
+        self.encoder = encoder
+        self.joint_encoder = None
+        self.detector = detector
+        self.pos_encoder = pos_encoder
+        self.compute_dtype = torch.bfloat16
+        self.skip_dead_frames = True
+
+    @property
+    def separate_encoder(self):
+        return self.encoder

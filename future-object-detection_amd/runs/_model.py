@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 import future_od.models.transformer as transformer
-from future_od.models.paper import (JointEncoder, JointEncoderSequential, CDetrBackbone, CDetrDetectorSpatioTemporal, FuturePredCore,
+from future_od.models.paper import (JointEncoder, JointEncoderSequential, SingleFrameCore, CDetrBackbone, CDetrDetectorSpatioTemporal, FuturePredCore,
                                     PositionalEncoder, SeparateEncoder)
 from future_od.models.st_detr import SpatioTemporalDETR, SpatioTemporalDETRArgs
 from future_od.native import functional as Fn
@@ -45,7 +45,10 @@ def _joint_encoder(args, detr_args):
 def build_model(args, detr_args: SpatioTemporalDETRArgs):
     Fn.PREP.clear()
     num_images = getattr(args, "num_images", 2)
-    core = FuturePredCore(
+    single = getattr(args, "core", "future_pred") == "single_frame"       # paper.py:488 SingleFrameCore (baseline)
+    make_core = (lambda separate_encoder, joint_encoder, **kw: SingleFrameCore(encoder=separate_encoder, **kw)) \
+        if single else FuturePredCore
+    core = make_core(
         separate_encoder=SeparateEncoder(
             backbone=CDetrBackbone(name=getattr(args, "backbone", "resnet50"),
                                    train_backbone=detr_args.lr_backbone > 0, dilation=False,

@@ -53,6 +53,8 @@ class Config:
     joint_egodeep: bool = False         # transformer.py:442-447 IMU attention in the joint layers (keys: 1 token sequential, L tokens joint)
     dec_slotstates: bool = False        # transformer.py:210-215 decoder layers attend to the previous frame's final queries
     dec_egodeep: bool = False           # transformer.py:217-222 decoder layers attend to the frame's IMU token
+    single_frame: bool = False          # paper.py:488-528 SingleFrameCore: no frame is dropped, no joint encoder; its
+                                        # SeparateEncoder is called `encoder` (see rename_for_core)
     train_backbone: bool = True         # runs/_model.py:21 (lr_backbone > 0)
     # matcher / loss (st_detr.py:41-51)
     set_cost_class: float = 2.0
@@ -557,13 +559,23 @@ def detector_forward(sd, cfg, features, pos_enc, skip_dead=False, attn_out=None,
     return out
 
 
+def rename_for_core(sd, cfg):
+    """The same tensors under the key names of the reference core that cfg selects: SingleFrameCore calls its
+    SeparateEncoder `encoder` (paper.py:499), FuturePredCore `separate_encoder` (paper.py:444)."""
+    if not cfg.single_frame:
+        return sd
+    return {k.replace(P_SEP, P_CORE + "encoder.", 1) if k.startswith(P_SEP) else k: v for k, v in sd.items()}
+
+
 def core_forward(sd, cfg, images, imu=None, temporal_offsets=None, skip_dead=False, taps=None,
                  attn_out=None):
-    """FuturePredCore.forward.  paper.py:448-485.  images (B,L,3,H,W), imu (B,L,14)."""
-    images = images[:, :-1]
-    imu = imu[:, :-1] if imu is not None else None
-    if temporal_offsets is not None:
-        temporal_offsets = temporal_offsets[:, :-1]
+    """FuturePredCore.forward (paper.py:448-485) or, with cfg.single_frame, SingleFrameCore.forward (:502-528), which
+    differs in not dropping the last frame and having no joint encoder.  images (B,L,3,H,W), imu (B,L,14)."""
+    if not cfg.single_frame:
+        images = images[:, :-1]
+        imu = imu[:, :-1] if imu is not None else None
+        if temporal_offsets is not None:
+            temporal_offsets = temporal_offsets[:, :-1]
     if skip_dead and cfg.image_memory_mode == "attend one at a time" and not cfg.joint_layers and not cfg.dec_slotstates:
         keep = min(cfg.num_images, images.shape[1])
         images = images[:, -keep:]

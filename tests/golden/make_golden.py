@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "future-object-detection_amd"))
 
 from oracle import thirdparty  # noqa: E402
-from oracle.stdetr import Config, make_state_dict, param_spec  # noqa: E402
+from oracle.stdetr import Config, make_state_dict, param_spec, rename_for_core  # noqa: E402
 
 REF = "/root/reference"
 
@@ -78,14 +78,16 @@ def build_reference(cfg: Config, paper, transformer, st_detr):
         transformer.TransformerEncoderLayer(D=cfg.hidden_dim, Nhead=cfg.nheads, Dff=cfg.dim_feedforward,
                                             use_egodeep=cfg.use_imu)
         for _ in range(cfg.enc_layers)))
-    core = paper.FuturePredCore(
-        separate_encoder=paper.SeparateEncoder(
-            backbone=paper.CDetrBackbone(name=cfg.backbone, train_backbone=True, dilation=False,
-                                         hidden_dim=cfg.hidden_dim, pretrained=False),
-            imu_layers=nn.Sequential(nn.Linear(cfg.imu_dim, cfg.imu_hidden), nn.ReLU(inplace=True),
-                                     nn.Linear(cfg.imu_hidden, cfg.hidden_dim)) if cfg.use_imu else None,
-            transformer=enc),
-        joint_encoder=joint_encoder(cfg, paper, transformer),
+    sep = paper.SeparateEncoder(
+        backbone=paper.CDetrBackbone(name=cfg.backbone, train_backbone=True, dilation=False,
+                                     hidden_dim=cfg.hidden_dim, pretrained=False),
+        imu_layers=nn.Sequential(nn.Linear(cfg.imu_dim, cfg.imu_hidden), nn.ReLU(inplace=True),
+                                 nn.Linear(cfg.imu_hidden, cfg.hidden_dim)) if cfg.use_imu else None,
+        transformer=enc)
+    core_kw = dict(encoder=sep) if cfg.single_frame else dict(separate_encoder=sep,
+                                                              joint_encoder=joint_encoder(cfg, paper, transformer))
+    core = (paper.SingleFrameCore if cfg.single_frame else paper.FuturePredCore)(
+        **core_kw,
         detector=paper.CDetrDetectorSpatioTemporal(
             decoder=transformer.TransformerDecoder(
                 layers=nn.ModuleList([
@@ -104,7 +106,7 @@ def build_reference(cfg: Config, paper, transformer, st_detr):
 
 
 def load_weights(model, cfg, seed):
-    sd = make_state_dict(cfg, seed)
+    sd = rename_for_core(make_state_dict(cfg, seed), cfg)
     ref_keys = set(model.state_dict().keys())
     assert ref_keys == set(sd.keys()), (sorted(ref_keys ^ set(sd.keys()))[:20])
     model.load_state_dict(sd)
@@ -196,6 +198,10 @@ def main():
                                           first_layer_special_when="first frame"), 2, 4, 64, 96, 18),
         # IMU attention with SEVERAL keys: the joint encoder's layers and the all-at-once detector attend to the IMU
         # tokens of all past frames (paper.py:196-198, 337-339)
+        # SingleFrameCore (paper.py:488-528): the single-frame baseline; a three-frame clip exercises its frame loop
+        # (the first frame is dead work with num_images = 2)
+        "g17_single_frame_core": (Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2,
+                                         single_frame=True), 2, 3, 64, 96, 20),
         "g16_multikey_egodeep": (Config(backbone="resnet18", enc_layers=1, joint_layers=1, joint_egodeep=True,
                                         dec_layers=2, num_images=1, image_memory_mode="attend all at once",
                                         dec_egodeep=True, no_temporal=False), 2, 4, 64, 96, 19),
@@ -221,10 +227,10 @@ def main():
             if not cfg.no_temporal:                       # as st_detr.py:115-118 does with encode_offset
                 kw["temporal_offsets"] = data["temporal_offsets"]
             core_out, _ = model._model(data["video"], **kw)
-            # dead-work equivalence (G10): feed only the last K past frames (+ future frame)
-            keep = min(cfg.num_images, L - 1)
-            kw2 = {k: v[:, -(keep + 1):] for k, v in kw.items()}
-            core_out_dead, _ = model._model(data["video"][:, -(keep + 1):], **kw2)
+            # dead-work equivalence (G10): feed only the last K past frames (+ future frame, unless single-frame core)
+            keep = min(cfg.num_images, L) if cfg.single_frame else min(cfg.num_images, L - 1) + 1
+            kw2 = {k: v[:, -keep:] for k, v in kw.items()}
+            core_out_dead, _ = model._model(data["video"][:, -keep:], **kw2)
         arrays = {
             "meta": np.array([B, L, H, W, seed]),
             "pred_logits": core_out["pred_logits"], "pred_boxes": core_out["pred_boxes"],

@@ -19,7 +19,7 @@ DEV = "cuda:0"
 
 if torch.cuda.is_available():
     import future_od.models.transformer as T
-    from future_od.models.paper import (CDetrBackbone, CDetrDetectorSpatioTemporal, FuturePredCore, JointEncoder, JointEncoderSequential,
+    from future_od.models.paper import (CDetrBackbone, CDetrDetectorSpatioTemporal, FuturePredCore, JointEncoder, JointEncoderSequential, SingleFrameCore,
                                         PositionalEncoder, SeparateEncoder)
     from future_od.models.st_detr import SpatioTemporalDETR, SpatioTemporalDETRArgs
     from future_od.native import functional as Fn
@@ -44,15 +44,16 @@ def build_product(cfg: Config, dtype, seed):
                                   dim_feedforward=cfg.dim_feedforward, hidden_dim=cfg.hidden_dim,
                                   enc_nheads=cfg.nheads, nheads=cfg.nheads, pretrained_backbone=False,
                                   encode_offset=not cfg.no_temporal)
-    core = FuturePredCore(
-        separate_encoder=SeparateEncoder(
-            backbone=CDetrBackbone(cfg.backbone, True, False, cfg.hidden_dim, pretrained=False),
-            imu_layers=nn.Sequential(nn.Linear(cfg.imu_dim, cfg.imu_hidden), nn.ReLU(inplace=True),
-                                     nn.Linear(cfg.imu_hidden, cfg.hidden_dim)) if cfg.use_imu else None,
-            transformer=T.TransformerEncoder(nn.ModuleList(
-                T.TransformerEncoderLayer(cfg.hidden_dim, cfg.nheads, cfg.dim_feedforward, use_egodeep=cfg.use_imu)
-                for _ in range(cfg.enc_layers)))),
-        joint_encoder=build_joint(cfg),
+    sep = SeparateEncoder(
+        backbone=CDetrBackbone(cfg.backbone, True, False, cfg.hidden_dim, pretrained=False),
+        imu_layers=nn.Sequential(nn.Linear(cfg.imu_dim, cfg.imu_hidden), nn.ReLU(inplace=True),
+                                 nn.Linear(cfg.imu_hidden, cfg.hidden_dim)) if cfg.use_imu else None,
+        transformer=T.TransformerEncoder(nn.ModuleList(
+            T.TransformerEncoderLayer(cfg.hidden_dim, cfg.nheads, cfg.dim_feedforward, use_egodeep=cfg.use_imu)
+            for _ in range(cfg.enc_layers))))
+    core_kw = dict(encoder=sep) if cfg.single_frame else dict(separate_encoder=sep, joint_encoder=build_joint(cfg))
+    core = (SingleFrameCore if cfg.single_frame else FuturePredCore)(
+        **core_kw,
         detector=CDetrDetectorSpatioTemporal(
             decoder=T.TransformerDecoder(nn.ModuleList(
                 [T.TransformerDecoderLayer(cfg.hidden_dim, cfg.nheads, cfg.dim_feedforward, 0.1, cfg.num_images,
@@ -65,7 +66,7 @@ def build_product(cfg: Config, dtype, seed):
         pos_encoder=PositionalEncoder(no_temporal=cfg.no_temporal))
     core.compute_dtype = dtype
     model = SpatioTemporalDETR(args, core)
-    sd = O.make_state_dict(cfg, seed)
+    sd = O.rename_for_core(O.make_state_dict(cfg, seed), cfg)
     missing = set(model.state_dict().keys()) ^ set(sd.keys())
     assert not missing, sorted(missing)[:10]                      # same key schema as the reference
     model.load_state_dict(sd)
@@ -91,6 +92,7 @@ CASES = {
     "g16_multikey_egodeep": Config(backbone="resnet18", enc_layers=1, joint_layers=1, joint_egodeep=True, dec_layers=2,
                                    num_images=1, image_memory_mode="attend all at once", dec_egodeep=True,
                                    no_temporal=False),
+    "g17_single_frame_core": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2, single_frame=True),
 }
 
 

@@ -82,6 +82,7 @@ CASES = {
     "g16_multikey_egodeep": Config(backbone="resnet18", enc_layers=1, joint_layers=1, joint_egodeep=True, dec_layers=2,
                                    num_images=1, image_memory_mode="attend all at once", dec_egodeep=True,
                                    no_temporal=False),
+    "g17_single_frame_core": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2, single_frame=True),
 }
 
 
@@ -95,6 +96,7 @@ def test_g5_full_model_loss_and_grads(golden, name):
     for k, (_, kind) in spec.items():
         if kind == "param":
             sd[k].requires_grad_(True)
+    by_ref_name = O.rename_for_core(sd, cfg)           # the fixture names parameters as the reference's core does
     data = make_batch(B, L, H, W, seed=seed, max_boxes=12)
     imu = O.imu_from_data(data) if cfg.use_imu else None
     offs = None if cfg.no_temporal else data["temporal_offsets"]          # st_detr.py passes them with encode_offset
@@ -111,7 +113,7 @@ def test_g5_full_model_loss_and_grads(golden, name):
     loss.backward()
     names, norms = list(g["grad_names"]), g["grad_norms"]
     for n, ref_norm in zip(names, norms):
-        got = sd[n].grad
+        got = by_ref_name[n].grad
         if ref_norm < 0:                       # reference left .grad = None
             assert got is None or float(got.abs().max()) == 0.0, n
             continue
@@ -120,7 +122,7 @@ def test_g5_full_model_loss_and_grads(golden, name):
     for k in g.files:
         if k.startswith("gidx:"):
             n = k[5:]
-            close(sd[n].grad.reshape(-1)[g[k]], g["gval:" + n], atol=1e-5, rtol=2e-4)
+            close(by_ref_name[n].grad.reshape(-1)[g[k]], g["gval:" + n], atol=1e-5, rtol=2e-4)
     # G10: dead-work equivalence -- both in the reference (fixture) and in the oracle.  With one memory of all past
     # frames, a joint encoder or slot states nothing is dead (the fixture's truncated run then differs, as it must).
     if cfg.image_memory_mode == "attend all at once" or cfg.joint_layers or cfg.dec_slotstates:
