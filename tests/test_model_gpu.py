@@ -264,3 +264,19 @@ def test_bf16_mode_tracks_fp32():
     assert min(r[0] for r in big) > 0.95, rows[:5]            # gradients that carry the update
     assert np.mean([r[0] for r in rows]) > 0.98, rows[:5]
     assert rows[0][0] > 0.3, rows[:5]                         # small gradients are noisier in bf16, never garbage
+
+
+def test_build_model_single_frame_core_trains_on_one_frame_clips():
+    """runs/_model.py knob `core="single_frame"`: plain single-image detection (reference SingleFrameCore), one step."""
+    from types import SimpleNamespace
+    from runs._model import build_model
+    args = SimpleNamespace(device=DEV, distributed=False, compute_dtype="bf16", backbone="resnet18", core="single_frame")
+    detr = SpatioTemporalDETRArgs(num_classes=8, num_queries=32, lr_backbone=1e-4, enc_layers=1, dec_layers=1,
+                                  pretrained_backbone=False)
+    model = build_model(args, detr).eval()
+    assert any(k.startswith("_model.encoder.backbone.") for k in model.state_dict())      # the reference's key names
+    data = make_batch(2, 1, 64, 96, seed=3, device=DEV, max_boxes=5)
+    out, _, loss, stats, od = model(data=data, distributed=False)
+    loss.backward()
+    assert torch.isfinite(loss) and out["class_scores"].shape[:2] == (2, 1)
+    assert model._model.detector.class_embed.weight.grad.abs().sum() > 0
