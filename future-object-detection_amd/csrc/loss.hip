@@ -372,6 +372,83 @@ extern "C" int fod_set_loss_bwd(const float* logits, const float* boxes, const i
   return FOD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Tracker baseline (reference future_od/models/paper.py:531-646, TrackerFuturePredictor; evaluation only, no gradients)
+namespace {
+// cost[b, m, n] = 0.5 * |centre2[b,m] - centre1[b,n]|_2 + 0.5 * max_c |sigmoid(l2[b,m,c]) - sigmoid(l1[b,n,c])|
+__global__ void tracker_cost_kernel(const float* __restrict__ boxes2, const float* __restrict__ logits2,
+                                    const float* __restrict__ boxes1, const float* __restrict__ logits1,
+                                    float* __restrict__ cost, int B, int M, int N, int C) {
+  const long total = (long)B * M * N;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % N);
+    const long bm = i / N;
+    const int b = (int)(bm / M);
+    const float* p2 = boxes2 + bm * 4;
+    const float* p1 = boxes1 + ((long)b * N + n) * 4;
+    const float dx = p2[0] - p1[0], dy = p2[1] - p1[1];
+    const float* l2 = logits2 + bm * C;
+    const float* l1 = logits1 + ((long)b * N + n) * C;
+    float dmax = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float s2 = 1.f / (1.f + expf(-l2[c])), s1 = 1.f / (1.f + expf(-l1[c]));
+      dmax = fmaxf(dmax, fabsf(s2 - s1));
+    }
+    cost[i] = 0.5f * sqrtf(dx * dx + dy * dy) + 0.5f * dmax;
+  }
+}
+
+// mode: 0 = keep the current size, 1 = linear (clamped at 0), 2 = percentual, 3 = average (paper.py:590-603)
+__global__ void tracker_extrapolate_kernel(const float* __restrict__ boxes2, const float* __restrict__ logits2,
+                                           const float* __restrict__ boxes1, const float* __restrict__ logits1,
+                                           const int* __restrict__ map, const float* __restrict__ factor,
+                                           float* __restrict__ out_boxes, float* __restrict__ out_logits, int B, int M,
+                                           int N, int C, int mode) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * M) return;
+  const int b = i / M;
+  const int j = map[i];
+  const bool has = j >= 0;
+  const float f = factor ? factor[b] : 1.f;
+  const float* p2 = boxes2 + (long)i * 4;
+  const float* p1 = has ? boxes1 + ((long)b * N + j) * 4 : p2;          // unmatched boxes are kept as they are
+  float* o = out_boxes + (long)i * 4;
+  o[0] = p2[0] + (p2[0] - p1[0]) * f;
+  o[1] = p2[1] + (p2[1] - p1[1]) * f;
+  for (int d = 2; d < 4; ++d) {
+    float v = p2[d];
+    if (mode == 1) v = fmaxf(p2[d] + (p2[d] - p1[d]) * f, 0.f);
+    else if (mode == 2) v = p2[d] * powf(p2[d] / p1[d], f);
+    else if (mode == 3) v = 0.5f * (p2[d] + p1[d]);
+    o[d] = v;
+  }
+  const float* l2 = logits2 + (long)i * C;
+  const float* l1 = logits1 + ((long)b * N + (has ? j : 0)) * C;
+  for (int c = 0; c < C; ++c) out_logits[(long)i * C + c] = 0.5f * (l2[c] + (has ? l1[c] : 0.f));   // unmatched add no info
+}
+}  // namespace
+
+extern "C" int fod_tracker_cost(const float* boxes2, const float* logits2, const float* boxes1, const float* logits1,
+                                float* cost, int B, int M, int N, int C, hipStream_t stream) {
+  FOD_REQUIRE(boxes2 && logits2 && boxes1 && logits1 && cost && B > 0 && M > 0 && N > 0 && C > 0, "tracker_cost: bad args");
+  const long total = (long)B * M * N;
+  hipLaunchKernelGGL(tracker_cost_kernel, dim3((unsigned)std::min<long>(ceil_div(total, 256L), 2048L)), dim3(256), 0, stream,
+                     boxes2, logits2, boxes1, logits1, cost, B, M, N, C);
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
+}
+
+extern "C" int fod_tracker_extrapolate(const float* boxes2, const float* logits2, const float* boxes1,
+                                       const float* logits1, const int32_t* map, const float* factor, float* out_boxes,
+                                       float* out_logits, int B, int M, int N, int C, int mode, hipStream_t stream) {
+  FOD_REQUIRE(boxes2 && logits2 && boxes1 && logits1 && map && out_boxes && out_logits, "tracker_extrapolate: null operand");
+  FOD_REQUIRE(B > 0 && M > 0 && N > 0 && C > 0 && mode >= 0 && mode <= 3, "tracker_extrapolate: bad extents / mode %d", mode);
+  hipLaunchKernelGGL(tracker_extrapolate_kernel, dim3(ceil_div(B * M, 256)), dim3(256), 0, stream, boxes2, logits2, boxes1,
+                     logits1, map, factor, out_boxes, out_logits, B, M, N, C, mode);
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
+}
+
 extern "C" int fod_post_proc(const float* logits, const float* boxes, float* class_scores, float* boxes_px, int R,
                              int C, float img_h, float img_w, hipStream_t stream) {
   FOD_REQUIRE(logits && boxes && class_scores && boxes_px && R > 0 && C > 0, "post_proc: bad args");

@@ -360,3 +360,56 @@ class SingleFrameCore(FuturePredCore):
     @property
     def separate_encoder(self):
         return self.encoder
+
+
+class TrackerFuturePredictor(nn.Module):
+    """Future detections by assignment between two frames' detections and extrapolation (reference paper.py:531-646):
+    cost = 0.5 * centre distance + 0.5 * L-inf distance of class probabilities, one assignment problem per sample
+    (host, the same solver as the matcher), then `fod_tracker_extrapolate`.  Evaluation only: no gradients."""
+
+    def __init__(self, dim_extrapolation: str = None):
+        super().__init__()
+        if dim_extrapolation not in ops.TRACKER_MODES:
+            raise ValueError(f"Unknown dim extrapolation: {dim_extrapolation}")
+        self._dim_extrapolation = dim_extrapolation
+
+    @torch.no_grad()
+    def forward(self, pred1, pred2, temporal_offsets=None):
+        b1, l1 = pred1["pred_boxes"].float().contiguous(), pred1["pred_logits"].float().contiguous()
+        b2, l2 = pred2["pred_boxes"].float().contiguous(), pred2["pred_logits"].float().contiguous()
+        B, M, _ = b2.shape
+        N = b1.shape[1]
+        cost = ops.tracker_cost(b2, l2, b1, l1)
+        mapping = ops.lap_solve_batch_host(cost.cpu(), [N] * B).to(b2.device)             # [B, M]: column or -1
+        factor = None
+        if temporal_offsets is not None:                       # (t2 - t1) / (t1 - t0), reference :635-637
+            t = temporal_offsets.to(device=b2.device, dtype=torch.float32)
+            factor = ((t[:, 2] - t[:, 1]) / (t[:, 1] - t[:, 0])).contiguous()
+        boxes, logits = ops.tracker_extrapolate(b2, l2, b1, l1, mapping, factor, self._dim_extrapolation)
+        return {"pred_boxes": boxes, "pred_logits": logits}
+
+
+class TrackerBaselineCore(SingleFrameCore):
+    """Single-frame detector + tracker extrapolation (reference paper.py:649-706): clips of ONE frame are detected as
+    by SingleFrameCore (training); clips of THREE frames yield detections for the first two frames, each on its own,
+    and the third frame's detections come from the tracker (evaluation)."""
+
+    def __init__(self, encoder: SeparateEncoder, detector: CDetrDetectorSpatioTemporal, pos_encoder: PositionalEncoder,
+                 tracker_future_predictor: TrackerFuturePredictor):
+        super().__init__(encoder, detector, pos_encoder)
+        self.tracker_future_predictor = tracker_future_predictor
+
+    def forward(self, images: Tensor, imu: Tensor = None, temporal_offsets: Tensor = None):
+        B, L = images.shape[:2]
+        if L == 1:
+            return super().forward(images, imu, temporal_offsets)
+        if L != 3:
+            raise ValueError("TrackerBaselineCore takes clips of 1 frame (detect) or 3 frames (detect, detect, extrapolate)")
+        if not self.pos_encoder._no_temporal:
+            raise NotImplementedError("TrackerBaselineCore with the temporal positional term")
+        preds = []
+        for l in range(2):                                     # each frame on its own, as a first frame (reference :693-700)
+            out, _ = super().forward(images[:, l:l + 1], imu[:, l:l + 1] if imu is not None else None, None)
+            preds.append(out)
+        pred = self.tracker_future_predictor(preds[0], preds[1], temporal_offsets)
+        return pred, [["model happy" for _ in range(L)] for _ in range(B)]

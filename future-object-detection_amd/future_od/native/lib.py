@@ -97,6 +97,8 @@ SIGNATURES = {
     "fod_set_loss_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "fod_od_map": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p],
     "fod_post_proc": [_p, _p, _p, _p, _i, _i, _f, _f, _p],
+    "fod_tracker_cost": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "fod_tracker_extrapolate": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "fod_multi_sqnorm_acc": [_p, _p, _p, _p, _i, _p, _p],
     "fod_multi_adamw": [_p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p, _f, _p],
 }

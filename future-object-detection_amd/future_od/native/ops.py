@@ -568,3 +568,35 @@ def od_map(scores, boxes_px, anno_boxes, anno_classes, anno_active, imsize, T=10
          ptr(confs), ptr(is_pos), ptr(sizes), ptr(num_annos), B, M, C1, N, T, float(imsize[0]),
          float(imsize[1]), stream())
     return confs, is_pos, sizes, num_annos
+
+
+# ------------------------------------------------------------------------------------------------ tracker baseline
+TRACKER_MODES = {None: 0, "linear": 1, "percentual": 2, "average": 3}
+
+
+def tracker_cost(boxes2, logits2, boxes1, logits1):
+    """-> cost f32 [B,M,N] between current (2) and previous (1) detections (reference paper.py:538-544,641)."""
+    for t, n in ((boxes2, "boxes2"), (logits2, "logits2"), (boxes1, "boxes1"), (logits1, "logits1")):
+        _chk(t, n, torch.float32)
+    B, M, _ = boxes2.shape
+    N, Cc = boxes1.shape[1], logits2.shape[-1]
+    assert boxes2.shape == (B, M, 4) and boxes1.shape == (B, N, 4) and logits2.shape == (B, M, Cc) \
+        and logits1.shape == (B, N, Cc), (boxes2.shape, logits2.shape, boxes1.shape, logits1.shape)
+    cost = torch.empty((B, M, N), dtype=torch.float32, device=boxes2.device)
+    call("fod_tracker_cost", ptr(boxes2), ptr(logits2), ptr(boxes1), ptr(logits1), ptr(cost), B, M, N, Cc, stream())
+    return cost
+
+
+def tracker_extrapolate(boxes2, logits2, boxes1, logits1, mapping, factor, mode):
+    """mapping i32 [B,M] (previous detection or -1), factor f32 [B] or None -> (boxes [B,M,4], logits [B,M,C])."""
+    B, M, _ = boxes2.shape
+    N, Cc = boxes1.shape[1], logits2.shape[-1]
+    _chk(mapping, "mapping", torch.int32); assert mapping.shape == (B, M)
+    if factor is not None:
+        _chk(factor, "factor", torch.float32); assert factor.numel() == B
+    if mode not in TRACKER_MODES:
+        raise ValueError(f"Unknown dim extrapolation: {mode}")
+    ob, ol = torch.empty_like(boxes2), torch.empty_like(logits2)
+    call("fod_tracker_extrapolate", ptr(boxes2), ptr(logits2), ptr(boxes1), ptr(logits1), ptr(mapping), ptr(factor),
+         ptr(ob), ptr(ol), B, M, N, Cc, TRACKER_MODES[mode], stream())
+    return ob, ol

@@ -296,6 +296,18 @@ int fod_od_map(const float* scores, const float* boxes, const float* anno_boxes,
                const int64_t* anno_active, float* confs, uint8_t* is_positive, uint8_t* size_categories,
                int64_t* num_annos, int B, int M, int C1, int N, int T, float img_h, float img_w,
                fod_stream_t stream);
+/* Tracker baseline, evaluation only (future_od/models/paper.py:531-646 TrackerFuturePredictor).
+ * cost f32 [B,M,N] = 0.5 * L2 distance of the box centres + 0.5 * L-inf distance of the class probabilities between
+ * the current detections (boxes2 [B,M,4] cxcywh, logits2 [B,M,C]) and the previous ones (boxes1 [B,N,4], logits1
+ * [B,N,C]) (:538-544,641); the assignment is fod_lap_solve_batch_host on its host copy.  fod_tracker_extrapolate:
+ * map i32 [B,M] = matched previous detection or -1; factor f32 [B] or NULL (= 1); centres move on by factor times the
+ * last displacement, sizes per `mode` (0 keep, 1 linear clamped at 0, 2 percentual, 3 average; :590-603), logits
+ * are averaged with the matched ones (unmatched: with 0) (:560-588). */
+int fod_tracker_cost(const float* boxes2, const float* logits2, const float* boxes1, const float* logits1, float* cost,
+                     int B, int M, int N, int C, fod_stream_t stream);
+int fod_tracker_extrapolate(const float* boxes2, const float* logits2, const float* boxes1, const float* logits1,
+                            const int32_t* map, const float* factor, float* out_boxes, float* out_logits, int B, int M,
+                            int N, int C, int mode, fod_stream_t stream);
 /* class_scores = sigmoid(logits) with appended max; boxes cxcywh(0..1) -> xyxy pixels (st_detr.py:198-210) */
 int fod_post_proc(const float* logits, const float* boxes, float* class_scores, float* boxes_px, int R,
                   int C, float img_h, float img_w, fod_stream_t stream);

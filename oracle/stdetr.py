@@ -617,3 +617,53 @@ def imu_from_data(data, with_speed=True):
     """st_detr.py:88-90,115-116."""
     keys = ["translation", "acceleration", "rotation", "rotation_rate"] + (["speed"] if with_speed else [])
     return torch.cat([data[k] for k in keys], dim=2)
+
+
+# ======================================================================================
+# tracker baseline (paper.py:531-706)
+def tracker_future_predictor(pred1, pred2, temporal_offsets=None, dim_extrapolation=None):
+    """TrackerFuturePredictor.forward, paper.py:605-646 (with :538-603)."""
+    from scipy.optimize import linear_sum_assignment
+    b1, l1, b2, l2 = pred1["pred_boxes"], pred1["pred_logits"], pred2["pred_boxes"], pred2["pred_logits"]
+    with torch.no_grad():
+        cost = 0.5 * torch.cdist(b2[:, :, 0:2], b1[:, :, 0:2], p=2) \
+            + 0.5 * torch.cdist(l2.sigmoid(), l1.sigmoid(), p=float("inf"))            # (B, M, N)   :538-544,641
+        B, M, N = cost.shape
+        mapping = torch.full((B, M), -1, dtype=torch.int64)                               # :546-558
+        for b in range(B):
+            r, c = linear_sum_assignment(cost[b].numpy())
+            mapping[b, torch.as_tensor(r)] = torch.as_tensor(c)
+        if temporal_offsets is None:                                                      # :631-637
+            f = 1.0
+        else:
+            f = ((temporal_offsets[:, 2] - temporal_offsets[:, 1])
+                 / (temporal_offsets[:, 1] - temporal_offsets[:, 0]))[:, None, None]
+        has = mapping != -1                                                               # :560-588
+        idx = mapping.clamp(min=0)
+        c1 = b1.gather(1, idx[:, :, None].expand(-1, -1, 4)).clone()
+        c1[~has] = b2[~has]
+        if dim_extrapolation is None:                                                     # :590-603
+            dims = b2[..., 2:4]
+        elif dim_extrapolation == "linear":
+            dims = torch.clamp(b2[..., 2:4] + (b2[..., 2:4] - c1[..., 2:4]) * f, min=0)
+        elif dim_extrapolation == "percentual":
+            dims = b2[..., 2:4] * (b2[..., 2:4] / c1[..., 2:4]) ** f
+        elif dim_extrapolation == "average":
+            dims = (b2[..., 2:4] + c1[..., 2:4]) / 2
+        else:
+            raise ValueError(dim_extrapolation)
+        pos = b2[..., 0:2] + (b2[..., 0:2] - c1[..., 0:2]) * f
+        cl = l1.gather(1, idx[..., None].expand(-1, -1, l1.shape[-1])).clone()
+        cl[~has] = 0.0
+        return {"pred_boxes": torch.cat([pos, dims], dim=2), "pred_logits": 0.5 * (l2 + cl)}
+
+
+def tracker_core_forward(sd, cfg, images, imu=None, temporal_offsets=None, dim_extrapolation=None):
+    """TrackerBaselineCore.forward, paper.py:665-706 (cfg.single_frame key names; no temporal term)."""
+    assert cfg.single_frame and cfg.no_temporal
+    L = images.shape[1]
+    if L == 1:
+        return core_forward(sd, cfg, images, imu)
+    assert L == 3
+    preds = [core_forward(sd, cfg, images[:, l:l + 1], imu[:, l:l + 1] if imu is not None else None) for l in range(2)]
+    return tracker_future_predictor(preds[0], preds[1], temporal_offsets, dim_extrapolation)

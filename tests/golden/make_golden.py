@@ -261,6 +261,37 @@ def main():
             arrays["gidx:" + n], arrays["gval:" + n] = idx, val
         save(name, **arrays)
 
+    # ---------------------------------------------------------------- G18 tracker baseline (paper.py:531-706)
+    if not ONLY or "g18_tracker_baseline" in ONLY:
+        arrays = {}
+        g = torch.Generator().manual_seed(31)
+        B, M, N, C = 3, 24, 20, 8                                           # rectangular: 4 current detections unmatched
+        p1 = {"pred_boxes": torch.rand(B, N, 4, generator=g) * 0.6 + 0.2, "pred_logits": torch.randn(B, N, C, generator=g) * 2}
+        p2 = {"pred_boxes": torch.rand(B, M, 4, generator=g) * 0.6 + 0.2, "pred_logits": torch.randn(B, M, C, generator=g) * 2}
+        offs = torch.tensor([[-1.0, -0.5, 0.0], [-0.9, -0.5, 0.0], [-1.0, -0.2, 0.0]])
+        arrays.update(u_b1=p1["pred_boxes"], u_l1=p1["pred_logits"], u_b2=p2["pred_boxes"], u_l2=p2["pred_logits"], u_offs=offs)
+        for mode in (None, "linear", "percentual", "average"):
+            for tag, o in (("none", None), ("offs", offs)):
+                out = paper.TrackerFuturePredictor(mode)({k: v.clone() for k, v in p1.items()},
+                                                         {k: v.clone() for k, v in p2.items()}, o)
+                arrays[f"u_{mode}_{tag}_boxes"], arrays[f"u_{mode}_{tag}_logits"] = out["pred_boxes"], out["pred_logits"]
+        # the whole core on three-frame clips (evaluation) and on one-frame clips (training path = single-frame core)
+        cfg = Config(backbone="resnet18", enc_layers=1, dec_layers=1, num_images=1, single_frame=True, num_queries=32)
+        model = build_reference(cfg, paper, transformer, st_detr)
+        load_weights(model, cfg, 32)
+        single = model._model
+        core = paper.TrackerBaselineCore(encoder=single.encoder, detector=single.detector, pos_encoder=single.pos_encoder,
+                                         tracker_future_predictor=paper.TrackerFuturePredictor("linear")).eval()
+        data = make_batch(2, 3, 64, 96, seed=32, device="cpu", max_boxes=6)
+        imu = torch.cat([data[k] for k in model._imu_keys], dim=2)
+        offs3 = torch.tensor([[-1.0, -0.5, 0.0], [-0.8, -0.5, 0.0]])
+        with torch.no_grad():
+            out3, _ = core(data["video"], imu=imu, temporal_offsets=offs3)
+            out1, _ = core(data["video"][:, :1], imu=imu[:, :1])
+        arrays.update(meta=np.array([2, 3, 64, 96, 32]), offs3=offs3, core3_boxes=out3["pred_boxes"],
+                      core3_logits=out3["pred_logits"], core1_boxes=out1["pred_boxes"], core1_logits=out1["pred_logits"])
+        save("g18_tracker_baseline", **arrays)
+
     # ---------------------------------------------------------------- G3/G4 encoder & decoder stacks alone
     cfg = Config(backbone="resnet18", hidden_dim=64, nheads=4, dim_feedforward=96, enc_layers=2,
                  dec_layers=3, num_queries=20, num_images=2)

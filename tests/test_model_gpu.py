@@ -280,3 +280,36 @@ def test_build_model_single_frame_core_trains_on_one_frame_clips():
     loss.backward()
     assert torch.isfinite(loss) and out["class_scores"].shape[:2] == (2, 1)
     assert model._model.detector.class_embed.weight.grad.abs().sum() > 0
+
+
+def test_tracker_baseline_matches_reference_fixture(golden):
+    """fod_tracker_cost + host assignment + fod_tracker_extrapolate against the reference's TrackerFuturePredictor
+    (four size modes, with / without temporal offsets, 24 current vs 20 previous detections), and TrackerBaselineCore on
+    three-frame (evaluation) and one-frame (training) clips, fp32 mode; fixture g18."""
+    from future_od.models.paper import TrackerBaselineCore, TrackerFuturePredictor
+    g = golden("g18_tracker_baseline")
+    t = lambda k: torch.from_numpy(g[k]).to(DEV)
+    p1 = {"pred_boxes": t("u_b1"), "pred_logits": t("u_l1")}
+    p2 = {"pred_boxes": t("u_b2"), "pred_logits": t("u_l2")}
+    for mode in (None, "linear", "percentual", "average"):
+        for tag, offs in (("none", None), ("offs", t("u_offs"))):
+            out = TrackerFuturePredictor(mode)(p1, p2, offs)
+            rel_close(out["pred_boxes"], g[f"u_{mode}_{tag}_boxes"], 1e-4, f"tracker boxes {mode} {tag}")
+            rel_close(out["pred_logits"], g[f"u_{mode}_{tag}_logits"], 1e-4, f"tracker logits {mode} {tag}")
+    with pytest.raises(ValueError):
+        TrackerFuturePredictor("cubic")
+    cfg = Config(backbone="resnet18", enc_layers=1, dec_layers=1, num_images=1, single_frame=True, num_queries=32)
+    B, L, H, W, seed = (int(v) for v in g["meta"])
+    model, _ = build_product(cfg, torch.float32, seed)
+    single = model._model
+    core = TrackerBaselineCore(single.encoder, single.detector, single.pos_encoder, TrackerFuturePredictor("linear")).eval()
+    core.compute_dtype = torch.float32
+    data = make_batch(B, L, H, W, seed=seed, device=DEV, max_boxes=6)
+    imu = torch.cat([data[k] for k in model._imu_keys], dim=2)
+    with torch.no_grad():
+        out3, _ = core(data["video"], imu=imu, temporal_offsets=t("offs3"))
+        out1, _ = core(data["video"][:, :1], imu=imu[:, :1])
+    rel_close(out3["pred_boxes"], g["core3_boxes"], 1e-3, "tracker core boxes")
+    rel_close(out3["pred_logits"], g["core3_logits"], 1e-3, "tracker core logits")
+    rel_close(out1["pred_boxes"], g["core1_boxes"], 1e-3, "tracker core, one frame: boxes")
+    rel_close(out1["pred_logits"], g["core1_logits"], 1e-3, "tracker core, one frame: logits")

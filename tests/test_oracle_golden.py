@@ -170,3 +170,27 @@ def test_g9_od_map(golden):
         for t in range(out[0].shape[0]):
             ap = ood.average_precision(out[0][t], out[1][t], out[2], out[3][:, :, None])
             np.testing.assert_allclose(ap, g[f"c{ci}_ap"][t], atol=1e-6, rtol=1e-5, equal_nan=True)
+
+
+def test_g18_tracker_baseline(golden):
+    """TrackerFuturePredictor (all four size-extrapolation modes, with and without temporal offsets, rectangular
+    assignment) and TrackerBaselineCore on three-frame and one-frame clips, reference paper.py:531-706."""
+    g = golden("g18_tracker_baseline")
+    t = lambda k: torch.from_numpy(g[k])
+    p1 = {"pred_boxes": t("u_b1"), "pred_logits": t("u_l1")}
+    p2 = {"pred_boxes": t("u_b2"), "pred_logits": t("u_l2")}
+    for mode in (None, "linear", "percentual", "average"):
+        for tag, offs in (("none", None), ("offs", t("u_offs"))):
+            out = O.tracker_future_predictor(p1, p2, offs, mode)
+            close(out["pred_boxes"], g[f"u_{mode}_{tag}_boxes"])
+            close(out["pred_logits"], g[f"u_{mode}_{tag}_logits"])
+    cfg = Config(backbone="resnet18", enc_layers=1, dec_layers=1, num_images=1, single_frame=True, num_queries=32)
+    B, L, H, W, seed = (int(v) for v in g["meta"])
+    sd = O.make_state_dict(cfg, seed)
+    data = make_batch(B, L, H, W, seed=seed, max_boxes=6)
+    imu = O.imu_from_data(data)
+    with torch.no_grad():
+        out3 = O.tracker_core_forward(sd, cfg, data["video"], imu, t("offs3"), "linear")
+        out1 = O.tracker_core_forward(sd, cfg, data["video"][:, :1], imu[:, :1])
+    close(out3["pred_boxes"], g["core3_boxes"]); close(out3["pred_logits"], g["core3_logits"])
+    close(out1["pred_boxes"], g["core1_boxes"]); close(out1["pred_logits"], g["core1_logits"])
