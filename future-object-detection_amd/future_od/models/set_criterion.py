@@ -231,7 +231,14 @@ def _host_group():
     """Process group for host-side scalar collectives: the default group when it is gloo (CPU tests, rehearsal),
     else a gloo group created once next to the RCCL one (every rank reaches this at its first forward)."""
     if not _HOST_GROUP:
-        _HOST_GROUP.append(None if dist.get_backend() == "gloo" else dist.new_group(backend="gloo"))
+        if dist.get_backend() == "gloo":
+            _HOST_GROUP.append(None)
+        else:
+            try:
+                _HOST_GROUP.append(dist.new_group(backend="gloo"))
+            except Exception as e:                       # no usable host transport: fall back to the device group
+                print(f"[fod] no gloo group for host-side scalars ({e}); using a device all-reduce (one host stall per step)")
+                _HOST_GROUP.append("device")
     return _HOST_GROUP[0]
 
 
@@ -265,8 +272,13 @@ class SetCriterion(nn.Module):
         n = float(sum(int(t["labels"].shape[0]) for t in targets))
         if not distributed:
             return max(n, 1.0)
-        t = torch.tensor([n], dtype=torch.float64)
-        dist.all_reduce(t, group=_host_group())
+        group = _host_group()
+        if group == "device":
+            t = _to_device_async(torch.tensor([n], dtype=torch.float32), torch.device(device))
+            dist.all_reduce(t)
+        else:
+            t = torch.tensor([n], dtype=torch.float64)
+            dist.all_reduce(t, group=group)
         return max(float(t.item()) / dist.get_world_size(), 1.0)
 
     def forward(self, outputs, targets, distributed, packed=None, num_boxes=None):
