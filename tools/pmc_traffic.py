@@ -38,16 +38,21 @@ def load(d, counter):
     return tot, n
 
 
-fetch, nf = load(sys.argv[1], "FETCH_SIZE")
-write, nw = load(sys.argv[2], "WRITE_SIZE")
-steps = int(sys.argv[3])
-out = {"_note": "bytes per training step and per launch; FETCH_SIZE doubled (gfx950), WRITE_SIZE as read; "
-                "Infinity-Cache hits included; rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes",
-       "_steps_in_run": steps}
-for e in sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch[k] + write[k])):
-    launches = max(nf[e], nw[e])
-    tb = 2.0 * fetch[e] + write[e]
-    out[e] = {"launches_per_step": launches / steps, "read_bytes_per_step": 2.0 * fetch[e] / steps,
-              "write_bytes_per_step": write[e] / steps, "bytes_per_launch": tb / max(launches, 1)}
-    print(f"{e:24s} launches/step {launches/steps:7.1f}  read {2*fetch[e]/steps/1e6:9.1f} MB  write {write[e]/steps/1e6:9.1f} MB  per launch {tb/max(launches,1)/1e6:8.2f} MB")
-json.dump(out, open(sys.argv[4], "w"), indent=1)
+def main():
+    fetch, nf = load(sys.argv[1], "FETCH_SIZE")
+    write, nw = load(sys.argv[2], "WRITE_SIZE")
+    steps = int(sys.argv[3])
+    out = {"_note": "bytes per training step and per launch; FETCH_SIZE doubled (gfx950), WRITE_SIZE as read; "
+                    "Infinity-Cache hits included; rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes",
+           "_steps_in_run": steps}
+    for e in sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch[k] + write[k])):
+        launches = max(nf[e], nw[e])
+        tb = 2.0 * fetch[e] + write[e]
+        out[e] = {"launches_per_step": launches / steps, "read_bytes_per_step": 2.0 * fetch[e] / steps,
+                  "write_bytes_per_step": write[e] / steps, "bytes_per_launch": tb / max(launches, 1)}
+        print(f"{e:24s} launches/step {launches/steps:7.1f}  read {2*fetch[e]/steps/1e6:9.1f} MB  write {write[e]/steps/1e6:9.1f} MB  per launch {tb/max(launches,1)/1e6:8.2f} MB")
+    json.dump(out, open(sys.argv[4], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
