@@ -151,10 +151,30 @@ class _AsyncLap:
             except BaseException:
                 L._plain_call("fod_host_flag_set", self.flag, self.ticket)         # nothing may stay parked
                 raise
+            for fn in take_unrun_while_matching():       # independent GPU work, queued ahead of the parked wait
+                fn()
             L._plain_call("fod_stream_wait_flag", self.flag, self.ticket, stream)
         # the host block is read when this kernel RUNS, i.e. after the worker has released the stream
         L._plain_call("fod_copy_from_host_i32", match_host, match.data_ptr(), Lv * B * M, stream)
         return match
+
+
+# Work that does not depend on the matches (post-processing, AP bookkeeping) can be queued between the cost matrices'
+# host copy and the parked wait: the GPU then runs it while the worker solves the assignments instead of idling.
+_WHILE_MATCHING = []
+
+
+def run_while_matching(fn):
+    """Register `fn` (no arguments) to be called by the next asynchronous submission right before the stream parks.
+    If that submission does not park (host-sync path, inline solve, CPU), the caller runs it itself: see
+    `take_unrun_while_matching`."""
+    _WHILE_MATCHING.append(fn)
+
+
+def take_unrun_while_matching():
+    fns = list(_WHILE_MATCHING)
+    _WHILE_MATCHING.clear()
+    return fns
 
 
 _ASYNC_LAP = {}

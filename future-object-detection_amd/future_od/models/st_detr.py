@@ -11,7 +11,8 @@ from dataclasses import dataclass
 import torch
 import torch.nn as nn
 
-from future_od.models.set_criterion import SetCriterion, build_matcher, pack_targets
+from future_od.models.set_criterion import (SetCriterion, build_matcher, pack_targets, run_while_matching,
+                                            take_unrun_while_matching)
 from future_od.native import ops
 from future_od.utils.od_map import prepare_od_map_stuffs
 
@@ -101,9 +102,19 @@ class SpatioTemporalDETR(nn.Module):
         outputs, model_moods = self._model(images, **kwargs)
         if not (isinstance(outputs, dict) and outputs["pred_logits"].dim() == 3):
             raise ValueError("cannot interpret output on the format: %s" % type(outputs))
-        loss, stats = self.loss(data, outputs, distributed, targets=targets, packed=packed, num_boxes=num_boxes)
-        od_map_stuffs, post = self.post_proc(outputs["pred_logits"][:, None], outputs["pred_boxes"][:, None],
-                                             data, images)
+        # post-processing / AP bookkeeping do not depend on the matching: when the matcher parks the stream they are
+        # queued ahead of the parked wait and run while the worker thread solves the assignments
+        done = []
+        post_proc = lambda: done.append(self.post_proc(outputs["pred_logits"][:, None], outputs["pred_boxes"][:, None],
+                                                       data, images))
+        run_while_matching(post_proc)
+        try:
+            loss, stats = self.loss(data, outputs, distributed, targets=targets, packed=packed, num_boxes=num_boxes)
+        finally:
+            unrun = take_unrun_while_matching()
+        for fn in unrun:
+            fn()
+        od_map_stuffs, post = done[0]
         post["moods"] = model_moods
         return post, None, loss, stats, od_map_stuffs
 
