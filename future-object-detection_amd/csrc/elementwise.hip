@@ -297,6 +297,28 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict
   }
 }
 
+// bf16, 8 output channels (one 16-byte chunk per pixel), pixel count a multiple of 4: four pixels per thread, one
+// 16-byte load per plane and four 16-byte stores; the frame index comes from blockIdx.y (no 64-bit division).
+__global__ __launch_bounds__(256) void nchw_to_nhwc8_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, int C,
+                                                            long hw, int inner, long stride_outer, long stride_inner) {
+  const int f = blockIdx.y;
+  const float* s = src + (long)(f / inner) * stride_outer + (long)(f % inner) * stride_inner;
+  __bf16* o = dst + (long)f * hw * 8;
+  for (long px = 4 * ((long)blockIdx.x * blockDim.x + threadIdx.x); px < hw; px += 4L * gridDim.x * blockDim.x) {
+    float4 pl[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      pl[c] = c < C ? *reinterpret_cast<const float4*>(s + c * hw + px) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x8_t v;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) v[c] = (__bf16)(j == 0 ? pl[c].x : j == 1 ? pl[c].y : j == 2 ? pl[c].z : pl[c].w);
+      *reinterpret_cast<bf16x8_t*>(o + (px + j) * 8) = v;
+    }
+  }
+}
+
 // Same fold for raw uint8 frames, with the dataset's pixel pipeline (reference future_od/datasets/transforms.py:12-15
 // and nu_scenes.py:97-101: x.float() / 255, then (x - mean[c]) / std[c]) applied on the fly in fp32, in that order,
 // so the fp32-mode result is bit-identical to normalising on the host.  A quarter of the bytes cross PCIe and HBM.
@@ -685,6 +707,15 @@ extern "C" int fod_nchw_to_nhwc(int dtype, const float* src, void* dst, int F, i
                                 int inner, long stride_outer, long stride_inner, hipStream_t stream) {
   FOD_REQUIRE(src && dst && F > 0 && C > 0 && Cp >= C && inner > 0 && F % inner == 0, "nchw_to_nhwc: bad args");
   const long n = (long)F * H * W;
+  const long hw = (long)H * W;
+  if (dtype == FOD_BF16 && Cp == 8 && hw % 4 == 0 && stride_outer % 4 == 0 && stride_inner % 4 == 0 &&
+      (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && F <= 65535) {
+    const int bx = (int)std::min<long>((hw / 4 + 255) / 256, 512);
+    hipLaunchKernelGGL(nchw_to_nhwc8_kernel, dim3(bx, F), dim3(256), 0, stream, src, (__bf16*)dst, C, hw, inner,
+                       stride_outer, stride_inner);
+    FOD_LAUNCH_CHECK();
+    return FOD_OK;
+  }
   FOD_DISPATCH_T(dtype, "nchw_to_nhwc",
                  hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(n)), dim3(256), 0, stream, src, (T*)dst, F,
                                     C, H, W, Cp, inner, stride_outer, stride_inner))
