@@ -192,6 +192,12 @@ extern "C" int fod_host_flag_set(void* flag, uint32_t value) {
   return FOD_OK;
 }
 
+extern "C" int fod_stream_wait_supported(int device) {
+  int can = 0;
+  if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) != hipSuccess) return 0;
+  return can ? 1 : 0;
+}
+
 extern "C" int fod_stream_wait_flag(void* flag, uint32_t value, fod_stream_t stream) {
   if (!flag) return FOD_ERR_ARG;
   const hipError_t e = hipStreamWaitValue32(reinterpret_cast<hipStream_t>(stream), flag, value, hipStreamWaitValueGte, 0xFFFFFFFFu);

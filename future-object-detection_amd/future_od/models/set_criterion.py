@@ -153,7 +153,13 @@ class _AsyncLap:
                 raise
             for fn in take_unrun_while_matching():       # independent GPU work, queued ahead of the parked wait
                 fn()
-            L._plain_call("fod_stream_wait_flag", self.flag, self.ticket, stream)
+            try:
+                L._plain_call("fod_stream_wait_flag", self.flag, self.ticket, stream)
+            except L.FodError:
+                # the stream could not be parked: wait for the worker on the host instead (correct, one stall), and
+                # keep to the host-synchronous matcher from now on
+                self.join()
+                _WAIT_SUPPORT[self.device.index or 0] = False
         # the host block is read when this kernel RUNS, i.e. after the worker has released the stream
         L._plain_call("fod_copy_from_host_i32", match_host, match.data_ptr(), Lv * B * M, stream)
         return match
@@ -187,11 +193,23 @@ def _async_lap(device):
     return _ASYNC_LAP[key]
 
 
+_WAIT_SUPPORT = {}
+
+
+def _stream_wait_supported(device):
+    idx = torch.device(device).index or 0
+    if idx not in _WAIT_SUPPORT:
+        from future_od.native import lib as L
+        _WAIT_SUPPORT[idx] = bool(L._ENTRY["fod_stream_wait_supported"](idx))      # a capability, not a status code
+    return _WAIT_SUPPORT[idx]
+
+
 def async_matching_enabled(device):
     """The asynchronous matcher needs a GPU stream to park; FOD_ASYNC_MATCH=0 restores the host sync, =2 parks even
     when the cost matrices have already arrived (so that tests reach the worker path on tiny inputs)."""
     import os
-    return torch.device(device).type == "cuda" and os.environ.get("FOD_ASYNC_MATCH", "1") != "0"
+    return (torch.device(device).type == "cuda" and os.environ.get("FOD_ASYNC_MATCH", "1") != "0"
+            and _stream_wait_supported(device))
 
 
 def build_matcher(args):

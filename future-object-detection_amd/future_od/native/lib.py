@@ -92,6 +92,7 @@ SIGNATURES = {
     "fod_copy_from_host_i32": [_p, _p, _i, _p],
     "fod_host_flag_set": [_p, C.c_uint32],
     "fod_stream_wait_flag": [_p, C.c_uint32, _p],
+    "fod_stream_wait_supported": [_i],
     "fod_match_after_event": [_i, _p, _p, _i, _i, _i, _p, _p, _p, _p, C.c_uint32, _i],
     "fod_set_loss_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "fod_set_loss_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],

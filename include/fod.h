@@ -270,6 +270,9 @@ int fod_copy_from_host_i32(const int32_t* src_host, int32_t* dst, int n, fod_str
 int fod_host_flag_destroy(void* flag);
 int fod_host_flag_set(void* flag, uint32_t value);
 int fod_stream_wait_flag(void* flag, uint32_t value, fod_stream_t stream);
+/* 1 if streams of `device` can wait on a memory value (hipDeviceAttributeCanUseStreamWaitValue), else 0: the caller
+ * then keeps the host-synchronous matcher.  (Returns the capability, not a status code.) */
+int fod_stream_wait_supported(int device);
 int fod_match_after_event(int device, void* event, const float* cost_host, int nprob, int M, int ld_n,
                           const int32_t* n_cols, const int32_t* col_offset, int32_t* match_out, void* flag,
                           uint32_t ticket, int threads);
