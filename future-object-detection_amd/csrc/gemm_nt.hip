@@ -720,7 +720,14 @@ int launch_nt(const NtParams& p, hipStream_t stream) {
   // epilogue (~4.5 us) then overlap nothing; two narrower blocks per CU overlap each other
   static const char* env_narrow = getenv("FOD_NT_NARROW");
   const int narrow_below = env_narrow ? atoi(env_narrow) : 320;
-  const bool narrow = p.N <= 64 || (long)q.gy * ceil_div(p.N, 128) < narrow_below;
+  // ... and when the last round of 128-wide blocks would leave most of the chip idle: fill = tiles / (rounds x
+  // resident blocks), 2 wide or 3 narrow blocks per CU (registers / LDS); a narrow tile is ~10 % less efficient per
+  // FLOP, hence the margin.  layer4's 3x3 convolutions (544 wide tiles: 53 % -> 71 %): forward 0.149 -> 0.130 ms,
+  // input gradient 0.203 -> 0.174 ms; the layer1/2 shapes (tens of thousands of tiles) stay wide.
+  const long t_wide = (long)q.gy * ceil_div(p.N, 128), t_narrow = (long)q.gy * ceil_div(p.N, 64);
+  const double fill_wide = (double)t_wide / (double)(ceil_div(t_wide, 512L) * 512L);
+  const double fill_narrow = (double)t_narrow / (double)(ceil_div(t_narrow, 768L) * 768L);
+  const bool narrow = p.N <= 64 || t_wide < narrow_below || (!env_narrow && fill_narrow > 1.15 * fill_wide);
   const dim3 block(256);
   constexpr int BK = ROW_BYTES / (int)sizeof(T);
   const bool utap = MODE != MODE_DENSE && p.Cs % BK == 0;     // a k-tile never straddles two taps
