@@ -32,9 +32,25 @@ def patched(ctx, *a):
 
 
 SC._SetLossFn.forward = staticmethod(patched)
+# other insertion points: the start of the step, the start of the backbone's backward (POINT=step|backbone)
+POINT = os.environ.get("POINT", "matcher")
+if POINT != "matcher":
+    SC._SetLossFn.forward = staticmethod(orig)
+if POINT == "backbone":
+    from future_od.native import backbone as BB
+    orig_bb = BB.BackboneFn.backward
+
+    def patched_bb(ctx, *a):
+        if DELAY[0] > 0:
+            torch.cuda._sleep(int(DELAY[0] * cyc_per_ms))
+        return orig_bb(ctx, *a)
+
+    BB.BackboneFn.backward = staticmethod(patched_bb)
 
 
 def step():
+    if POINT == "step" and DELAY[0] > 0:
+        torch.cuda._sleep(int(DELAY[0] * cyc_per_ms))
     opt.zero_grad()
     out, _s, loss, stats, od = model(data=data, distributed=False)
     loss.backward()
@@ -59,4 +75,4 @@ base = run(0.0)
 print(f"no delay: {base:.2f} ms/step")
 for d in (2.0, 4.0, 8.0):
     t = run(d)
-    print(f"delay {d:.0f} ms after the matcher sync: {t:.2f} ms/step (+{t - base:.2f}): {d - (t - base):.2f} ms absorbed")
+    print(f"delay {d:.0f} ms at {POINT}: {t:.2f} ms/step (+{t - base:.2f}): {d - (t - base):.2f} ms absorbed")
