@@ -3,6 +3,7 @@
 One process per GPU; backend "nccl" is RCCL on ROCm (xGMI inside a node).  The gradient all-reduce
 itself lives in future_od.parallel (bucketed, overlapped with backward); what is here are the
 per-iteration scalars, batched into as few collectives as the data allows."""
+import builtins
 import os
 import signal
 import threading
@@ -10,56 +11,67 @@ import threading
 import torch
 import torch.distributed as distrib
 
+# Set by SIGINT / SIGTERM / SIGUSR2 (slurm's pre-emption notice): the Trainer finishes the iteration it is in,
+# then returns, so a checkpoint is never cut off in the middle of a write.
 EXIT = threading.Event()
-EXIT.clear()
 
 
-def _clean_exit_handler(signum, frame):
+def _request_exit(signum, _frame):
     EXIT.set()
-    print("Exiting cleanly", flush=True)
+    builtins.print(f"signal {signum}: finishing the current iteration, then exiting", flush=True)
 
 
-def install_signal_handlers():
-    for sig in (signal.SIGINT, signal.SIGTERM, signal.SIGUSR2):
-        try:
-            signal.signal(sig, _clean_exit_handler)
-        except ValueError:        # not the main thread
-            pass
+def install_signal_handlers(signals=(signal.SIGINT, signal.SIGTERM, signal.SIGUSR2)):
+    """Route the given signals to EXIT.  Only the main thread may install handlers; elsewhere this is a no-op."""
+    if threading.current_thread() is not threading.main_thread():
+        return False
+    for s in signals:
+        signal.signal(s, _request_exit)
+    return True
 
 
 install_signal_handlers()
 
 
+class _RankFilteredPrint:
+    """print() for one-process-per-GPU runs: only the master rank's lines reach stdout unless force=True is given."""
+
+    def __init__(self, is_master):
+        self.is_master = bool(is_master)
+        self.inner = builtins.print.inner if isinstance(builtins.print, _RankFilteredPrint) else builtins.print
+
+    def __call__(self, *values, force=False, **kw):
+        if self.is_master or force:
+            self.inner(*values, **kw)
+
+
 def disable_prints_unless_master(is_master):
-    import builtins
-    builtin_print = builtins.print
+    builtins.print = _RankFilteredPrint(is_master)
 
-    def print(*args, **kwargs):
-        force = kwargs.pop("force", False)
-        if is_master or force:
-            builtin_print(*args, **kwargs)
 
-    builtins.print = print
+def _env_int(*names, default=0):
+    for n in names:
+        if n in os.environ:
+            return int(os.environ[n])
+    return int(default)
 
 
 def init_distributed_and_device_(args):
-    if args.distributed:
-        args.world_size = int(os.environ.get("WORLD_SIZE", os.environ.get("SLURM_NTASKS", 1)))
-        args.world_rank = int(os.environ.get("RANK", os.environ.get("SLURM_PROCID", 0)))
-        local = int(os.environ.get("LOCAL_RANK", getattr(args, "local_rank", 0)))
-        args.local_rank = local
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            args.device = torch.device("cuda", local)
-            torch.cuda.set_device(args.device)
-        else:
-            args.device = torch.device("cpu")
-        distrib.init_process_group(backend=backend, init_method="env://")
-        disable_prints_unless_master(args.world_rank == 0)
-    else:
-        args.local_rank = 0
-        args.world_rank = 0
-        args.world_size = 1
+    """Fill args.world_size / world_rank / local_rank / device and, if args.distributed, join the process group given
+    by the launcher's environment (torch.distributed.run or slurm).  RCCL ("nccl") when a GPU is visible, gloo
+    otherwise (CPU tests)."""
+    if not getattr(args, "distributed", False):
+        args.world_size, args.world_rank, args.local_rank = 1, 0, 0
+        return
+    args.world_size = _env_int("WORLD_SIZE", "SLURM_NTASKS", default=1)
+    args.world_rank = _env_int("RANK", "SLURM_PROCID", default=0)
+    args.local_rank = _env_int("LOCAL_RANK", default=getattr(args, "local_rank", 0))
+    on_gpu = torch.cuda.is_available()
+    args.device = torch.device("cuda", args.local_rank) if on_gpu else torch.device("cpu")
+    if on_gpu:
+        torch.cuda.set_device(args.device)
+    distrib.init_process_group(backend="nccl" if on_gpu else "gloo", init_method="env://")
+    disable_prints_unless_master(args.world_rank == 0)
 
 
 def reduce_distrib_loss(input_dict, average=True):

@@ -25,23 +25,26 @@ STAGES = (((448, 800), 32), ((896, 1600), 16))          # (size, global batch), 
 
 
 def train(model, args, detr_args, config):
-    lr_sched, optimizer = setup_optimizer(detr_args, model, get_lr_func(args.epochs))
+    """Stage k runs until `until[k]` epochs have been done in total (60 % / 100 %): the learning-rate schedule spans
+    both stages, the loaders are swapped in between (reference :17-41)."""
+    schedule, optimizer = setup_optimizer(detr_args, model, get_lr_func(args.epochs))
     stages = getattr(args, "stages", STAGES)
-    (size1, batch1), (size2, batch2) = stages
-    train_loader, val_loaders = get_nusc_loaders(size1, offsets=OFFSETS, config=config, args=args,
-                                                 train_batch_size=batch1)
-    trainer = get_trainer(args, config, detr_args, lr_sched, model, optimizer, train_loader, val_loaders)
-    print("Starting first training stage")
-    trainer.train(int(args.epochs * 0.60))
-    print("Starting second training stage")
-    trainer._train_loader, trainer._val_loaders = get_nusc_loaders(size2, offsets=OFFSETS, config=config, args=args,
-                                                                   train_batch_size=batch2)
-    trainer.train(args.epochs)
+    until = (int(args.epochs * 0.60), args.epochs)
+    trainer = None
+    for k, ((size, global_batch), last_epoch) in enumerate(zip(stages, until)):
+        loaders = get_nusc_loaders(size, offsets=OFFSETS, config=config, args=args, train_batch_size=global_batch)
+        if trainer is None:
+            trainer = get_trainer(args, config, detr_args, schedule, model, optimizer, *loaders)
+        else:
+            trainer._train_loader, trainer._val_loaders = loaders
+        print(f"Starting {('first', 'second')[k]} training stage: {size[0]}x{size[1]}, global batch {global_batch}, "
+              f"epochs up to {last_epoch}")
+        trainer.train(last_epoch)
     return trainer
 
 
 def main(argv=None):
-    print("Started script: {}, with pytorch {}".format(os.path.basename(__file__), torch.__version__))
+    print(f"{os.path.basename(__file__)}: pytorch {torch.__version__}, hip {torch.version.hip}")
     parser = build_base_parser()
     parser.add_argument("--epochs", default=160, type=int, help="Number of training epochs")
     parser.add_argument("--steps_per_epoch", default=8, type=int, help="synthetic batches per epoch")
@@ -59,7 +62,6 @@ def main(argv=None):
                                        pretrained_backbone=False)
     init_distributed_and_device_(args)
     model = build_model(args, detr_args)
-    print("built model")
     os.makedirs(args.out, exist_ok=True)
     config = {"checkpoint_path": args.out, "visualization_path": args.out}
     return train(model, args, detr_args, config)

@@ -137,3 +137,22 @@ def test_fastcall_wrappers_cover_every_entry_point_and_agree_with_ctypes():
     assert L.FAST["fod_multi_permute_chunk"]() == L.LIB.fod_multi_permute_chunk()
     with pytest.raises(TypeError):
         L.FAST["fod_colsum_acc"](0, None)                          # wrong arity is a Python error, not a wild call
+
+
+def test_average_meter_semantics_and_checkpoint_state():
+    """Weighted epoch mean, history, and a pickled state with the reference's attribute names (checkpoints carry
+    these objects: reference future_od/trainer.py:282-300)."""
+    import pickle
+    from future_od.utils.stats import AverageMeter
+    m = AverageMeter()
+    assert m.avg == 0
+    m.update(2.0, 0)
+    assert m.avg == "nan"
+    m.update(2.0, 1); m.update(4.0, 3)
+    assert abs(m.avg - 3.5) < 1e-12 and m.val == 4.0 and m.count == 4
+    state = m.__getstate__()
+    assert set(state) == {"history", "val", "sum", "avg", "count"}
+    m2 = pickle.loads(pickle.dumps(m))
+    assert m2.avg == m.avg and m2.count == 4
+    m.new_epoch()
+    assert m.history == [3.5] and m.avg == 0 and m.count == 0
