@@ -89,7 +89,9 @@ class FusedAdamW(torch.optim.Optimizer):
         up = [self._upload(x, dev) for x in (ptrs, numel, lr_wd, torch.tensor(bt, dtype=torch.int32),
                                              torch.tensor(bc, dtype=torch.int32))]
         # pinned copies of the pointer table, used in turn when only gradient addresses move between steps; the
-        # step's one host sync (the matcher) bounds how far the GPU lags, three buffers are never in flight at once
+        # launching thread runs at most one step ahead of the GPU (the matcher joins its previous job at each
+        # submission, or blocks on the cost matrices in the host-synchronous mode), so three buffers are never in
+        # flight at once
         ring = [up[0][1], up[0][1].clone().pin_memory(), up[0][1].clone().pin_memory()]
         self._keep = [u[1] for u in up]
         return tuple(u[0] for u in up), ring
