@@ -313,3 +313,16 @@ def test_tracker_baseline_matches_reference_fixture(golden):
     rel_close(out3["pred_logits"], g["core3_logits"], 1e-3, "tracker core logits")
     rel_close(out1["pred_boxes"], g["core1_boxes"], 1e-3, "tracker core, one frame: boxes")
     rel_close(out1["pred_logits"], g["core1_logits"], 1e-3, "tracker core, one frame: logits")
+
+
+def test_ctypes_fallback_binding_still_runs_the_model():
+    """Without the generated fast-call wrappers (FOD_FASTCALL=0) every entry point is called through ctypes with the same
+    integer addresses: the smoke step (one forward + backward checked against the oracle) must pass that way too."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FOD_FASTCALL="0")
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "smoke ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
