@@ -97,16 +97,25 @@ class FusedAdamW(torch.optim.Optimizer):
         return tuple(u[0] for u in up), ring
 
     def _refresh_grad_pointers(self, plan):
-        """Same parameters as last step; returns False if the plan no longer applies."""
+        """Same parameters (with a gradient) as last step, in one pass over all parameters; returns False if the plan
+        no longer applies."""
         gptrs = []
-        for p, old in zip(plan["params"], plan["gptrs"]):
-            g = p.grad
-            if g is None:
-                return False
-            gp = g.data_ptr()
-            if gp != old and (g.dtype != torch.float32 or not _same_layout(g, p)):
-                return False
-            gptrs.append(gp)
+        planned, olds = plan["params"], plan["gptrs"]
+        n, i = len(planned), 0
+        for grp in self.param_groups:
+            for p in grp["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                if i >= n or p is not planned[i]:
+                    return False                     # a parameter gained (or another lost) its gradient
+                gp = g.data_ptr()
+                if gp != olds[i] and (g.dtype != torch.float32 or not _same_layout(g, p)):
+                    return False
+                gptrs.append(gp)
+                i += 1
+        if i != n:
+            return False
         if gptrs != plan["gptrs"]:
             plan["turn"] = (plan["turn"] + 1) % len(plan["ring"])
             host = plan["ring"][plan["turn"]]
@@ -143,9 +152,8 @@ class FusedAdamW(torch.optim.Optimizer):
         # then only the pointer column is refreshed -- asynchronously, never a blocking copy
         plan = getattr(self, "_plan", None)
         if plan is not None:
-            n_with_grad = sum(1 for grp in self.param_groups for p in grp["params"] if p.grad is not None)
             ok = (plan["lrs"] == [(g["lr"], g["weight_decay"]) for g in self.param_groups]
-                  and n_with_grad == len(plan["params"]) and self._refresh_grad_pointers(plan))
+                  and self._refresh_grad_pointers(plan))
             if ok:
                 self._launch(plan["tab"], plan["dev"], betas, eps)
                 return None
