@@ -35,6 +35,26 @@ def _lin(x, m: nn.Linear, relu=False, out_f32=False):
     return Fn.linear(x, m.weight, m.bias, relu=relu, out_f32=out_f32)
 
 
+class _Proj:
+    """An output projection that has not been applied yet: `_add_norm` applies it together with the residual add and
+    the post-norm as one autograd node (Fn.linear_add_norm), or on its own when dropout sits in between."""
+    __slots__ = ("a", "lin")
+
+    def __init__(self, a, lin):
+        self.a, self.lin = a, lin
+
+
+def _add_norm(x, new, norm: nn.LayerNorm, p, training):
+    """norm(x + dropout(new)) -- the post-norm residual step of every sub-layer (reference transformer.py:271-272,
+    285-286, 310-311, 417-418); `new` is a tensor or a pending `_Proj`."""
+    if isinstance(new, _Proj):
+        vec_ok = new.lin.weight.shape[0] % 8 == 0
+        if vec_ok and not (training and p > 0.0):
+            return Fn.linear_add_norm(new.a, x, new.lin.weight, new.lin.bias, norm.weight, norm.bias)
+        new = _lin(new.a, new.lin)
+    return Fn.layer_norm(x, norm.weight, norm.bias, residual=Fn.dropout(new, p, training))
+
+
 class MLP(nn.Module):
     """Linear -> ReLU -> ... -> Linear (reference transformer.py:18-32)."""
 
@@ -88,7 +108,7 @@ class SlotToSlotAttention(Attention):
         q = Fn.add(qc, qp, b_row_mod=M)
         k = Fn.add(kc, kp, b_row_mod=M)
         a = Fn.attention(q, k, v, 1.0 / math.sqrt(self.D // self.Nhead), drop_p=self.droprate, training=self.training)
-        return _lin(a, self.fun.out_proj)
+        return _Proj(a, self.fun.out_proj)
 
     def forward_cross(self, x, qpos, other):
         """Queries attend to another query set `other` [B,M,D] that shares their positions (the previous frame's
@@ -99,7 +119,7 @@ class SlotToSlotAttention(Attention):
         q = Fn.add(qc, _lin(qpos, self.query_pos), b_row_mod=M)
         k = Fn.add(kc, _lin(qpos, self.key_pos), b_row_mod=M)
         a = Fn.attention(q, k, v, 1.0 / math.sqrt(self.D // self.Nhead), drop_p=self.droprate, training=self.training)
-        return _lin(a, self.fun.out_proj)
+        return _Proj(a, self.fun.out_proj)
 
 
 class EgodeepAttention(nn.Module):
@@ -190,7 +210,7 @@ class SlotToImageAttention(Attention):
         if self.store_attention:
             kc, ks, _v = side.slots(layer, image)
             self.stored_attention = _head_mean_weights(qc, kc, qs, ks.unsqueeze(0).expand(B, -1, -1), self.Nhead)
-        return _lin(a, self.fun.out_proj)
+        return _Proj(a, self.fun.out_proj)
 
 
 @torch.no_grad()
@@ -235,16 +255,16 @@ class TransformerDecoderLayer(nn.Module):
         slotstates [B,M,D] or None; egodeep [B,D] (ONE IMU token per sample) or None."""
         t, p = self.training, self.droprate
         o = self.self_attend(x, qpos, pos_proj["sa"] if pos_proj else None)
-        x = Fn.layer_norm(x, self.norm_sa.weight, self.norm_sa.bias, residual=Fn.dropout(o, p, t))
+        x = _add_norm(x, o, self.norm_sa, p, t)
         # the sine embedding is the same for every image of the layer: all their query_sine projections at once
         qs_all = Fn.group_linear(query_sine, [self.image_attend[i].query_sine for i in range(side.K)])
         for i in range(side.K):
             o = self.image_attend[i](x, qpos, query_sine, side, layer, i, is_first, qs=qs_all[i],
                                      qpos_proj=pos_proj["ca"][i] if (pos_proj and is_first) else None)
-            x = Fn.layer_norm(x, self.norm_ia[i].weight, self.norm_ia[i].bias, residual=Fn.dropout(o, p, t))
+            x = _add_norm(x, o, self.norm_ia[i], p, t)
         if self.slotstates_attend is not None and slotstates is not None:
             o = self.slotstates_attend.forward_cross(x, qpos, slotstates)
-            x = Fn.layer_norm(x, self.norm_ssa.weight, self.norm_ssa.bias, residual=Fn.dropout(o, p, t))
+            x = _add_norm(x, o, self.norm_ssa, p, t)
         if self.egodeep_attend is not None and egodeep is not None and egodeep.dim() == 3:     # [B,S,D]: several keys
             e = Fn.dropout(self.egodeep_attend.forward_keys(x, qpos, egodeep), p, t)
             x = Fn.layer_norm(x, self.norm_eda.weight, self.norm_eda.bias, residual=e)
@@ -255,8 +275,7 @@ class TransformerDecoderLayer(nn.Module):
             if torch.is_grad_enabled():
                 x = Fn.ZeroGradAnchor.apply(x, *self.egodeep_attend.dead_parameters())
         h = Fn.dropout(_lin(x, self.feedforward[0], relu=True), p, t)
-        return Fn.layer_norm(x, self.norm_out.weight, self.norm_out.bias,
-                             residual=Fn.dropout(_lin(h, self.feedforward[3]), p, t))
+        return _add_norm(x, _Proj(h, self.feedforward[3]), self.norm_out, p, t)
 
 
 class TransformerDecoder(nn.Module):
@@ -353,10 +372,9 @@ class EncoderAttention(nn.Module):
             q, k, v = Fn.in_proj_cross(xp, add_pos(other), other, self.attn.in_proj_weight, self.attn.in_proj_bias)
         a = Fn.attention(q, k, v, 1.0 / math.sqrt(D // self.H), drop_p=self.droprate, training=self.training)
         t, p = self.training, self.droprate
-        src = Fn.layer_norm(src, self.norm1.weight, self.norm1.bias,
-                            residual=Fn.dropout(_lin(a, self.attn.out_proj), p, t))
+        src = _add_norm(src, _Proj(a, self.attn.out_proj), self.norm1, p, t)
         h = Fn.dropout(_lin(src, self.mlp[0], relu=True), p, t)
-        return Fn.layer_norm(src, self.norm2.weight, self.norm2.bias, residual=Fn.dropout(_lin(h, self.mlp[3]), p, t))
+        return _add_norm(src, _Proj(h, self.mlp[3]), self.norm2, p, t)
 
 
 class TransformerEncoderLayer(nn.Module):
