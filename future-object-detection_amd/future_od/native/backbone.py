@@ -129,7 +129,7 @@ def _conv_fwd(x, cw, bn, dtype, relu, residual=None, cin_pad=None):
     scale, shift = bn.scale_shift()
     w = Fn.prep_conv(cw.weight, dtype, scale, False, cin_pad=cin_pad)
     geom = ops.conv_geom(x.shape, cw.weight.shape[0], cw.k, cw.stride, cw.pad)
-    return ops.conv2d_fwd(x, w, geom, shift=shift, residual=residual, relu=relu), geom
+    return ops.conv2d_fwd(x, w, geom, shift=shift, residual=residual, relu=relu, work_cin=cw.weight.shape[1]), geom
 
 
 class BackboneFn(Function):

@@ -181,12 +181,13 @@ def conv_geom(x_shape, cout, k, stride, pad):
     return ConvGeom(n, h, w, cin, ho, wo, cout, k, k, stride, pad)
 
 
-def _conv_flops(g):
-    """Algorithmic FLOPs of one conv pass: 2 * output pixels * Cout * kh*kw*Cin (same for dgrad, wgrad)."""
-    return 2.0 * g.Nimg * g.Ho * g.Wo * g.Cout * g.kh * g.kw * g.Cin
+def _conv_flops(g, cin=None):
+    """Algorithmic FLOPs of one conv pass: 2 * output pixels * Cout * kh*kw*Cin (same for dgrad, wgrad).  `cin`: the
+    layer's real input channels when the operand is channel-padded (the stem: 3, stored as 8)."""
+    return 2.0 * g.Nimg * g.Ho * g.Wo * g.Cout * g.kh * g.kw * (g.Cin if cin is None else cin)
 
 
-def conv2d_fwd(x, w, geom, *, scale=None, shift=None, residual=None, relu=False):
+def conv2d_fwd(x, w, geom, *, scale=None, shift=None, residual=None, relu=False, work_cin=None):
     """x NHWC, w [Cout, kh, kw, Cin] (same dtype) -> y NHWC."""
     _chk(x, "x"); _chk(w, "w", x.dtype)
     assert tuple(x.shape) == (geom.Nimg, geom.H, geom.W, geom.Cin), (x.shape, geom.H, geom.W, geom.Cin)
@@ -198,7 +199,7 @@ def conv2d_fwd(x, w, geom, *, scale=None, shift=None, residual=None, relu=False)
     if residual is not None:
         _chk(residual, "residual", x.dtype); assert residual.shape == y.shape
     call("fod_conv2d_fwd", dt(x), ptr(x), ptr(w), ptr(y), _Addr(geom),
-         _epi(scale, shift, residual, geom.Cout, 0, None, 0, relu), stream(), work=_conv_flops(geom))
+         _epi(scale, shift, residual, geom.Cout, 0, None, 0, relu), stream(), work=_conv_flops(geom, work_cin))
     return y
 
 
