@@ -21,5 +21,5 @@ hipcc --offload-arch=gfx950 -shared -fPIC -o lib/libfod_hip.so build/*.o -lpthre
 # fast-call CPython wrappers of the same entry points (generated from the binding's signature table)
 python3 ../tools/gen_fastcall.py > /dev/null
 gcc -O2 -shared -fPIC -I"$(python3 -c 'import sysconfig; print(sysconfig.get_paths()["include"])')" \
-    csrc/fastcall.c -o lib/_fodfast.so -Llib -lfod_hip -Wl,-rpath,'$ORIGIN'
+    build/fastcall.c -o lib/_fodfast.so -Llib -lfod_hip -Wl,-rpath,'$ORIGIN'
 echo "built $(pwd)/lib/libfod_hip.so"

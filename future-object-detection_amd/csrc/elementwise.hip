@@ -344,6 +344,60 @@ __global__ void u8_nchw_to_nhwc_kernel(const unsigned char* __restrict__ src, T*
   }
 }
 
+// The stem's input layout (gemm_nt.hip MODE_STEM): [F][Hp][Wp][4] with image pixel (y, x) at (y + 3, x + 3), 3
+// real channels + one zero, zeros in the halo -- the kernel writes the WHOLE haloed frame, so the buffer needs no
+// clearing.  Source: f32 planes (already normalised) or raw uint8 planes normalised on the fly, in fp32, in the
+// reference's order ((x / 255) - mean) / std (transforms.py:12-15, nu_scenes.py:97-101).  Two pixels per thread.
+template <typename T, typename S>
+__global__ __launch_bounds__(256) void stem_layout_kernel(const S* __restrict__ src, T* __restrict__ dst, int C, int H,
+                                                          int W, int Hp, int Wp, int inner, long stride_outer,
+                                                          long stride_inner, const float* __restrict__ mean,
+                                                          const float* __restrict__ stdv) {
+  const int f = blockIdx.y;
+  const S* s = src + (long)(f / inner) * stride_outer + (long)(f % inner) * stride_inner;
+  const long hw = (long)H * W;
+  const int pairs_per_row = Wp / 2;
+  const long npairs = (long)Hp * pairs_per_row;
+  T* o = dst + (long)f * Hp * Wp * 4;
+  float m[3] = {0.f, 0.f, 0.f}, sd[3] = {1.f, 1.f, 1.f};
+  if (mean) {
+    for (int c = 0; c < 3 && c < C; ++c) {
+      m[c] = mean[c];
+      sd[c] = stdv[c];
+    }
+  }
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += (long)gridDim.x * blockDim.x) {
+    const int yp = (int)(i / pairs_per_row);
+    const int xp = 2 * (int)(i - (long)yp * pairs_per_row);
+    const int y = yp - 3;
+    T v[8];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int x = xp + j - 3;
+      const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float val = 0.f;
+        if (in && c < C && c < 3) {
+          val = (float)s[c * hw + (long)y * W + x];
+          if (sizeof(S) == 1) {
+            val = val / 255.f;
+            val = (val - m[c]) / sd[c];
+          }
+        }
+        v[j * 4 + c] = from_f32<T>(val);
+      }
+    }
+    T* q = o + ((long)yp * Wp + xp) * 4;
+    if (sizeof(T) == 2) {
+      *reinterpret_cast<uint4*>(q) = *reinterpret_cast<const uint4*>(v);
+    } else {
+      *reinterpret_cast<uint4*>(q) = *reinterpret_cast<const uint4*>(v);
+      *reinterpret_cast<uint4*>(q + 4) = *reinterpret_cast<const uint4*>(v + 4);
+    }
+  }
+}
+
 template <typename T>
 __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int Nimg, int H, int W, int C, int Ho,
                                int Wo) {
@@ -732,6 +786,33 @@ extern "C" int fod_u8_nchw_to_nhwc(int dtype, const unsigned char* src, void* ds
   FOD_DISPATCH_T(dtype, "u8_nchw_to_nhwc",
                  hipLaunchKernelGGL((u8_nchw_to_nhwc_kernel<T>), dim3(grid_for(n)), dim3(256), 0, stream, src, (T*)dst,
                                     F, C, H, W, Cp, inner, stride_outer, stride_inner, mean, stdv))
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
+}
+
+extern "C" int fod_clip_to_stem_layout(int dtype, int src_u8, const void* src, void* dst, int F, int C, int H, int W,
+                                       int Hp, int Wp, int inner, long stride_outer, long stride_inner,
+                                       const float* mean, const float* stdv, hipStream_t stream) {
+  FOD_REQUIRE(src && dst && F > 0 && F <= 65535 && C > 0 && C <= 3 && inner > 0 && F % inner == 0,
+              "clip_to_stem_layout: bad args");
+  FOD_REQUIRE(Hp >= H + 3 && Wp >= W + 3 && Wp % 2 == 0, "clip_to_stem_layout: haloed frame %dx%d too small for %dx%d",
+              Hp, Wp, H, W);
+  FOD_REQUIRE(!src_u8 || (mean && stdv), "clip_to_stem_layout: uint8 frames need mean / std");
+  FOD_REQUIRE(((uintptr_t)dst % 16) == 0, "clip_to_stem_layout: destination must be 16-byte aligned");
+  const long npairs = (long)Hp * (Wp / 2);
+  const int bx = (int)std::min<long>((npairs + 255) / 256, 1024);
+  const dim3 grid(bx, F), block(256);
+  if (src_u8) {
+    FOD_DISPATCH_T(dtype, "clip_to_stem_layout",
+                   hipLaunchKernelGGL((stem_layout_kernel<T, unsigned char>), grid, block, 0, stream,
+                                      (const unsigned char*)src, (T*)dst, C, H, W, Hp, Wp, inner, stride_outer,
+                                      stride_inner, mean, stdv))
+  } else {
+    FOD_DISPATCH_T(dtype, "clip_to_stem_layout",
+                   hipLaunchKernelGGL((stem_layout_kernel<T, float>), grid, block, 0, stream, (const float*)src,
+                                      (T*)dst, C, H, W, Hp, Wp, inner, stride_outer, stride_inner,
+                                      (const float*)nullptr, (const float*)nullptr))
+  }
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }

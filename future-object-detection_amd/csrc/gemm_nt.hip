@@ -11,6 +11,10 @@
 //                 taps with r = (hi+pad)%2 (mod 2), s likewise, reach an output pixel, so a class contracts over
 //                 its own compact tap list (3x3: 4+2+2+1 taps instead of 4x9) and no gathered row is ever
 //                 discarded for parity: 4x fewer MFMAs and loads than running MODE_DGRAD with stride 2.
+//   MODE_STEM   : the 7x7 stride-2 stem over a ZERO-HALOED 4-channel image (fod_clip_to_stem_layout): the k axis
+//                 is (tap row r, 8 pixels, 4 channels) = 7 x 32 -- a tap row is 32 contiguous elements of the source,
+//                 A(m,k) = xp[img, 2*ho + r, 2*wo + px, ch] with k = 32 r + 4 px + ch, no bounds checks at all.
+//                 K = 224 for 147 real taps (8-channel NHWC needed 7x7x8 = 392) and half the input bytes.
 //
 // Replaces, on the reference path, every torch conv2d / linear forward and input-gradient:
 //   torchvision ResNet convs via reference future_od/models/paper.py:114-116, nn.Linear in
@@ -27,7 +31,7 @@
 
 namespace {
 
-enum { MODE_DENSE = 0, MODE_CONV = 1, MODE_DGRAD = 2, MODE_DGRAD_S2 = 3 };
+enum { MODE_DENSE = 0, MODE_CONV = 1, MODE_DGRAD = 2, MODE_DGRAD_S2 = 3, MODE_STEM = 4 };
 
 struct NtParams {
   const void* A;
@@ -143,7 +147,11 @@ FOD_DEVINL void gemm_nt_body(const NtParams& p) {
         }
       }
       a_base[i] = (unsigned)((long)img * p.Hs * p.Ws * p.Cs * (long)sizeof(T));
-      if (MODE == MODE_CONV) {
+      if (MODE == MODE_STEM) {
+        // byte offset of haloed pixel (img, 2 ho, 2 wo): the first tap of output pixel (ho, wo)
+        a_base[i] = valid ? a_base[i] + (unsigned)(((long)(2 * ph) * p.Ws + 2 * pw) * p.Cs * (long)sizeof(T)) : OOB;
+        a_h[i] = a_w[i] = 0;
+      } else if (MODE == MODE_CONV) {
         a_h[i] = valid ? ph * p.stride - p.pad : -(1 << 28);
         a_w[i] = pw * p.stride - p.pad;
       } else if (MODE == MODE_DGRAD_S2) {
@@ -187,7 +195,8 @@ FOD_DEVINL void gemm_nt_body(const NtParams& p) {
   //   else : per-thread walk of this thread's chunk; offsets by multiplication (stem, ragged channel counts).
   int tap_r = 0, tap_s = 0, tap_c = UTAP ? 0 : ccs * VEC;
   unsigned tap_off = 0, tap_kb = 0;
-  if (MODE != MODE_DENSE) {
+  const unsigned stem_row_b = (unsigned)(p.Ws * p.Cs) * ESZ;   // MODE_STEM: bytes per source image row
+  if (MODE != MODE_DENSE && MODE != MODE_STEM) {
     const int tap = tap_c / p.Cs;
     tap_c -= tap * p.Cs;
     tap_r = tap / tap_w;
@@ -214,7 +223,7 @@ FOD_DEVINL void gemm_nt_body(const NtParams& p) {
     if (MODE == MODE_DGRAD_S2)
       kb = UTAP ? tap_kb + cc_off
                 : (unsigned)(((p.r_first + 2 * r) * p.kw + p.s_first + 2 * s) * p.Cs + c) * ESZ;
-    if (MODE != MODE_DENSE) {                        // advance to the next tile's tap
+    if (MODE != MODE_DENSE && MODE != MODE_STEM) {   // advance to the next tile's tap
       tap_c += BK;
       if (UTAP) {
         tap_off = MODE == MODE_CONV ? tap_off + BKB : tap_off - BKB;
@@ -241,6 +250,8 @@ FOD_DEVINL void gemm_nt_body(const NtParams& p) {
       unsigned off;
       if (MODE == MODE_DENSE) {
         off = (kin && a_base[i] != OOB) ? a_base[i] + kb : OOB;
+      } else if (MODE == MODE_STEM) {
+        off = (kin && a_base[i] != OOB) ? a_base[i] + (unsigned)(k >> 5) * stem_row_b + (unsigned)(k & 31) * ESZ : OOB;
       } else {
         // forward: source = (a_h + r, a_w + s); both dgrad modes walk the taps backwards
         const int hs = MODE == MODE_CONV ? a_h[i] + r : a_h[i] - r;
@@ -518,6 +529,10 @@ template <typename T, int NT, bool UTAP>
 __global__ __launch_bounds__(256, 2) void conv2d_fwd_kernel(const NtParams p) {
   gemm_nt_body<T, MODE_CONV, NT, UTAP>(p);
 }
+template <typename T, int NT>
+__global__ __launch_bounds__(256, 2) void conv_stem_fwd_kernel(const NtParams p) {
+  gemm_nt_body<T, MODE_STEM, NT, false>(p);
+}
 template <typename T, int NT, bool UTAP>
 __global__ __launch_bounds__(256, 2) void conv2d_dgrad_kernel(const NtParams p) {
   gemm_nt_body<T, MODE_DGRAD, NT, UTAP>(p);
@@ -730,7 +745,7 @@ int launch_nt(const NtParams& p, hipStream_t stream) {
   const bool narrow = p.N <= 64 || t_wide < narrow_below || (!env_narrow && fill_narrow > 1.15 * fill_wide);
   const dim3 block(256);
   constexpr int BK = ROW_BYTES / (int)sizeof(T);
-  const bool utap = MODE != MODE_DENSE && p.Cs % BK == 0;     // a k-tile never straddles two taps
+  const bool utap = MODE != MODE_DENSE && MODE != MODE_STEM && p.Cs % BK == 0;     // a k-tile never straddles two taps
   q.gx = ceil_div(p.N, narrow ? 64 : 128);
   const dim3 grid(q.gx * ((q.gy + 7) / 8 * 8));
   const size_t lds = 2 * (BM + (narrow ? 64 : 128)) * ROW_BYTES;
@@ -741,6 +756,8 @@ int launch_nt(const NtParams& p, hipStream_t stream) {
   } while (0)
   if constexpr (MODE == MODE_DENSE) {
     FOD_NT_LAUNCH((gemm_nt_kernel<T, 1>), (gemm_nt_kernel<T, 2>));
+  } else if constexpr (MODE == MODE_STEM) {
+    FOD_NT_LAUNCH((conv_stem_fwd_kernel<T, 1>), (conv_stem_fwd_kernel<T, 2>));
   } else if constexpr (MODE == MODE_CONV) {
     if (utap) FOD_NT_LAUNCH((conv2d_fwd_kernel<T, 1, true>), (conv2d_fwd_kernel<T, 2, true>));
     else FOD_NT_LAUNCH((conv2d_fwd_kernel<T, 1, false>), (conv2d_fwd_kernel<T, 2, false>));
@@ -932,4 +949,38 @@ extern "C" int fod_conv2d_fwd(int dtype, const void* x, const void* w, void* y, 
 extern "C" int fod_conv2d_dgrad(int dtype, const void* dy, const void* w_t, void* dx, const fod_conv_geom* g,
                                 const fod_epilogue* epi, hipStream_t stream) {
   return conv_common(dtype, true, dy, w_t, dx, g, epi, stream);
+}
+
+// The ResNet stem (7x7, stride 2, pad 3, 3 input channels; torchvision conv1 via reference paper.py:94-98,114-116)
+// over the haloed 4-channel layout written by fod_clip_to_stem_layout: xp [Nimg][Hp][Wp][4] with image pixel
+// (y, x) at (y + 3, x + 3) and zeros elsewhere; w [Cout][7][8][4] (tap row, pixel, channel; zero for pixel 7 and
+// channel 3); y NHWC [Nimg][Ho][Wo][Cout].
+extern "C" int fod_conv_stem_fwd(int dtype, const void* xp, const void* w, void* y, int Nimg, int Hp, int Wp, int Ho,
+                                 int Wo, int Cout, const fod_epilogue* epi, hipStream_t stream) {
+  const int vec = dtype == FOD_BF16 ? 8 : 4;
+  FOD_REQUIRE(xp && w && y, "conv_stem: null operand");
+  FOD_REQUIRE(Nimg > 0 && Ho > 0 && Wo > 0 && Cout > 0 && Cout % vec == 0, "conv_stem: bad extents");
+  FOD_REQUIRE(Hp >= 2 * Ho + 5 && Wp >= 2 * Wo + 6 && Wp % 2 == 0,
+              "conv_stem: haloed image %dx%d too small for %dx%d outputs (need >= %dx%d, even width)", Hp, Wp, Ho, Wo,
+              2 * Ho + 5, 2 * Wo + 6);
+  FOD_REQUIRE(((uintptr_t)xp % 16) == 0 && ((uintptr_t)w % 16) == 0, "conv_stem: operands must be 16-byte aligned");
+  FOD_REQUIRE((long)Nimg * Ho * Wo < (1L << 31), "conv_stem: pixel count overflows int");
+  NtParams p{};
+  p.A = xp; p.B = w; p.C = y;
+  p.Hs = Hp; p.Ws = Wp; p.Cs = 4;
+  p.Hd = Ho; p.Wd = Wo;
+  p.kh = 7; p.kw = 8; p.stride = 2; p.pad = 3;
+  p.M = Nimg * Ho * Wo;
+  p.N = Cout;
+  p.K = 7 * 32;
+  p.ldb = p.K;
+  p.ldc = p.N;
+  fill_epilogue(p, epi);
+  decide_vec_epilogue(p);
+  const long esz = dtype == FOD_BF16 ? 2 : 4;
+  const long ab = (long)Nimg * Hp * Wp * 4 * esz, bb = (long)p.N * p.K * esz;
+  FOD_REQUIRE(ab < 0xFFFFFFF0L - 16 && bb < 0xFFFFFFF0L - 16, "conv_stem: operand larger than 4 GiB");
+  p.a_bytes = (unsigned)ab;
+  p.b_bytes = (unsigned)bb;
+  return dispatch_nt<MODE_STEM>(dtype, p, stream);
 }

@@ -9,6 +9,8 @@ because stem and layer1 are frozen (reference future_od/models/paper.py:102-109)
 Module/parameter names follow torchvision's ResNet so checkpoints load unchanged
 (SURVEY.md 8b): body.conv1, body.bn1, body.layer{1..4}.{i}.{conv,bn}{1,2,3}, downsample.{0,1}.
 """
+import os
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -122,14 +124,24 @@ class ResNetBody(nn.Module):
         return c
 
 
-STEM_CIN_PAD = 8   # 3 input channels padded to one 16-byte bf16 chunk
+# frames per pass of the frozen front (stem .. last frozen block); 0 (default) = all frames at once
+FRONT_FRAMES = int(os.environ.get("FOD_FRONT_FRAMES", "0")) or (1 << 30)
 
 
-def _conv_fwd(x, cw, bn, dtype, relu, residual=None, cin_pad=None):
+def _conv_fwd(x, cw, bn, dtype, relu, residual=None, cin_pad=None, out=None):
     scale, shift = bn.scale_shift()
     w = Fn.prep_conv(cw.weight, dtype, scale, False, cin_pad=cin_pad)
     geom = ops.conv_geom(x.shape, cw.weight.shape[0], cw.k, cw.stride, cw.pad)
-    return ops.conv2d_fwd(x, w, geom, shift=shift, residual=residual, relu=relu, work_cin=cw.weight.shape[1]), geom
+    return ops.conv2d_fwd(x, w, geom, shift=shift, residual=residual, relu=relu, work_cin=cw.weight.shape[1],
+                          out=out), geom
+
+
+def _scale7(bn, scale):
+    """The frozen-BN scale repeated per tap row ([Cout*7], the row index of the stem weight's permute job)."""
+    hit = getattr(bn, "_s7", None)
+    if hit is None or hit[0] is not scale:
+        bn._s7 = (scale, scale.repeat_interleave(7).contiguous())
+    return bn._s7[1]
 
 
 class BackboneFn(Function):
@@ -138,27 +150,64 @@ class BackboneFn(Function):
         """video f32 [B,L,3,H,W] (a strided view is fine) -> features NHWC [(l b), h, w, hidden];
         train_weights = trainable conv weights in body.blocks() order, then proj.weight, proj.bias
         (listed only so autograd routes their gradients)."""
-        x = ops.clip_to_nhwc_frame_major(video, dtype, STEM_CIN_PAD, *body.pixel_norm(video))
-        x, _ = _conv_fwd(x, body.conv1, body.bn1, dtype, relu=True, cin_pad=STEM_CIN_PAD)
-        x = ops.maxpool3x3s2(x)
-        tape = []
-        for stage, blk in body.blocks():
+        scale1, shift1 = body.bn1.scale_shift()
+        w_stem = Fn.prep_stem(body.conv1.weight, dtype, _scale7(body.bn1, scale1))
+        norm = body.pixel_norm(video)
+
+        def block_fwd(blk, x, out=None):
+            """One residual block forward; returns (output, activations, geometries, downsample geometry)."""
             main, ds = blk.convs()
-            trainable = main[0][0].weight.requires_grad
-            idt = x
-            ds_geom = None
+            idt, ds_geom = x, None
             if ds is not None:
                 idt, ds_geom = _conv_fwd(x, ds[0], ds[1], dtype, relu=False)
             acts, geoms = [x], []
             h = x
             for j, (cw, bn) in enumerate(main):
                 last = j == len(main) - 1
-                h, g = _conv_fwd(h, cw, bn, dtype, relu=True, residual=idt if last else None)
+                h, g = _conv_fwd(h, cw, bn, dtype, relu=True, residual=idt if last else None,
+                                 out=out if last else None)
                 acts.append(h)
                 geoms.append(g)
-            if trainable:
+            return h, acts, geoms, ds_geom
+
+        blocks = list(body.blocks())
+        # The frozen front of the network (stem, max-pool and every leading block without trainable weights: layer1
+        # in the reference's configuration, paper.py:102-109) keeps nothing for backward, so it CAN run a few frames
+        # at a time (FOD_FRONT_FRAMES) in the hope that a producer's output (46 MB per 900x1600 frame) is still in
+        # the 256 MB Infinity Cache when its consumer reads it.  Measured (profiles/r02b): no gain -- conv forward
+        # 5.35 ms with all 10 frames per launch, 5.58 / 5.45 ms with 2 / 4 -- so the default is all frames at once.
+        n_front = 0
+        while n_front < len(blocks) and not blocks[n_front][1].convs()[0][0][0].weight.requires_grad:
+            n_front += 1
+        b_sz, l_sz = video.shape[0], video.shape[1]
+        steps = max(1, min(l_sz, FRONT_FRAMES // max(b_sz, 1)))
+        x = None
+        for l0 in range(0, l_sz, steps):
+            part = video[:, l0:l0 + steps]
+            xp = ops.clip_to_stem_layout(part, dtype, *norm)
+            h = ops.conv_stem_fwd(xp, w_stem, video.shape[-2], video.shape[-1], shift=shift1, relu=True)
+            del xp
+            h = ops.maxpool3x3s2(h)
+            for i in range(n_front):
+                dst = None
+                if i == n_front - 1 and steps < l_sz:
+                    if x is None:
+                        cout = blocks[i][1].convs()[0][-1][0].weight.shape[0]
+                        x = torch.empty((l_sz * b_sz, h.shape[1], h.shape[2], cout), dtype=dtype, device=video.device)
+                    dst = x[l0 * b_sz:(l0 + part.shape[1]) * b_sz]
+                h, _, _, _ = block_fwd(blocks[i][1], h, out=dst)
+            if steps >= l_sz:
+                x = h
+            elif n_front == 0:
+                if x is None:
+                    x = torch.empty((l_sz * b_sz,) + tuple(h.shape[1:]), dtype=dtype, device=video.device)
+                x[l0 * b_sz:(l0 + part.shape[1]) * b_sz].copy_(h)
+            del h
+        tape = []
+        for _stage, blk in blocks[n_front:]:
+            x, acts, geoms, ds_geom = block_fwd(blk, x)
+            if blk.convs()[0][0][0].weight.requires_grad:
                 tape.append((blk, acts, geoms, ds_geom))
-            x = h
         geom_p = ops.conv_geom(x.shape, proj.weight.shape[0], 1, 1, 0)
         wp = Fn.prep_conv(proj.weight, dtype, None, False)
         feat = ops.conv2d_fwd(x, wp, geom_p, shift=proj.bias.detach())

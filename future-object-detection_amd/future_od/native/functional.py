@@ -238,6 +238,22 @@ def prep_conv(weight, dtype, scale, transposed, cin_pad=None):
     return PREP.get(_wkey(weight, tag, dtype, (cp, 0 if scale is None else scale.data_ptr())), [weight], build)
 
 
+def prep_stem(weight, dtype, scale7):
+    """Stem weight OIHW [Cout,3,7,7] f32 -> [Cout][7 tap rows][8 pixels][4 channels] * scale (zeros for pixel 7 /
+    channel 3): the k order of fod_conv_stem_fwd.  `scale7` = the frozen-BN scale repeated per tap row [Cout*7]."""
+    co, ci, kh, kw = weight.shape
+    s_co, s_ci, s_kh, s_kw = weight.stride()
+    assert (ci, kh, kw) == (3, 7, 7) and s_co == kh * s_kh, "stem weight: expected [Cout,3,7,7] with dense tap rows"
+    w = weight.detach()
+
+    def build():
+        out = torch.empty((co, 7, 8, 4), dtype=dtype, device=w.device)
+        return out, [_Job(w, out, (co * 7, 8, 4), (s_kh, s_kw, s_ci), valid1=7, valid2=3, scale=scale7,
+                          axis=0 if scale7 is not None else -1)]
+
+    return PREP.get(_wkey(weight, "stem", dtype, (0 if scale7 is None else scale7.data_ptr(),)), [weight], build)
+
+
 def cast(t, dtype, pad_cols=None):
     """[rows, cols] tensor -> dtype, optionally zero-padding the last dim."""
     cols = t.shape[-1]

@@ -187,12 +187,16 @@ def _conv_flops(g, cin=None):
     return 2.0 * g.Nimg * g.Ho * g.Wo * g.Cout * g.kh * g.kw * (g.Cin if cin is None else cin)
 
 
-def conv2d_fwd(x, w, geom, *, scale=None, shift=None, residual=None, relu=False, work_cin=None):
-    """x NHWC, w [Cout, kh, kw, Cin] (same dtype) -> y NHWC."""
+def conv2d_fwd(x, w, geom, *, scale=None, shift=None, residual=None, relu=False, work_cin=None, out=None):
+    """x NHWC, w [Cout, kh, kw, Cin] (same dtype) -> y NHWC (`out`: a contiguous destination of that shape)."""
     _chk(x, "x"); _chk(w, "w", x.dtype)
     assert tuple(x.shape) == (geom.Nimg, geom.H, geom.W, geom.Cin), (x.shape, geom.H, geom.W, geom.Cin)
     assert w.numel() == geom.Cout * geom.kh * geom.kw * geom.Cin
-    y = torch.empty((geom.Nimg, geom.Ho, geom.Wo, geom.Cout), dtype=x.dtype, device=x.device)
+    if out is None:
+        y = torch.empty((geom.Nimg, geom.Ho, geom.Wo, geom.Cout), dtype=x.dtype, device=x.device)
+    else:
+        y = _chk(out, "out", x.dtype)
+        assert tuple(y.shape) == (geom.Nimg, geom.Ho, geom.Wo, geom.Cout), (y.shape,)
     for v in (scale, shift):
         if v is not None:
             _chk(v, "scale/shift", torch.float32); assert v.numel() == geom.Cout
@@ -200,6 +204,47 @@ def conv2d_fwd(x, w, geom, *, scale=None, shift=None, residual=None, relu=False,
         _chk(residual, "residual", x.dtype); assert residual.shape == y.shape
     call("fod_conv2d_fwd", dt(x), ptr(x), ptr(w), ptr(y), _Addr(geom),
          _epi(scale, shift, residual, geom.Cout, 0, None, 0, relu), stream(), work=_conv_flops(geom, work_cin))
+    return y
+
+
+def stem_geom(h, w):
+    """(Ho, Wo, Hp, Wp) of the 7x7 stride-2 pad-3 stem and of the haloed layout it reads."""
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    return ho, wo, max(2 * ho + 5, h + 3), max(2 * wo + 6, w + 3 + ((w + 3) & 1))
+
+
+def clip_to_stem_layout(video, dtype, mean=None, std=None):
+    """[B,L,3,H,W] f32 (normalised) or uint8 (raw; normalised on the fly with `mean` / `std`) -> the stem's haloed
+    4-channel layout [L*B, Hp, Wp, 4] ordered (l, b); see fod_clip_to_stem_layout."""
+    if not video.is_cuda or video.dtype not in (torch.float32, torch.uint8):
+        raise L.FodError("video must be a float32 or uint8 device tensor")
+    b, l, c, h, w = video.shape
+    sb, sl, sc, sh, sw = video.stride()
+    assert c <= 3 and (sc, sh, sw) == (h * w, w, 1), f"frame planes must be contiguous, got strides {video.stride()}"
+    _, _, hp, wp = stem_geom(h, w)
+    out = torch.empty((l * b, hp, wp, 4), dtype=dtype, device=video.device)
+    u8 = video.dtype == torch.uint8
+    if u8:
+        _chk(mean, "mean", torch.float32); _chk(std, "std", torch.float32)
+        assert mean.numel() == c and std.numel() == c
+    call("fod_clip_to_stem_layout", _DT[dtype], int(u8), ptr(video), ptr(out), l * b, c, h, w, hp, wp, b, sl, sb,
+         ptr(mean) if u8 else None, ptr(std) if u8 else None, stream())
+    return out
+
+
+def conv_stem_fwd(xp, w, h, wd, *, shift=None, relu=True):
+    """xp: haloed layout of an [*, 3, h, wd] clip; w [Cout, 7, 8, 4] -> y NHWC [F, Ho, Wo, Cout]."""
+    _chk(xp, "xp"); _chk(w, "w", xp.dtype)
+    f, hp, wp, c4 = xp.shape
+    ho, wo, hp_need, wp_need = stem_geom(h, wd)
+    cout = w.shape[0]
+    assert c4 == 4 and (hp, wp) == (hp_need, wp_need) and tuple(w.shape[1:]) == (7, 8, 4), (xp.shape, w.shape)
+    if shift is not None:
+        _chk(shift, "shift", torch.float32); assert shift.numel() == cout
+    y = torch.empty((f, ho, wo, cout), dtype=xp.dtype, device=xp.device)
+    call("fod_conv_stem_fwd", dt(xp), ptr(xp), ptr(w), ptr(y), f, hp, wp, ho, wo, cout,
+         _epi(None, shift, None, cout, 0, None, 0, relu), stream(), work=2.0 * f * ho * wo * cout * 147,
+         tag="fod_conv2d_fwd")
     return y
 
 

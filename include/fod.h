@@ -121,6 +121,13 @@ typedef struct fod_conv_geom {
  * chain and the 1x1 input_proj: future_od/models/paper.py:94-98,112-116. */
 int fod_conv2d_fwd(int dtype, const void* x, const void* w, void* y, const fod_conv_geom* g,
                    const fod_epilogue* epi, fod_stream_t stream);
+/* The ResNet stem: 7x7 stride-2 pad-3 convolution of a 3-channel image (+ frozen-BN shift, ReLU in `epi`);
+ * torchvision resnet conv1 / bn1 / relu via future_od/models/paper.py:94-98,114-116.
+ * xp: the haloed 4-channel layout of fod_clip_to_stem_layout, [Nimg][Hp][Wp][4], Hp >= 2*Ho+5, Wp >= 2*Wo+6 (even);
+ * w: [Cout][7 tap rows][8 pixels][4 channels] (zero for pixel 7 and channel 3, frozen-BN scale folded in);
+ * y: NHWC [Nimg][Ho][Wo][Cout].  Contracts over 7 x 32 = 224 instead of 7 x 7 x 8 = 392 padded taps. */
+int fod_conv_stem_fwd(int dtype, const void* xp, const void* w, void* y, int Nimg, int Hp, int Wp, int Ho, int Wo,
+                      int Cout, const fod_epilogue* epi, fod_stream_t stream);
 /* dx = epi(conv2d_input_grad(dy, w)).  w_t is the weight re-laid as [Cin][kh][kw][Cout]. */
 int fod_conv2d_dgrad(int dtype, const void* dy, const void* w_t, void* dx, const fod_conv_geom* g,
                      const fod_epilogue* epi, fod_stream_t stream);
@@ -144,6 +151,15 @@ int fod_nchw_to_nhwc(int dtype, const float* src, void* dst, int F, int C, int H
 int fod_u8_nchw_to_nhwc(int dtype, const unsigned char* src, void* dst, int F, int C, int H, int W, int Cp,
                         int inner, long stride_outer, long stride_inner, const float* mean, const float* std,
                         fod_stream_t stream);
+
+/* The frame tensor's one read for the stem (future_od/models/paper.py:146; pixel pipeline of
+ * future_od/datasets/transforms.py:12-15, nu_scenes.py:97-101 when src_u8): writes the WHOLE haloed frame
+ * dst [F][Hp][Wp][4] (dtype): image pixel (y, x), channels 0..2, at (y + 3, x + 3); everything else zero.
+ * src: f32 planes (src_u8 = 0) or uint8 planes (src_u8 = 1, normalised on the fly with mean / std [C]);
+ * frame f is read from src + (f / inner)*stride_outer + (f % inner)*stride_inner (elements). */
+int fod_clip_to_stem_layout(int dtype, int src_u8, const void* src, void* dst, int F, int C, int H, int W, int Hp,
+                            int Wp, int inner, long stride_outer, long stride_inner, const float* mean,
+                            const float* std, fod_stream_t stream);
 
 /* dst[i0][i1][i2] = src[i0*s0 + i1*s1 + i2*s2] * scale[index on scale_axis]   (i2 >= valid2 -> 0)
  * src_dtype/dst_dtype independent.  Weight preparation (cast, transpose, BN-scale fold, channel pad)

@@ -147,6 +147,76 @@ def test_conv2d_fwd_dgrad_wgrad(dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 3, 17, 23, "f32"), (1, 2, 64, 96, "u8"), (1, 3, 33, 40, "f32"), (1, 1, 225, 401, "u8")])
+def test_stem_layout_and_conv(dtype, case):
+    """fod_clip_to_stem_layout + fod_conv_stem_fwd (K-packed 7x7 stride-2 stem) against F.conv2d on the same
+    (rounded) pixels and weights, through the module-level weight preparation."""
+    from future_od.native import functional as Fn
+    b, l, h, w_, kind = case
+    g = torch.Generator().manual_seed(h * 1000 + w_)
+    mean, std = torch.tensor([0.485, 0.456, 0.406]), torch.tensor([0.229, 0.224, 0.225])
+    if kind == "u8":
+        video = torch.randint(0, 256, (b, l, 3, h, w_), generator=g, dtype=torch.uint8)
+        pix = ((video.float() / 255.0) - mean.view(1, 1, 3, 1, 1)) / std.view(1, 1, 3, 1, 1)
+        xp = ops.clip_to_stem_layout(video.to(DEV), dtype, mean.to(DEV), std.to(DEV))
+    else:
+        video = torch.randn((b, l, 3, h, w_), generator=g)
+        pix = video
+        xp = ops.clip_to_stem_layout(video.to(DEV), dtype)
+    ho, wo, hp, wp = ops.stem_geom(h, w_)
+    assert tuple(xp.shape) == (l * b, hp, wp, 4)
+    want = torch.zeros(l * b, hp, wp, 4)
+    want[:, 3:3 + h, 3:3 + w_, :3] = pix.transpose(0, 1).reshape(l * b, 3, h, w_).permute(0, 2, 3, 1)
+    if kind == "u8" and dtype == torch.float32:
+        assert torch.equal(xp.cpu(), want), "uint8 fold must be bit-equal to host normalisation"
+    check(xp, want.to(dtype), dtype, 1, f"stem layout {case}")
+    weight = torch.nn.Parameter((torch.randn(64, 3, 7, 7, generator=g) / math.sqrt(147)).contiguous(
+        memory_format=torch.channels_last).to(DEV))
+    scale, shift = (torch.rand(64, generator=g) + 0.5), torch.randn(64, generator=g) * 0.1
+    wprep = Fn.prep_stem(weight, dtype, scale.repeat_interleave(7).contiguous().to(DEV))
+    y = ops.conv_stem_fwd(xp, wprep, h, w_, shift=shift.to(DEV), relu=True)
+    x_r = xp[:, 3:3 + h, 3:3 + w_, :3].float().cpu().permute(0, 3, 1, 2)          # the rounded pixels the kernel saw
+    w_r = (weight.detach().cpu() * scale.view(-1, 1, 1, 1)).to(dtype).float()
+    ref = (F.conv2d(x_r, w_r, None, 2, 3) + shift.view(1, -1, 1, 1)).clamp(min=0).permute(0, 2, 3, 1)
+    assert tuple(y.shape) == (l * b, ho, wo, 64)
+    check(y, ref, dtype, 4, f"stem conv {case}")
+
+
+# One real layer per ResNet-50 stage at the headline resolution (900x1600: maps 225x400, 113x200, 57x100, 29x50),
+# one frame: ragged edge tiles in every dimension.  (Nimg, H, W, Cin, Cout, k, stride, pad)
+REAL_CONV_CASES = [
+    (1, 225, 400, 64, 256, 1, 1, 0),       # layer1.x.conv3
+    (1, 225, 400, 128, 128, 3, 2, 1),      # layer2.0.conv2 -> 113x200
+    (1, 57, 100, 1024, 256, 1, 1, 0),      # layer3.x.conv1
+    (1, 29, 50, 512, 512, 3, 1, 1),        # layer4.x.conv2
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", REAL_CONV_CASES)
+def test_conv2d_real_layer_shapes(dtype, case):
+    n, h, w_, cin, cout, k, stride, pad = case
+    x = rnd((n, h, w_, cin), dtype, 11)
+    w = rnd((cout, k, k, cin), dtype, 12, scale=1.0 / math.sqrt(k * k * cin))
+    shift = torch.randn(cout) * 0.1
+    geom = ops.conv_geom(x.shape, cout, k, stride, pad)
+    x32 = x.float().requires_grad_(True)
+    w32 = w.float().requires_grad_(True)
+    y_lin = _conv_ref(x32, w32, stride, pad)
+    y = ops.conv2d_fwd(x.to(DEV), w.to(DEV), geom, shift=shift.to(DEV), relu=True)
+    check(y, (y_lin + shift.view(1, -1, 1, 1)).clamp(min=0).permute(0, 2, 3, 1), dtype, 2, f"conv fwd {case}")
+    dy = rnd((n, geom.Ho, geom.Wo, cout), dtype, 14)
+    y_lin.backward(dy.float().permute(0, 3, 1, 2))
+    mask = rnd((n, h, w_, cin), dtype, 16)
+    dx = ops.conv2d_dgrad(dy.to(DEV), w.permute(3, 1, 2, 0).contiguous().to(DEV), geom, relu_mask=mask.to(DEV))
+    check(dx, torch.where(mask.float() > 0, x32.grad, torch.zeros(())), dtype, 4, f"conv dgrad {case}")
+    dw = torch.zeros((cout, k, k, cin), device=DEV)
+    ops.conv2d_wgrad_acc(dy.to(DEV), x.to(DEV), dw, geom)
+    check(dw, w32.grad, torch.float32 if dtype == torch.float32 else dtype, math.sqrt(n * geom.Ho * geom.Wo),
+          f"conv wgrad {case}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_layout_helpers(dtype):
     v = torch.randn(3, 3, 10, 13)
     out = ops.nchw_to_nhwc(v.to(DEV), dtype, 8)

@@ -50,6 +50,19 @@ def conv_shapes():
     return out
 
 
+if which in ("all", "conv", "stem"):
+    from future_od.native import functional as Fn
+    video = torch.randn(2, FR // 2, 3, 900, 1600, device=DEV)
+    wst = torch.nn.Parameter(torch.randn(64, 3, 7, 7, device=DEV).contiguous(memory_format=torch.channels_last))
+    wprep = Fn.prep_stem(wst, dtype, torch.ones(64 * 7, device=DEV))
+    shift = torch.zeros(64, device=DEV)
+    tl = timeit(lambda: ops.clip_to_stem_layout(video, dtype))
+    xp = ops.clip_to_stem_layout(video, dtype)
+    ts = timeit(lambda: ops.conv_stem_fwd(xp, wprep, 900, 1600, shift=shift))
+    fl = 2.0 * FR * 450 * 800 * 64 * 147
+    print(f"stem (K-packed, haloed 4-ch layout): layout {tl * 1e3:.3f} ms, conv {ts * 1e3:.3f} ms = {fl / ts / 1e12:.1f} TF (147 real taps)")
+    del video, xp
+
 if which in ("all", "conv"):
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
     print(f"{'conv':28s} {'shape':34s} {'fwd TF':>8s} {'dgrad TF':>9s} {'wgrad TF':>9s}   ms(f/d/w)")
