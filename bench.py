@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the K=2 / fp32 side measurements")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="N=1 only: launch every kernel from Python (the default replays the step as one hipGraph)")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--rehearse", action="store_true",
                     help="tiny shapes, gloo backend, every rank on cuda:0: exercises the N>1 code path on a 1-GPU box")
@@ -199,6 +201,15 @@ def main():
             opt.step()
             return loss
 
+        eager_step = step
+        if use_graph:
+            # the same step -- same kernels, same order -- captured once and replayed (future_od/graph.py); the
+            # capture and its eager warm-up steps happen before the timed region
+            from future_od.graph import GraphedStep
+            graphed = GraphedStep(model, opt, warmup=2)
+            graphed(data)
+            step = lambda: graphed(data)[1]
+
         for _ in range(warmup):
             step()
         fence()
@@ -214,12 +225,13 @@ def main():
         summ, nprof = None, 2
         if profile and rank != 0:
             for _ in range(nprof):                   # the steps hold collectives: every rank runs them, rank 0 measures
-                step()
+                eager_step()
         if profile and rank == 0:
-            # every entry point timed with events on the launching stream for a few more steps
+            # every entry point timed with events on the launching stream for a few more (eagerly launched) steps
+            eager_step()
             L.PROFILER.start()
             for _ in range(nprof):
-                step()
+                eager_step()
             L.PROFILER.stop()
             summ = L.PROFILER.summary()
         final = float(loss.detach())
@@ -229,6 +241,7 @@ def main():
         torch.cuda.empty_cache()
         return dt, final, summ, nprof
 
+    use_graph = (not distributed) and (not a.no_graph) and (not a.rehearse)
     dt, final_loss, summ, nprof = measure(a.num_images, a.dtype, a.steps, a.warmup, not a.no_roofline)
     seqs = BATCH_PER_GPU * world * a.steps
     value = seqs / dt
@@ -246,6 +259,7 @@ def main():
                    "global_batch": BATCH_PER_GPU * world, "frames": T_FRAMES, "resolution": [HEIGHT, WIDTH],
                    "num_images": a.num_images, "parallelism": f"dp{world}"},
         "final_loss": final_loss,
+        "launch_mode": "hipgraph replay (one graph per step)" if use_graph else "eager (one Python call per kernel)",
     }
     fl = live_flops_per_sequence(a.num_images)
     if fl:

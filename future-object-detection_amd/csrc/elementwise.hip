@@ -253,34 +253,116 @@ __global__ void permute3_kernel(const TS* __restrict__ src, TD* __restrict__ dst
 // otherwise).  Block b works on chunk blk_chunk[b] (MP_CHUNK elements) of job blk_job[b].
 constexpr int MP_CHUNK = 8192;
 
+// Three shapes of job, chosen per job on the host side of the table (fod_multi_permute_tiles):
+//   rows      (s2 == 1)            : source rows are contiguous along the destination's fast dim: 4 elements per
+//                                    thread, 16-byte loads (f32) / 8-byte stores (bf16);
+//   transpose (s0 == 1 or s1 == 1) : the source is contiguous along destination dim f (0 or 1): a 32 (dim f) x 256
+//                                    (dim 2) tile goes through LDS, read along f and written along dim 2, so both
+//                                    sides move whole 128-byte lines (a per-element gather touched 64 lines per
+//                                    wave-load: the per-step refresh of all weight copies cost 0.94 ms, ~8x its bytes);
+//   generic   (anything else)      : one element per thread.
+// A chunk is MP_CHUNK destination elements: consecutive ones (rows / generic) or one 32 x 256 tile (transpose).
+__host__ __device__ inline int mp_fast_dim(const fod_permute_job& j) {
+  if (j.s2 == 1 || j.d2 == 1) return 2;
+  if (j.s1 == 1 && j.d1 > 1) return 1;
+  if (j.s0 == 1 && j.d0 > 1) return 0;
+  return -1;
+}
+
 template <typename TS, typename TD>
-FOD_DEVINL void multi_permute_body(const fod_permute_job& j, long first) {
+FOD_DEVINL void multi_permute_body(const fod_permute_job& j, long chunk, float* tile) {
   const TS* __restrict__ src = reinterpret_cast<const TS*>(j.src);
   TD* __restrict__ dst = reinterpret_cast<TD*>(j.dst);
-  const long n = (long)j.d0 * j.d1 * j.d2;
-  const long last = min(n, first + MP_CHUNK);
-  for (long i = first + threadIdx.x; i < last; i += blockDim.x) {
-    const int i2 = (int)(i % j.d2);
-    const long t = i / j.d2;
-    const int i1 = (int)(t % j.d1);
-    const int i0 = (int)(t / j.d1);
+  const unsigned d0 = j.d0, d1 = j.d1, d2 = j.d2;
+  const int fast = mp_fast_dim(j);
+  const int tid = threadIdx.x;
+  if (fast == 0 || fast == 1) {
+    // ---- transpose through LDS: tile = 32 indices of dim f x 256 of dim 2, for one index of the other dim g
+    const unsigned df = fast == 1 ? d1 : d0, dg = fast == 1 ? d0 : d1;
+    const long sg = fast == 1 ? j.s0 : j.s1;
+    const unsigned tiles2 = (d2 + 255) / 256, tilesf = (df + 31) / 32;
+    const unsigned c = (unsigned)chunk;
+    const unsigned t2 = c % tiles2, rest = c / tiles2;
+    const unsigned tf = rest % tilesf, ig = rest / tilesf;
+    if (ig >= dg) return;
+    const unsigned f0 = tf * 32, c0 = t2 * 256;
+    // read: lane = index along f (contiguous in the source), 8 columns per pass
+    const unsigned lf = tid & 31, lc = tid >> 5;
+#pragma unroll 4
+    for (unsigned cc = lc; cc < 256; cc += 8) {
+      const unsigned i2 = c0 + cc, ifx = f0 + lf;
+      float v = 0.f;
+      const unsigned i1 = fast == 1 ? ifx : ig;
+      if (ifx < df && i2 < d2 && i1 < (unsigned)j.valid1 && i2 < (unsigned)j.valid2)
+        v = to_f32(src[(long)ig * sg + ifx + (long)i2 * j.s2]);
+      tile[lf * 257 + cc] = v;
+    }
+    __syncthreads();
+    // write: lane = column (contiguous in the destination)
+    for (unsigned r = 0; r < 32; ++r) {
+      const unsigned ifx = f0 + r, i2 = c0 + tid;
+      if (ifx >= df || i2 >= d2) continue;
+      const unsigned i0 = fast == 1 ? ig : ifx, i1 = fast == 1 ? ifx : ig;
+      float v = tile[r * 257 + tid];
+      if (j.scale) v *= j.scale[j.scale_axis == 0 ? i0 : (j.scale_axis == 1 ? i1 : i2)];
+      dst[(long)i0 * j.t0 + (long)i1 * j.t1 + i2] = from_f32<TD>(v);
+    }
+    return;
+  }
+  const unsigned n = d0 * d1 * d2;                 // < 2^31 (host-checked)
+  const unsigned first = (unsigned)chunk * MP_CHUNK;
+  const unsigned last = min(n, first + (unsigned)MP_CHUNK);
+  if (fast == 2 && (d2 & 3) == 0 && (j.valid2 & 3) == 0 && sizeof(TS) == 4 &&
+      ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)(j.s0 * 4) | (uintptr_t)(j.s1 * 4)) & 15) == 0 &&
+      ((j.t0 | j.t1) & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    // ---- rows: four consecutive elements of one source row per thread
+    for (unsigned i = first + 4 * tid; i < last; i += 1024) {
+      const unsigned i2 = i % d2, t = i / d2;
+      const unsigned i1 = t % d1, i0 = t / d1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i1 < (unsigned)j.valid1 && i2 < (unsigned)j.valid2) {
+        v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (long)i0 * j.s0 + (long)i1 * j.s1 + i2);
+        if (j.scale) {
+          if (j.scale_axis == 2) {
+            const float4 sc = *reinterpret_cast<const float4*>(j.scale + i2);
+            v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+          } else {
+            const float sc = j.scale[j.scale_axis == 0 ? i0 : i1];
+            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+          }
+        }
+      }
+      TD* o = dst + (long)i0 * j.t0 + (long)i1 * j.t1 + i2;
+      if (sizeof(TD) == 2) {
+        *reinterpret_cast<bf16x4_t*>(o) = bf16x4_t{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+      } else {
+        *reinterpret_cast<float4*>(o) = v;
+      }
+    }
+    return;
+  }
+  for (unsigned i = first + tid; i < last; i += blockDim.x) {
+    const unsigned i2 = i % d2, t = i / d2;
+    const unsigned i1 = t % d1, i0 = t / d1;
     float v = 0.f;
-    if (i1 < j.valid1 && i2 < j.valid2) {
-      v = to_f32(src[i0 * j.s0 + i1 * j.s1 + i2 * j.s2]);
+    if (i1 < (unsigned)j.valid1 && i2 < (unsigned)j.valid2) {
+      v = to_f32(src[(long)i0 * j.s0 + (long)i1 * j.s1 + (long)i2 * j.s2]);
       if (j.scale) v *= j.scale[j.scale_axis == 0 ? i0 : (j.scale_axis == 1 ? i1 : i2)];
     }
-    dst[i0 * j.t0 + i1 * j.t1 + i2] = from_f32<TD>(v);
+    dst[(long)i0 * j.t0 + (long)i1 * j.t1 + i2] = from_f32<TD>(v);
   }
 }
 
-__global__ void multi_permute3_kernel(const fod_permute_job* __restrict__ jobs, const int* __restrict__ blk_job,
-                                      const int* __restrict__ blk_chunk) {
+__global__ __launch_bounds__(256) void multi_permute3_kernel(const fod_permute_job* __restrict__ jobs,
+                                                             const int* __restrict__ blk_job,
+                                                             const int* __restrict__ blk_chunk) {
+  __shared__ float tile[32 * 257];
   const fod_permute_job j = jobs[blk_job[blockIdx.x]];
-  const long first = (long)blk_chunk[blockIdx.x] * MP_CHUNK;
-  if (j.src_dtype == FOD_F32 && j.dst_dtype == FOD_BF16) multi_permute_body<float, __bf16>(j, first);
-  else if (j.src_dtype == FOD_F32) multi_permute_body<float, float>(j, first);
-  else if (j.dst_dtype == FOD_BF16) multi_permute_body<__bf16, __bf16>(j, first);
-  else multi_permute_body<__bf16, float>(j, first);
+  const long chunk = blk_chunk[blockIdx.x];
+  if (j.src_dtype == FOD_F32 && j.dst_dtype == FOD_BF16) multi_permute_body<float, __bf16>(j, chunk, tile);
+  else if (j.src_dtype == FOD_F32) multi_permute_body<float, float>(j, chunk, tile);
+  else if (j.dst_dtype == FOD_BF16) multi_permute_body<__bf16, __bf16>(j, chunk, tile);
+  else multi_permute_body<__bf16, float>(j, chunk, tile);
 }
 
 template <typename T>
@@ -756,6 +838,21 @@ extern "C" int fod_multi_permute3(const fod_permute_job* jobs, const int* blk_jo
 }
 
 extern "C" int fod_multi_permute_chunk(void) { return MP_CHUNK; }
+
+// Number of blocks (chunks) job (d0, d1, d2, s0, s1, s2) takes in fod_multi_permute3: consecutive MP_CHUNK-element
+// chunks, or 32 x 256 tiles when the source is contiguous along destination dim 0 or 1 (transposing jobs).
+extern "C" int fod_multi_permute_tiles(int d0, int d1, int d2, long s0, long s1, long s2) {
+  fod_permute_job j{};
+  j.d0 = d0; j.d1 = d1; j.d2 = d2; j.s0 = s0; j.s1 = s1; j.s2 = s2;
+  const int fast = mp_fast_dim(j);
+  if (fast == 0 || fast == 1) {
+    const long df = fast == 1 ? d1 : d0, dg = fast == 1 ? d0 : d1;
+    return (int)(((d2 + 255) / 256) * ((df + 31) / 32) * dg);
+  }
+  const long n = (long)d0 * d1 * d2;
+  if (n >= (1L << 31)) return -1;
+  return (int)((n + MP_CHUNK - 1) / MP_CHUNK);
+}
 
 extern "C" int fod_nchw_to_nhwc(int dtype, const float* src, void* dst, int F, int C, int H, int W, int Cp,
                                 int inner, long stride_outer, long stride_inner, hipStream_t stream) {

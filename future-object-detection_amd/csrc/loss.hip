@@ -89,7 +89,9 @@ __global__ __launch_bounds__(256) void set_loss_fwd_kernel(const float* __restri
                                                            const float* __restrict__ tb,
                                                            const int32_t* __restrict__ toff,
                                                            float* __restrict__ out, int B, int M, int C,
-                                                           float num_boxes, float alpha) {
+                                                           float num_boxes, const float* __restrict__ num_boxes_dev,
+                                                           float alpha) {
+  if (num_boxes_dev) num_boxes = *num_boxes_dev;
   __shared__ float red[4];
   const int l = blockIdx.x;
   const float* lg = logits + (long)l * B * M * C;
@@ -192,7 +194,8 @@ __global__ void set_loss_bwd_kernel(const float* __restrict__ logits, const floa
                                     const int32_t* __restrict__ match, const int64_t* __restrict__ tl,
                                     const float* __restrict__ tb, const float* __restrict__ g,
                                     float* __restrict__ dlogits, float* __restrict__ dboxes, int L, int B, int M,
-                                    int C, float num_boxes, float alpha) {
+                                    int C, float num_boxes, const float* __restrict__ num_boxes_dev, float alpha) {
+  if (num_boxes_dev) num_boxes = *num_boxes_dev;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;   // (l, b, m)
   if (q >= L * B * M) return;
   const int l = q / (B * M);
@@ -332,6 +335,44 @@ __global__ __launch_bounds__(64) void od_map_kernel(const float* __restrict__ sc
   }
 }
 
+// Dense annotations -> the matcher's packed targets, on the device (reference st_detr.py:237-263 `to_detr_targets`
+// followed by the concatenation inside the matcher): per sample the ACTIVE rows in ascending order, boxes xyxy px
+// -> cxcywh / (W, H, W, H) computed as the reference does (0.5 * (x0 + x1), x1 - x0, then times the f32 reciprocals).
+// One block; a wave compacts 64 rows at a time with a ballot.
+__global__ __launch_bounds__(64) void pack_targets_kernel(const float* __restrict__ anno_boxes,
+                                                          const int64_t* __restrict__ anno_classes,
+                                                          const int64_t* __restrict__ anno_active, int B, int N,
+                                                          float inv_w, float inv_h, int64_t* __restrict__ labels,
+                                                          float* __restrict__ boxes, int32_t* __restrict__ offset,
+                                                          float* __restrict__ count) {
+  const int lane = threadIdx.x;
+  int total = 0;
+  for (int b = 0; b < B; ++b) {
+    if (lane == 0) offset[b] = total;
+    for (int n0 = 0; n0 < N; n0 += 64) {
+      const int n = n0 + lane;
+      const bool keep = n < N && anno_active[(long)b * N + n] == 1;
+      const unsigned long long mask = __ballot(keep);
+      if (keep) {
+        const int dst = total + __popcll(mask & ((1ull << lane) - 1ull));
+        const float* a = anno_boxes + ((long)b * N + n) * 4;
+        const float x0 = a[0], y0 = a[1], x1 = a[2], y1 = a[3];
+        float* o = boxes + (long)dst * 4;
+        o[0] = (0.5f * (x0 + x1)) * inv_w;
+        o[1] = (0.5f * (y0 + y1)) * inv_h;
+        o[2] = (x1 - x0) * inv_w;
+        o[3] = (y1 - y0) * inv_h;
+        labels[dst] = anno_classes[(long)b * N + n];
+      }
+      total += __popcll(mask);
+    }
+  }
+  if (lane == 0) {
+    offset[B] = total;
+    count[0] = (float)total;
+  }
+}
+
 }  // namespace
 
 extern "C" int fod_match_cost(const float* logits, const float* boxes, const int64_t* tgt_labels,
@@ -349,25 +390,25 @@ extern "C" int fod_match_cost(const float* logits, const float* boxes, const int
 
 extern "C" int fod_set_loss_fwd(const float* logits, const float* boxes, const int32_t* match,
                                 const int64_t* tgt_labels, const float* tgt_boxes, const int32_t* tgt_offset,
-                                float* out, int L, int B, int M, int C, float num_boxes, float alpha,
-                                hipStream_t stream) {
+                                float* out, int L, int B, int M, int C, float num_boxes, const float* num_boxes_dev,
+                                float alpha, hipStream_t stream) {
   FOD_REQUIRE(logits && boxes && match && tgt_offset && out && L > 0 && B > 0 && M > 0 && C > 0,
               "set_loss_fwd: bad args");
   hipLaunchKernelGGL(set_loss_fwd_kernel, dim3(L), dim3(256), 0, stream, logits, boxes, match, tgt_labels, tgt_boxes,
-                     tgt_offset, out, B, M, C, num_boxes, alpha);
+                     tgt_offset, out, B, M, C, num_boxes, num_boxes_dev, alpha);
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }
 
 extern "C" int fod_set_loss_bwd(const float* logits, const float* boxes, const int32_t* match,
                                 const int64_t* tgt_labels, const float* tgt_boxes, const float* g, float* dlogits,
-                                float* dboxes, int L, int B, int M, int C, float num_boxes, float alpha,
-                                hipStream_t stream) {
+                                float* dboxes, int L, int B, int M, int C, float num_boxes, const float* num_boxes_dev,
+                                float alpha, hipStream_t stream) {
   FOD_REQUIRE(logits && boxes && match && g && dlogits && dboxes && L > 0 && B > 0 && M > 0 && C > 0,
               "set_loss_bwd: bad args");
   const int rows = L * B * M;
   hipLaunchKernelGGL(set_loss_bwd_kernel, dim3(ceil_div(rows, 256)), dim3(256), 0, stream, logits, boxes, match,
-                     tgt_labels, tgt_boxes, g, dlogits, dboxes, L, B, M, C, num_boxes, alpha);
+                     tgt_labels, tgt_boxes, g, dlogits, dboxes, L, B, M, C, num_boxes, num_boxes_dev, alpha);
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }
@@ -475,6 +516,17 @@ extern "C" int fod_od_map(const float* scores, const float* boxes, const float* 
   hipLaunchKernelGGL(od_map_kernel, dim3(B, C1, T), dim3(64), 0, stream, scores, boxes, anno_boxes, anno_classes,
                      anno_active, confs, is_positive, size_categories, (unsigned long long*)num_annos, B, M, C1, N, T,
                      K, img_h, img_w);
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
+}
+
+extern "C" int fod_pack_targets(const float* anno_boxes, const int64_t* anno_classes, const int64_t* anno_active, int B,
+                                int N, float inv_w, float inv_h, int64_t* labels, float* boxes, int32_t* offset,
+                                float* count, hipStream_t stream) {
+  FOD_REQUIRE(anno_boxes && anno_classes && anno_active && labels && boxes && offset && count && B > 0 && N > 0,
+              "pack_targets: bad args");
+  hipLaunchKernelGGL(pack_targets_kernel, dim3(1), dim3(64), 0, stream, anno_boxes, anno_classes, anno_active, B, N,
+                     inv_w, inv_h, labels, boxes, offset, count);
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }

@@ -48,7 +48,12 @@ __global__ __launch_bounds__(256) void multi_adamw_kernel(const long* __restrict
                                                           const int* __restrict__ blk_tensor,
                                                           const int* __restrict__ blk_chunk, float b1, float b2,
                                                           float eps, float bc1, float bc2,
+                                                          const float* __restrict__ bias_dev,
                                                           const float* __restrict__ sqnorm, float max_norm) {
+  if (bias_dev) {            // bias corrections kept on the device (captured steps: the step count lives there)
+    bc1 = bias_dev[0];
+    bc2 = bias_dev[1];
+  }
   const int t = blk_tensor[blockIdx.x];
   const long base = (long)blk_chunk[blockIdx.x] * CHUNK;
   const long end = min(numel[t], base + CHUNK);
@@ -101,10 +106,11 @@ extern "C" int fod_multi_sqnorm_acc(const long* ptrs, const long* numel, const i
 
 extern "C" int fod_multi_adamw(const long* ptrs, const long* numel, const float* lr_wd, const int* blk_tensor,
                                const int* blk_chunk, int nblocks, float beta1, float beta2, float eps, float bias_c1,
-                               float bias_c2, const float* sqnorm, float max_norm, hipStream_t stream) {
+                               float bias_c2, const float* bias_dev, const float* sqnorm, float max_norm,
+                               hipStream_t stream) {
   FOD_REQUIRE(ptrs && numel && lr_wd && blk_tensor && blk_chunk && nblocks > 0, "multi_adamw: bad args");
   hipLaunchKernelGGL(multi_adamw_kernel, dim3(nblocks), dim3(256), 0, stream, ptrs, numel, lr_wd, blk_tensor,
-                     blk_chunk, beta1, beta2, eps, bias_c1, bias_c2, sqnorm, max_norm);
+                     blk_chunk, beta1, beta2, eps, bias_c1, bias_c2, bias_dev, sqnorm, max_norm);
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }

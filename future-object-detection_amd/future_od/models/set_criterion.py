@@ -60,6 +60,21 @@ class HungarianMatcher(nn.Module):
         return _async_lap(cost.device).submit(cost, sizes * Lv, packed["offset_cpu"][:B].repeat(Lv), threads)
 
     @torch.no_grad()
+    def match_levels_dev(self, logits, boxes, packed):
+        """match_levels() with nothing leaving the device: the cost matrices are solved by one wavefront per problem
+        (fod_lap_solve_batch_dev: the host solver's algorithm, arithmetic and tie rules, bit-identical assignments),
+        the target counts are read from the device-side offset table.  No copy, no host thread, no parked stream:
+        the step is a plain launch sequence (and can be captured as a hipGraph, future_od/graph.py).  Failures
+        (non-finite costs) are reported one step late through `_DeviceLapStatus`."""
+        cost = ops.match_cost(logits, boxes, packed["labels"], packed["boxes"], packed["offset"], packed["ld"],
+                              self.cost_class, self.cost_bbox, self.cost_giou)
+        st = _lap_status(cost.device)
+        st.check()
+        match = ops.lap_solve_batch_dev(cost, packed["offset"], st.flag)
+        st.publish()
+        return match
+
+    @torch.no_grad()
     def forward(self, outputs, targets):
         """Reference-shaped API: list of (idx_pred int64 ascending, idx_tgt int64) per sample."""
         packed = pack_targets(targets, outputs["pred_logits"].device)
@@ -163,6 +178,46 @@ class _AsyncLap:
         # the host block is read when this kernel RUNS, i.e. after the worker has released the stream
         L._plain_call("fod_copy_from_host_i32", match_host, match.data_ptr(), Lv * B * M, stream)
         return match
+
+
+class _DeviceLapStatus:
+    """Failure word of the device solver: a device int the kernel sets, mirrored into pinned host memory by an
+    asynchronous copy after every solve and looked at (without waiting) before the next one -- scipy would have
+    raised inside the step; here the error surfaces one step late, or at `check(wait=True)`."""
+
+    def __init__(self, device):
+        self.flag = torch.zeros(1, dtype=torch.int32, device=device)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+
+    def publish(self):
+        self.host.copy_(self.flag, non_blocking=True)
+
+    def check(self, wait=False):
+        if wait:
+            torch.cuda.current_stream(self.flag.device).synchronize()
+        code = int(self.host[0])
+        if code:
+            self.host.zero_()
+            self.flag.zero_()
+            from future_od.native.lib import FodError
+            raise FodError({1: "matcher: non-finite cost matrix", 2: "matcher: more targets than the cost matrix holds",
+                            3: "matcher: infeasible cost matrix"}.get(code, f"matcher: device solver status {code}"))
+
+
+_LAP_STATUS = {}
+
+
+def _lap_status(device):
+    key = (device.type, device.index)
+    if key not in _LAP_STATUS:
+        _LAP_STATUS[key] = _DeviceLapStatus(device)
+    return _LAP_STATUS[key]
+
+
+def device_matching_enabled(device):
+    """The matcher runs entirely on the GPU by default (FOD_DEVICE_MATCH=0: host solver, asynchronous or blocking)."""
+    import os
+    return torch.device(device).type == "cuda" and os.environ.get("FOD_DEVICE_MATCH", "1") != "0"
 
 
 # Work that does not depend on the matches (post-processing, AP bookkeeping) can be queued between the cost matrices'
@@ -319,6 +374,15 @@ class SetCriterion(nn.Module):
             dist.all_reduce(t, group=group)
         return max(float(t.item()) / dist.get_world_size(), 1.0)
 
+    def device_num_boxes(self, count, distributed):
+        """set_criterion.py:185-193 without the `.item()`: `count` is the device-side total of this rank's targets
+        (ops.pack_targets_dev); the normaliser stays a device scalar that the loss kernels read when they run."""
+        if distributed:
+            count = count.clone()
+            dist.all_reduce(count)
+            count = count / dist.get_world_size()
+        return torch.clamp(count, min=1.0)
+
     def forward(self, outputs, targets, distributed, packed=None, num_boxes=None):
         if "_stacked" in outputs:
             logits, boxes = outputs["_stacked"]
@@ -332,8 +396,10 @@ class SetCriterion(nn.Module):
             packed = pack_targets(targets, logits.device)
         if num_boxes is None:
             num_boxes = self.global_num_boxes(targets, logits.device, distributed)
-        if async_matching_enabled(logits.device):
-            levels = (lambda t: t.detach()) if self._matching_mode == "per level" else (lambda t: t.detach()[-1:])
+        levels = (lambda t: t.detach()) if self._matching_mode == "per level" else (lambda t: t.detach()[-1:].contiguous())
+        if packed.get("device"):
+            match = self.matcher.match_levels_dev(levels(logits), levels(boxes), packed)
+        elif async_matching_enabled(logits.device):
             match = self.matcher.match_levels_async(levels(logits), levels(boxes), packed)
         elif self._matching_mode == "per level":
             match, _ = self.matcher.match_levels(logits.detach(), boxes.detach(), packed)

@@ -11,8 +11,8 @@ from dataclasses import dataclass
 import torch
 import torch.nn as nn
 
-from future_od.models.set_criterion import (SetCriterion, build_matcher, pack_targets, run_while_matching,
-                                            take_unrun_while_matching)
+from future_od.models.set_criterion import (SetCriterion, build_matcher, device_matching_enabled, pack_targets,
+                                            run_while_matching, take_unrun_while_matching)
 from future_od.native import ops
 from future_od.utils.od_map import prepare_od_map_stuffs
 
@@ -88,11 +88,18 @@ class SpatioTemporalDETR(nn.Module):
         # them) this touches no device tensor: no wait on the previous step's queued backward, so the host
         # queues this forward while the GPU is still draining it.  Without them the boolean indexing below reads
         # the counts back from the device (one sync per sample, as in the reference).
-        anno = data.get("_host_annotations") or data
-        targets = to_detr_targets(H=H, W=W, anno_active=anno["active"], anno_boxes=anno["boxes"],
-                                  anno_classes=anno["classes"])
-        packed = pack_targets(targets, images.device)
-        num_boxes = self._criterion.global_num_boxes(targets, images.device, distributed, lazy=True)
+        if device_matching_enabled(images.device):
+            # targets packed, counted, matched and normalised on the device: the host never sees a count
+            targets = None
+            packed = ops.pack_targets_dev(data["boxes"].float().contiguous(), data["classes"].contiguous(),
+                                          data["active"].contiguous(), H, W)
+            num_boxes = self._criterion.device_num_boxes(packed["count"], distributed)
+        else:
+            anno = data.get("_host_annotations") or data
+            targets = to_detr_targets(H=H, W=W, anno_active=anno["active"], anno_boxes=anno["boxes"],
+                                      anno_classes=anno["classes"])
+            packed = pack_targets(targets, images.device)
+            num_boxes = self._criterion.global_num_boxes(targets, images.device, distributed, lazy=True)
         kwargs = {}
         if data.get("translation") is not None:
             kwargs["imu"] = torch.cat([data[k] for k in self._imu_keys], dim=2)
@@ -119,7 +126,7 @@ class SpatioTemporalDETR(nn.Module):
         return post, None, loss, stats, od_map_stuffs
 
     def loss(self, data, outputs, distributed, targets=None, packed=None, num_boxes=None):
-        if targets is None:
+        if targets is None and packed is None:
             H, W = data["video"].shape[-2:]
             targets = to_detr_targets(H=H, W=W, anno_active=data["active"], anno_boxes=data["boxes"],
                                       anno_classes=data["classes"])

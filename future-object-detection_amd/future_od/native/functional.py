@@ -37,7 +37,7 @@ class _Job:
 
 
 class _Entry:
-    __slots__ = ("params", "vers", "jobs", "value")
+    __slots__ = ("params", "vers", "jobs", "value", "epoch")
 
 
 class _Prepared:
@@ -45,6 +45,14 @@ class _Prepared:
         self._store = {}
         self._tables = {}
         self._chunk = None
+        # Bumped by every writer that changes parameters WITHOUT going through torch (the fused AdamW kernel and a
+        # replayed hipGraph write through raw pointers: `_version` does not move).  An operand is fresh only if both
+        # its parameters' versions and this epoch are the ones it was built at.
+        self.epoch = 0
+
+    def _fresh(self, e):
+        # (operands of frozen parameters -- stem, layer1, every frozen-BN fold -- are not touched by an optimizer)
+        return (e.epoch == self.epoch or e.epoch == -2) and e.vers == tuple(p._version for p in e.params)
 
     def get(self, key, params, build):
         """`build()` -> (value, jobs): allocates the persistent buffers and declares how they are filled."""
@@ -54,15 +62,16 @@ class _Prepared:
             e.params = [p for p in params if p is not None]
             e.value, e.jobs = build()
             e.vers = None
+            e.epoch = -1
             if len(self._store) > 4096:
                 self.clear()
             self._store[key] = e
-        if e.vers != tuple(p._version for p in e.params):
+        if not self._fresh(e):
             self.refresh()
         return e.value
 
     def refresh(self):
-        stale = [e for e in self._store.values() if e.vers != tuple(p._version for p in e.params)]
+        stale = [e for e in self._store.values() if not self._fresh(e)]
         if not stale:
             return
         key = tuple(id(e) for e in stale)
@@ -76,6 +85,7 @@ class _Prepared:
         L.call("fod_multi_permute3", ops.ptr(jobs_dev), ops.ptr(blk_job), ops.ptr(blk_chunk), nblocks, ops.stream())
         for e in stale:
             e.vers = tuple(p._version for p in e.params)
+            e.epoch = self.epoch if any(p.requires_grad for p in e.params) else -2
 
     def _build_tables(self, jobs):
         import ctypes as C
@@ -89,15 +99,20 @@ class _Prepared:
             arr[i] = L.PermuteJob(j.src.data_ptr(), j.dst.data_ptr(), 0 if j.scale is None else j.scale.data_ptr(),
                                   ops._DT[j.src.dtype], ops._DT[j.dst.dtype], d0, d1, d2, j.valid1, j.valid2, j.axis,
                                   j.sstr[0], j.sstr[1], j.sstr[2], j.dstr[0], j.dstr[1])
-            n = d0 * d1 * d2
-            for c in range((n + self._chunk - 1) // self._chunk):
-                bj.append(i)
-                bc.append(c)
+            nchunks = int(L.LIB.fod_multi_permute_tiles(d0, d1, d2, j.sstr[0], j.sstr[1], j.sstr[2]))
+            assert nchunks >= 0, f"permute job {j.dims} too large"
+            bj.extend([i] * nchunks)
+            bc.extend(range(nchunks))
         dev = jobs[0].dst.device
         raw = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy())
         up = lambda t: (t.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else t.to(dev))
         return (up(raw), up(torch.tensor(bj, dtype=torch.int32)), up(torch.tensor(bc, dtype=torch.int32)), len(bj),
                 [(j.src, j.dst, j.scale) for j in jobs])       # keep the operands alive while the table exists
+
+    def mark_stale(self):
+        """Every prepared operand is out of date (parameters were changed behind autograd's back, e.g. by a replayed
+        hipGraph whose AdamW kernel does not bump `_version`): the next request refreshes them all."""
+        self.epoch += 1
 
     def clear(self):
         self._store = {}                 # a NEW dict: per-parameter memos (prep_linear) compare its identity
@@ -190,7 +205,8 @@ def prep_linear(weight, dtype, transposed):
     memo = weight.__dict__.get("_fod_prep")
     if memo is not None:
         e = memo.get((transposed, dtype))
-        if e is not None and e[0] is PREP._store and e[2] == weight.data_ptr() and e[1].vers == (weight._version,):
+        if (e is not None and e[0] is PREP._store and e[2] == weight.data_ptr()
+                and (e[1].epoch == PREP.epoch or e[1].epoch == -2) and e[1].vers == (weight._version,)):
             return e[1].value
     N, K = weight.shape
     v = _VEC[dtype]

@@ -71,6 +71,7 @@ SIGNATURES = {
     "fod_dropout": [_i, _p, _p, _l, C.c_ulonglong, _f, _p],
     "fod_multi_permute3": [_p, _p, _p, _i, _p],
     "fod_multi_permute_chunk": [],
+    "fod_multi_permute_tiles": [_i, _i, _i, _l, _l, _l],
     "fod_nchw_to_nhwc": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _p],
     "fod_u8_nchw_to_nhwc": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _l, _l, _p, _p, _p],
     "fod_permute3_cast": [_i, _i, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _i, _p],
@@ -87,6 +88,8 @@ SIGNATURES = {
     "fod_box_finish_bwd": [_i, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "fod_match_cost": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _p],
     "fod_lap_solve_batch_host": [_p, _i, _i, _i, _p, _p, _i],
+    "fod_lap_solve_batch_dev": [_p, _i, _i, _i, _i, _p, _p, _p, _p],
+    "fod_pack_targets": [_p, _p, _p, _i, _i, _f, _f, _p, _p, _p, _p, _p],
     "fod_host_flag_create": [_p],
     "fod_host_flag_destroy": [_p],
     "fod_host_alloc": [_p, C.c_size_t],
@@ -96,14 +99,14 @@ SIGNATURES = {
     "fod_stream_wait_flag": [_p, C.c_uint32, _p],
     "fod_stream_wait_supported": [_i],
     "fod_match_after_event": [_i, _p, _p, _i, _i, _i, _p, _p, _p, _p, C.c_uint32, _i],
-    "fod_set_loss_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
-    "fod_set_loss_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
+    "fod_set_loss_fwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _f, _p],
+    "fod_set_loss_bwd": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p, _f, _p],
     "fod_od_map": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _f, _p],
     "fod_post_proc": [_p, _p, _p, _p, _i, _i, _f, _f, _p],
     "fod_tracker_cost": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "fod_tracker_extrapolate": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "fod_multi_sqnorm_acc": [_p, _p, _p, _p, _i, _p, _p],
-    "fod_multi_adamw": [_p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p, _f, _p],
+    "fod_multi_adamw": [_p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p, _p, _f, _p],
 }
 EXPORTS = sorted(list(SIGNATURES) + ["fod_last_error", "fod_abi_version", "fod_multi_chunk"])
 

@@ -567,12 +567,21 @@ def lap_solve_batch_host(cost_cpu, n_cols, threads=8):
     return out
 
 
+def _num_boxes_args(num_boxes):
+    """(host float, device scalar or None): a device tensor [1] f32 is read by the kernel when it runs."""
+    if isinstance(num_boxes, torch.Tensor):
+        _chk(num_boxes, "num_boxes", torch.float32); assert num_boxes.numel() == 1
+        return 1.0, num_boxes
+    return float(num_boxes), None
+
+
 def set_loss_fwd(logits, boxes, match, tgt_labels, tgt_boxes, tgt_offset, num_boxes, alpha):
     Lv, B, M, Cc = logits.shape
     _chk(match, "match", torch.int32); assert match.shape == (Lv, B, M)
     out = torch.empty((Lv, 5), dtype=torch.float32, device=logits.device)
+    nb, nb_dev = _num_boxes_args(num_boxes)
     call("fod_set_loss_fwd", ptr(logits), ptr(boxes), ptr(match), ptr(tgt_labels), ptr(tgt_boxes),
-         ptr(tgt_offset), ptr(out), Lv, B, M, Cc, float(num_boxes), alpha, stream())
+         ptr(tgt_offset), ptr(out), Lv, B, M, Cc, nb, ptr(nb_dev), alpha, stream())
     return out
 
 
@@ -580,9 +589,39 @@ def set_loss_bwd(logits, boxes, match, tgt_labels, tgt_boxes, g, num_boxes, alph
     Lv, B, M, Cc = logits.shape
     _chk(g, "g", torch.float32); assert g.shape == (Lv, 3)
     dlogits, dboxes = torch.empty_like(logits), torch.empty_like(boxes)
+    nb, nb_dev = _num_boxes_args(num_boxes)
     call("fod_set_loss_bwd", ptr(logits), ptr(boxes), ptr(match), ptr(tgt_labels), ptr(tgt_boxes), ptr(g),
-         ptr(dlogits), ptr(dboxes), Lv, B, M, Cc, float(num_boxes), alpha, stream())
+         ptr(dlogits), ptr(dboxes), Lv, B, M, Cc, nb, ptr(nb_dev), alpha, stream())
     return dlogits, dboxes
+
+
+def pack_targets_dev(anno_boxes, anno_classes, anno_active, H, W):
+    """Dense device annotations ([B,N,4] f32 xyxy px, [B,N] i64, [B,N] i64) -> the packed targets of the matcher and
+    the set loss, entirely on the device: dict(labels i64 [B*N], boxes f32 [B*N,4] cxcywh in (0,1), offset i32 [B+1],
+    count f32 [1] = total targets, ld = N, device = True)."""
+    _chk(anno_boxes, "anno_boxes", torch.float32); _chk(anno_classes, "anno_classes", torch.int64)
+    _chk(anno_active, "anno_active", torch.int64)
+    B, N = anno_classes.shape
+    assert anno_boxes.shape == (B, N, 4) and anno_active.shape == (B, N)
+    dev = anno_boxes.device
+    labels = torch.empty((B * N,), dtype=torch.int64, device=dev)
+    boxes = torch.empty((B * N, 4), dtype=torch.float32, device=dev)
+    offset = torch.empty((B + 1,), dtype=torch.int32, device=dev)
+    count = torch.empty((1,), dtype=torch.float32, device=dev)
+    call("fod_pack_targets", ptr(anno_boxes), ptr(anno_classes), ptr(anno_active), B, N, 1 / W, 1 / H, ptr(labels),
+         ptr(boxes), ptr(offset), ptr(count), stream())
+    return {"labels": labels, "boxes": boxes, "offset": offset, "count": count, "ld": N, "device": True}
+
+
+def lap_solve_batch_dev(cost, tgt_offset, status):
+    """cost f32 [L,B,M,ld] on the device, tgt_offset i32 [B+1] on the device -> match i32 [L,B,M] (GLOBAL target index
+    or -1), solved on the GPU (bit-identical to lap_solve_batch_host); `status` i32 [1] device, non-zero on failure."""
+    _chk(cost, "cost", torch.float32); _chk(tgt_offset, "tgt_offset", torch.int32); _chk(status, "status", torch.int32)
+    Lv, B, M, ld = cost.shape
+    assert tgt_offset.numel() == B + 1 and status.numel() == 1
+    match = torch.empty((Lv, B, M), dtype=torch.int32, device=cost.device)
+    call("fod_lap_solve_batch_dev", ptr(cost), Lv * B, B, M, ld, ptr(tgt_offset), ptr(match), ptr(status), stream())
+    return match
 
 
 def post_proc(logits, boxes, img_h, img_w):

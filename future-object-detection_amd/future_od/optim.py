@@ -28,6 +28,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self._chunk = L.LIB.fod_multi_chunk()
         self._tables = {}
         self._sq = None
+        self._bias_dev = None        # device-resident bias corrections (captured steps, see future_od/graph.py)
+        self._dev_step = self._dev_betas = None
         self.last_grad_norm = None
 
     def zero_grad(self, set_to_none=True):
@@ -127,8 +129,43 @@ class FusedAdamW(torch.optim.Optimizer):
             plan["gptrs"] = gptrs
         return True
 
+    def enable_device_step(self, device):
+        """Keep the step count and the bias corrections in device memory, advanced by (capturable) device ops inside
+        step(): a captured step must not bake `1 - beta**t` into a kernel argument."""
+        betas = self.param_groups[0]["betas"]
+        self._dev_step = torch.tensor([float(getattr(self, "_step_no", 0))], dtype=torch.float64, device=device)
+        self._dev_betas = torch.tensor(list(betas), dtype=torch.float64, device=device)
+        self._bias_dev = torch.ones(2, dtype=torch.float32, device=device)
+
+    def disable_device_step(self):
+        self._dev_step = self._dev_betas = self._bias_dev = None
+
+    def sync_hyperparams(self):
+        """Write changed learning rates / weight decays into the device table IN PLACE (a captured step reads that
+        table; the scheduler only changes the python-side groups).  Returns True if something changed."""
+        plan = getattr(self, "_plan", None)
+        if plan is None:
+            return False
+        lrs = [(g["lr"], g["weight_decay"]) for g in self.param_groups]
+        if lrs == plan["lrs"]:
+            return False
+        rows = []
+        for grp in self.param_groups:
+            for p in grp["params"]:
+                if p.grad is not None:
+                    rows.append((grp["lr"], grp["weight_decay"]))
+        assert len(rows) == plan["tab"][2].shape[0], "parameter set changed under a captured step"
+        host = torch.tensor(rows, dtype=torch.float32).pin_memory()
+        plan["tab"][2].copy_(host, non_blocking=True)
+        self._keep_lr = host
+        plan["lrs"] = lrs
+        return True
+
     def _launch(self, tab, dev, betas, eps):
         ptrs, numel, lr_wd, bt, bc = tab
+        if getattr(self, "_dev_step", None) is not None:
+            self._dev_step.add_(1.0)
+            self._bias_dev.copy_(1.0 - torch.pow(self._dev_betas, self._dev_step))
         if self._sq is None or self._sq.device != dev:
             self._sq = torch.zeros(1, dtype=torch.float32, device=dev)
         nblocks = bt.numel()
@@ -141,7 +178,11 @@ class FusedAdamW(torch.optim.Optimizer):
         bc1 = 1.0 - betas[0] ** self._step_no
         bc2 = 1.0 - betas[1] ** self._step_no
         L.call("fod_multi_adamw", ptr(ptrs), ptr(numel), ptr(lr_wd), ptr(bt), ptr(bc), nblocks, betas[0], betas[1],
-               eps, bc1, bc2, ptr(sq), self.max_norm, stream())
+               eps, bc1, bc2, ptr(self._bias_dev), ptr(sq), self.max_norm, stream())
+        # the kernel wrote the parameters through raw pointers (their `_version` did not move): every prepared
+        # operand derived from a parameter (compute-dtype / transposed / BN-folded copies) is now out of date
+        from future_od.native import functional as Fn
+        Fn.PREP.mark_stale()
 
     @torch.no_grad()
     def step(self, closure=None):

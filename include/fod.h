@@ -109,6 +109,9 @@ typedef struct fod_permute_job {
 int fod_multi_permute3(const fod_permute_job* jobs, const int* blk_job, const int* blk_chunk, int nblocks,
                        fod_stream_t stream);
 int fod_multi_permute_chunk(void);
+/* Blocks job (d0,d1,d2,s0,s1,s2) takes in fod_multi_permute3 (blk_chunk values 0 .. n-1 of that job); -1 if the
+ * job is too large. */
+int fod_multi_permute_tiles(int d0, int d1, int d2, long s0, long s1, long s2);
 
 typedef struct fod_conv_geom {
   int Nimg, H, W, Cin;   /* input  NHWC */
@@ -267,6 +270,27 @@ int fod_match_cost(const float* logits, const float* boxes, const int64_t* tgt_l
 int fod_lap_solve_batch_host(const float* cost_host, int nprob, int M, int ld_n, const int32_t* n_cols,
                              int32_t* match_out, int threads);
 
+/* DEVICE.  Dense annotations -> the matcher's packed targets (future_od/models/st_detr.py:237-263 `to_detr_targets`
+ * + the concatenation the matcher does): anno_boxes f32 [B,N,4] xyxy pixels, anno_classes / anno_active i64 [B,N];
+ * the rows with active == 1, in ascending order, become labels i64 [<= B*N] and boxes f32 [<= B*N, 4] = cxcywh /
+ * (W,H,W,H) (inv_w = 1/W, inv_h = 1/H as f32); offset i32 [B+1] = first packed row of each sample, count f32 [1] =
+ * total number of targets (the un-clamped `num_boxes` of set_criterion.py:185).  No host involvement: the step
+ * needs no read-back of the annotation counts. */
+int fod_pack_targets(const float* anno_boxes, const int64_t* anno_classes, const int64_t* anno_active, int B, int N,
+                     float inv_w, float inv_h, int64_t* labels, float* boxes, int32_t* offset, float* count,
+                     fod_stream_t stream);
+
+/* DEVICE.  The same assignment problems solved on the GPU, one wavefront per problem, bit-identical to
+ * fod_lap_solve_batch_host (same algorithm, double arithmetic and tie rules; tests/test_heads_gpu.py): cost f32
+ * [nprob][M][ld_n] in device memory, problems ordered (level, sample) with sample = p % B; the valid column count of
+ * a problem is tgt_offset[b+1] - tgt_offset[b], read ON THE DEVICE.  match_out[p*M + m] = GLOBAL target index
+ * (column + tgt_offset[b]) or -1.  *status (one device int, zeroed by the caller) becomes non-zero if a problem has
+ * non-finite costs or is infeasible (the host solver's error cases; that problem's matches are -1).  With it the
+ * reference's `C.cpu()` + scipy step (set_criterion.py:182,204) needs no host round trip, and a training step can
+ * be captured as one hipGraph.  M, ld_n <= 256. */
+int fod_lap_solve_batch_dev(const float* cost, int nprob, int B, int M, int ld_n, const int32_t* tgt_offset,
+                            int32_t* match_out, int32_t* status, fod_stream_t stream);
+
 /* HOST + stream.  The matcher without a host stall (the reference blocks the host on `C.cpu()` inside
  * HungarianMatcher.forward, called from future_od/models/set_criterion.py:182,204): the launching thread queues
  *   cost -> pinned host copy -> event;  fod_stream_wait_flag(flag, ticket);  pinned match -> device copy;  loss ...
@@ -293,19 +317,20 @@ int fod_match_after_event(int device, void* event, const float* cost_host, int n
                           const int32_t* n_cols, const int32_t* col_offset, int32_t* match_out, void* flag,
                           uint32_t ticket, int threads);
 
-/* Set losses (future_od/models/set_criterion.py:36-115) for all L levels at once.
+/* Set losses (future_od/models/set_criterion.py:36-115) for all L levels at once.  `num_boxes_dev` (one device
+ * float, may be NULL) overrides `num_boxes` when given: a captured step reads the normaliser from device memory.
  * match i32 [L,B,M]: matched GLOBAL target index or -1.  out f32 [L,5]:
  *   loss_ce, loss_bbox, loss_giou, cardinality_error, class_error.   (overwritten, not accumulated) */
 int fod_set_loss_fwd(const float* logits, const float* boxes, const int32_t* match,
                      const int64_t* tgt_labels, const float* tgt_boxes, const int32_t* tgt_offset,
-                     float* out, int L, int B, int M, int C, float num_boxes, float alpha,
-                     fod_stream_t stream);
+                     float* out, int L, int B, int M, int C, float num_boxes, const float* num_boxes_dev,
+                     float alpha, fod_stream_t stream);
 /* dlogits/dboxes (f32, same shapes) = sum_k g[l][k] * d loss_k ;  g f32 [L,3] = upstream weights of
  * (loss_ce, loss_bbox, loss_giou) per level. */
 int fod_set_loss_bwd(const float* logits, const float* boxes, const int32_t* match,
                      const int64_t* tgt_labels, const float* tgt_boxes, const float* g, float* dlogits,
-                     float* dboxes, int L, int B, int M, int C, float num_boxes, float alpha,
-                     fod_stream_t stream);
+                     float* dboxes, int L, int B, int M, int C, float num_boxes, const float* num_boxes_dev,
+                     float alpha, fod_stream_t stream);
 
 /* Detection post-processing + AP bookkeeping (st_detr.py:190-234, utils/od_map.py:214-287):
  * scores f32 [B,M,C1] (sigmoid, last class = max), boxes f32 [B,M,4] xyxy pixels, annotations dense
@@ -336,12 +361,14 @@ int fod_post_proc(const float* logits, const float* boxes, float* class_scores, 
  *   ptrs  i64 [T,4] = {param, grad, exp_avg, exp_avg_sq} f32 pointers (same dense layout each),
  *   numel i64 [T], lr_wd f32 [T,2]; block b works on elements [blk_chunk[b]*C, +C) of tensor
  *   blk_tensor[b], C = fod_multi_chunk().  sqnorm: device scalar = sum g^2 (from fod_multi_sqnorm_acc,
- *   which ADDS into it); the update scales g by min(1, max_norm/(sqrt(sqnorm)+1e-6)) when max_norm > 0. */
+ *   which ADDS into it); the update scales g by min(1, max_norm/(sqrt(sqnorm)+1e-6)) when max_norm > 0.
+ *   bias_dev (f32 [2] on the device, may be NULL) overrides the bias corrections bias_c1 / bias_c2: a captured step
+ *   keeps its step count on the device. */
 int fod_multi_sqnorm_acc(const long* ptrs, const long* numel, const int* blk_tensor, const int* blk_chunk,
                          int nblocks, float* out, fod_stream_t stream);
 int fod_multi_adamw(const long* ptrs, const long* numel, const float* lr_wd, const int* blk_tensor,
                     const int* blk_chunk, int nblocks, float beta1, float beta2, float eps, float bias_c1,
-                    float bias_c2, const float* sqnorm, float max_norm, fod_stream_t stream);
+                    float bias_c2, const float* bias_dev, const float* sqnorm, float max_norm, fod_stream_t stream);
 int fod_multi_chunk(void);
 
 #ifdef __cplusplus

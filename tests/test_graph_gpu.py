@@ -1,0 +1,142 @@
+"""The captured step (future_od/graph.py: one hipGraph for zero_grad + forward + device-side matching + loss +
+backward + clip + AdamW) against the eager step: same losses, same parameters, step after step."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _build(dtype, seed=3):
+    from future_od.models.st_detr import SpatioTemporalDETRArgs
+    from future_od.optim import FusedAdamW
+    from oracle import stdetr as O
+    from runs._model import build_model
+    cfg = O.Config(backbone="resnet18", enc_layers=1, dec_layers=2)
+    args = SimpleNamespace(device=DEV, distributed=False, compute_dtype=dtype, backbone="resnet18")
+    detr = SpatioTemporalDETRArgs(num_classes=8, num_queries=128, lr_backbone=1e-4, enc_layers=1, dec_layers=2,
+                                  pretrained_backbone=False)
+    model = build_model(args, detr)
+    model.load_state_dict(O.make_state_dict(cfg, seed))
+    model.eval()                                  # eval-mode math with autograd on (the bench's and BASELINE.md's mode)
+    opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=1e-4, max_norm=0.1)
+    return model, opt
+
+
+def _eager_step(model, opt, data):
+    opt.zero_grad()
+    post, _, loss, stats, od = model(data=data, distributed=False)
+    loss.backward()
+    opt.step()
+    return loss.detach().clone()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_graphed_steps_track_eager_steps(dtype):
+    from future_od.datasets.synthetic import make_batch
+    from future_od.graph import GraphedStep
+    data = make_batch(2, 3, 96, 128, seed=11, max_boxes=9, device=DEV)
+    data2 = make_batch(2, 3, 96, 128, seed=12, max_boxes=20, device=DEV)      # other targets, same shapes: no re-capture
+    m_e, o_e = _build(dtype)
+    m_g, o_g = _build(dtype)
+    step = GraphedStep(m_g, o_g, warmup=2)
+    seq = [data, data, data, data, data2, data, data2]
+    le = [float(_eager_step(m_e, o_e, d)) for d in seq]
+    # first call = 2 warm-up + 1 device-step eager steps + 1 replay: four optimizer steps, all on `data`
+    lg = [None, None, None, float(step(seq[3])[1].detach())]
+    lg += [float(step(d)[1].detach()) for d in seq[4:]]
+    assert step.replays == 4 and len(step._graphs) == 1
+    assert o_g._step_no == o_e._step_no == len(seq)
+    tol = 2e-5 if dtype == "fp32" else 2e-3
+    for i in range(3, len(seq)):
+        assert abs(lg[i] - le[i]) <= tol * max(abs(le[i]), 1.0), (i, lg[i], le[i])
+    # parameters after seven steps: a systematic divergence (a skipped or doubled update, stale operands) would show
+    # as ~lr = 1e-4 per step; what remains is accumulation-order noise of the f32 atomics amplified by Adam's
+    # normalisation on near-zero gradients (a fraction of one lr step)
+    worst, total, count = 0.0, 0.0, 0
+    for (n, pe), (_, pg) in zip(m_e.named_parameters(), m_g.named_parameters()):
+        d = (pe.detach() - pg.detach()).abs()
+        worst = max(worst, float(d.max()))
+        total += float(d.sum())
+        count += d.numel()
+    if dtype == "fp32":
+        assert worst < 3e-5, worst
+    else:
+        # bf16 activations: rounding turns the accumulation-order noise into sign flips of near-zero gradients, so
+        # single elements can drift by a few lr steps; a systematic difference would move EVERY element by ~1e-4
+        assert total / count < 2e-5 and worst < 1.5e-3, (total / count, worst)
+    # an eager forward after replays sees the replayed parameters (prepared operands are refreshed)
+    with torch.no_grad():
+        _, _, l1, _, _ = m_g(data=data, distributed=False)
+        _, _, l2, _, _ = m_e(data=data, distributed=False)
+    assert abs(float(l1) - float(l2)) <= tol * max(abs(float(l2)), 1.0)
+
+
+def test_graph_outputs_are_the_eager_outputs_at_equal_parameters():
+    """One replay against one eager forward/backward from the SAME parameters: the forward has no atomics, so the
+    loss, the detections and the AP bookkeeping must be bit-identical; gradients agree to accumulation-order noise."""
+    from future_od.datasets.synthetic import make_batch
+    from future_od.graph import GraphedStep
+    data = make_batch(2, 3, 96, 128, seed=21, max_boxes=12, device=DEV)
+    m_g, o_g = _build("fp32", seed=4)
+    step = GraphedStep(m_g, o_g, warmup=2)
+    step(data)                                              # capture + first replay
+    snap = {k: v.detach().clone() for k, v in m_g.state_dict().items()}
+    post, loss, stats, od = step(data)                      # replay from `snap`
+    got = (loss.detach().clone(), post["class_scores"].clone(), post["boxes"].clone(), [t.clone() for t in od])
+    grads = {n: p.grad.detach().clone() for n, p in m_g.named_parameters() if p.grad is not None}
+    m_e, o_e = _build("fp32", seed=4)
+    m_e.load_state_dict(snap)
+    o_e.zero_grad()
+    post_e, _, loss_e, _, od_e = m_e(data=data, distributed=False)
+    loss_e.backward()
+    assert torch.equal(got[0], loss_e.detach())
+    assert torch.equal(got[1], post_e["class_scores"]) and torch.equal(got[2], post_e["boxes"])
+    for a, b in zip(got[3], od_e):
+        assert torch.equal(a, b)
+    checked = 0
+    for n, p in m_e.named_parameters():
+        if p.grad is None:
+            continue
+        g = grads[n]
+        denom = float(p.grad.norm()) + 1e-12
+        assert float((g - p.grad).norm()) <= 1e-4 * denom + 1e-9, n
+        checked += 1
+    assert checked > 50
+
+
+def test_prepared_operands_follow_the_optimizer():
+    """The fused AdamW kernel writes parameters through raw pointers (their `_version` does not move): the compute-
+    dtype / transposed copies the GEMM kernels read must still be refreshed before the next forward.  (Round 1 shipped
+    without this: every GEMM weight stayed at its initial value while only biases / norms trained.)"""
+    from future_od.datasets.synthetic import make_batch
+    from future_od.native import functional as Fn
+    data = make_batch(2, 3, 96, 128, seed=11, max_boxes=9, device=DEV)
+    m, o = _build("bf16")
+    names = ["_model.detector.class_embed.weight", "_model.separate_encoder.transformer.layers.0.self_attn.mlp.0.weight",
+             "_model.detector.decoder.layers.1.feedforward.3.weight"]
+    params = dict(m.named_parameters())
+    start = {n: params[n].detach().clone() for n in names}
+    for _ in range(3):
+        _eager_step(m, o, data)
+    with torch.no_grad():
+        m(data=data, distributed=False)                       # the forward that must see the updated weights
+    for n in names:
+        p = params[n]
+        assert float((p.detach() - start[n]).abs().max()) > 1e-4, n           # it did train
+        w = Fn.prep_linear(p, torch.bfloat16, False)
+        assert torch.equal(w[:p.shape[0]], p.detach().to(torch.bfloat16)), n
+        wt = Fn.prep_linear(p, torch.bfloat16, True)
+        assert torch.equal(wt[:, :p.shape[0]], p.detach().to(torch.bfloat16).t()), n
+    # and a conv weight of the trainable part of the backbone, with its frozen-BN scale folded in
+    blk = m._model.separate_encoder.backbone.body.layer4[0]
+    scale, _ = blk.bn2.scale_shift()
+    w = Fn.prep_conv(blk.conv2.weight, torch.bfloat16, scale, False)
+    want = (blk.conv2.weight.detach() * scale.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(w.shape).to(torch.bfloat16)
+    assert torch.equal(w, want)
+    wt = Fn.prep_conv(blk.conv2.weight, torch.bfloat16, scale, True)                   # [Cin][taps][Cout]
+    want_t = (blk.conv2.weight.detach() * scale.view(-1, 1, 1, 1)).permute(1, 2, 3, 0).reshape(wt.shape).to(torch.bfloat16)
+    assert torch.equal(wt, want_t)

@@ -254,3 +254,88 @@ def test_async_matcher_failure_releases_the_stream_and_raises_late(monkeypatch):
     logits2, boxes2, targets2 = _criterion_inputs(seed=6)      # and the next submission works
     out2 = crit({"_stacked": (logits2, boxes2)}, targets2, distributed=False)
     assert torch.isfinite(out2.table[:, :3]).all()
+
+
+@pytest.mark.parametrize("case", [(128, [23, 7], 40), (128, [0, 1], 8), (128, [128, 127], 128), (128, [200, 129], 256),
+                                  (16, [40, 3], 64), (37, [1, 36], 48), (128, [256, 5], 256), (8, [8, 8], 8)])
+def test_device_lap_is_bit_identical_to_the_host_solver_and_scipy(case):
+    """fod_lap_solve_batch_dev (one wavefront per problem, target counts read on the device) against
+    fod_lap_solve_batch_host (scipy's algorithm) and scipy itself: identical assignments, exact ties included."""
+    from scipy.optimize import linear_sum_assignment
+    M, sizes, ld = case
+    B, Lv = len(sizes), 3
+    rng = np.random.default_rng(M * 7919 + sum(sizes) * 31 + ld)
+    cost = torch.from_numpy(rng.standard_normal((Lv, B, M, ld)).astype(np.float32) * 3)
+    cost[0, :, :, 1] = cost[0, :, :, 0]                 # a duplicated column: exact ties
+    cost[1] = torch.round(cost[1])                       # small-integer costs: many ties
+    cost[2, :, 1::2] = cost[2, :, 0::2][:, : cost[2, :, 1::2].shape[1]]   # duplicated rows
+    off = [0]
+    for s in sizes:
+        off.append(off[-1] + s)
+    off_dev = torch.tensor(off, dtype=torch.int32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    got = ops.lap_solve_batch_dev(cost.to(DEV), off_dev, status).cpu()
+    assert int(status.item()) == 0
+    host = ops.lap_solve_batch_host(cost.view(Lv * B, M, ld).contiguous(), sizes * Lv, threads=2).view(Lv, B, M)
+    for lv in range(Lv):
+        for b in range(B):
+            want = torch.where(host[lv, b] >= 0, host[lv, b] + off[b], host[lv, b])
+            assert torch.equal(got[lv, b], want), (lv, b, sizes[b])
+            n = sizes[b]
+            if n:
+                i, j = linear_sum_assignment(cost[lv, b, :, :n].numpy())
+                mine = got[lv, b]
+                assert np.array_equal(np.nonzero(mine.numpy() >= 0)[0], i)
+                assert np.array_equal(mine[mine >= 0].numpy() - off[b], j)
+
+
+def test_device_lap_flags_non_finite_costs():
+    cost = torch.zeros(1, 1, 16, 8)
+    cost[0, 0, 3, 2] = float("nan")
+    off = torch.tensor([0, 5], dtype=torch.int32, device=DEV)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    got = ops.lap_solve_batch_dev(cost.to(DEV), off, status)
+    assert int(status.item()) != 0 and bool((got == -1).all())
+
+
+def test_device_target_path_equals_host_matcher(monkeypatch):
+    """Targets packed on the device (fod_pack_targets), matched by the device solver and normalised by a device-side
+    `num_boxes` must give exactly the loss table and gradients of the host path (to_detr_targets + pack_targets +
+    host solver + host num_boxes)."""
+    from future_od.models.set_criterion import SetCriterion, build_matcher
+    from future_od.models.st_detr import SpatioTemporalDETRArgs, to_detr_targets
+    monkeypatch.setenv("FOD_ASYNC_MATCH", "0")
+    crit = SetCriterion(8, build_matcher(SpatioTemporalDETRArgs(num_classes=8)), {}, 0.25,
+                        ["labels", "boxes", "cardinality"], "per level")
+    H, W, N = 96, 160, 32
+    for seed, counts in ((1, [5, 0, 17]), (2, [32, 1, 9]), (3, [0, 0, 0])):
+        logits, boxes, _ = _criterion_inputs(seed=seed)
+        B = logits.shape[1]
+        g = torch.Generator().manual_seed(seed)
+        ab = torch.zeros(B, N, 4)
+        x0 = torch.rand(B, N, generator=g) * (W - 20)
+        y0 = torch.rand(B, N, generator=g) * (H - 20)
+        ab[..., 0], ab[..., 1] = x0, y0
+        ab[..., 2] = x0 + 4 + torch.rand(B, N, generator=g) * 15
+        ab[..., 3] = y0 + 4 + torch.rand(B, N, generator=g) * 15
+        cls = torch.randint(0, 8, (B, N), generator=g)
+        act = torch.zeros(B, N, dtype=torch.int64)
+        for b in range(B):
+            act[b, torch.randperm(N, generator=g)[:counts[b]]] = 1          # scattered active rows
+        targets = to_detr_targets(H=H, W=W, anno_active=act, anno_boxes=ab, anno_classes=cls)
+        out_h = crit({"_stacked": (logits, boxes)}, targets, distributed=False)
+        out_h.table[:, :3].sum().backward()
+        ref = (out_h.table.detach().cpu(), logits.grad.clone().cpu(), boxes.grad.clone().cpu())
+        logits.grad = None
+        boxes.grad = None
+        packed = ops.pack_targets_dev(ab.to(DEV), cls.to(DEV), act.to(DEV), H, W)
+        tot = sum(counts)
+        assert packed["offset"].cpu().tolist() == [0] + list(np.cumsum(counts)) and float(packed["count"].item()) == tot
+        if tot:
+            assert torch.equal(packed["labels"][:tot].cpu(), torch.cat([t["labels"] for t in targets]))
+            assert torch.equal(packed["boxes"][:tot].cpu(), torch.cat([t["boxes"] for t in targets]))
+        nb = crit.device_num_boxes(packed["count"], distributed=False)
+        out_d = crit({"_stacked": (logits, boxes)}, None, distributed=False, packed=packed, num_boxes=nb)
+        out_d.table[:, :3].sum().backward()
+        assert torch.equal(out_d.table.detach().cpu(), ref[0]), seed
+        assert torch.equal(logits.grad.cpu(), ref[1]) and torch.equal(boxes.grad.cpu(), ref[2]), seed
