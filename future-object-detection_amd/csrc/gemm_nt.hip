@@ -28,48 +28,11 @@
 #include <type_traits>
 
 #include "common.h"
+#include "gemm_nt.h"
 
 namespace {
 
-enum { MODE_DENSE = 0, MODE_CONV = 1, MODE_DGRAD = 2, MODE_DGRAD_S2 = 3, MODE_STEM = 4 };
-
-struct NtParams {
-  const void* A;
-  const void* B;
-  void* C;
-  long lda, ldb, ldc;
-  int M, N, K;
-  int a_row_mod;
-  const float* scale;
-  const float* shift;
-  const void* res;
-  long ldr;
-  int res_row_mod;
-  const void* mask;
-  long ldmask;
-  int relu;
-  int c_is_f32;
-  int vec_epi;   // host-checked: N, ldc, ldr, ldmask multiples of 4 and 16-byte aligned bases
-  unsigned a_bytes, b_bytes;   // extents of A and B for the buffer descriptors (< 4 GiB, host-checked)
-  int gx, gy;                  // tile grid (n-tiles, m-tiles); launched as a 1-D grid of gx * roundup(gy, 8)
-  // grouped form (short-launch kernel only): A's k range and C's columns are cut into segments that live
-  // a_seg_stride / c_seg_stride elements apart -- P same-shaped tensors side by side without a concatenation
-  int a_seg_len, c_seg_cols;   // elements per segment; 0 = not segmented
-  long a_seg_stride, c_seg_stride;
-  // MODE_DGRAD_S2: class geometry.  m indexes (img, hi', wi') of the class grid Hd x Wd; hi = 2*hi' + par_h
-  int par_h, par_w, out_H, out_W;   // parity of the class, full input dims (rows of C / residual / mask)
-  int r_first, s_first, n_s;        // first valid tap per axis, taps per row of the compact list
-  int off_h, off_w;                 // source row = hi' + off_h - ri
-  // gather geometry
-  int Hs, Ws, Cs;   // source image dims / channels
-  int Hd, Wd;       // m-domain dims
-  int kh, kw, stride, pad;
-};
-
-constexpr int BM = 128;
-constexpr int ROW_BYTES = 128;   // bytes of k per tile row
-
-FOD_DEVINL int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4); }
+using namespace fodnt;
 
 // UTAP (conv modes): the source channel count is a multiple of BK, so a k-tile lies inside ONE tap and the tap
 // walk (r, s, c) is block-uniform: it lives in SGPRs and costs scalar instructions; a row's gather offset is
@@ -716,7 +679,7 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const NtParams p) {
 
 // The short-launch kernel is used when its 64 x 64 tiles fit the chip in one wave of blocks.
 bool use_small_nt(int dtype, const NtParams& p) {
-  static const char* env = getenv("FOD_NT_SMALL");
+  const char* env = getenv("FOD_NT_SMALL");
   if (env && env[0] == '0') return false;
   if (dtype != FOD_BF16 || !p.vec_epi) return false;
   const long blocks = (long)ceil_div(p.M, 64) * ceil_div(p.N, 64);
@@ -729,6 +692,9 @@ bool use_small_nt(int dtype, const NtParams& p) {
 
 template <typename T, int MODE>
 int launch_nt(const NtParams& p, hipStream_t stream) {
+  if constexpr (std::is_same<T, __bf16>::value) {
+    if (big_applies(MODE, p)) return launch_big_mode(MODE, p, stream);
+  }
   NtParams q = p;
   q.gy = ceil_div(p.M, BM);
   // 64-wide tiles also when 128-wide ones would leave CUs with a single block (or none): a block's prologue and

@@ -430,3 +430,65 @@ def test_group_linear_kernels(shape):
     ops.group_linear_wgrad(g.to(DEV), x.to(DEV), dw, db, zeroed=True)
     check(dw, gcat.t() @ x.float(), dtype, math.sqrt(rows), f"group wgrad {shape}")
     check(db, gcat.sum(0), torch.float32, math.sqrt(rows), f"group bias grad {shape}")
+
+
+# The 256 x 128 LDS-DMA kernel (gemm_nt_big.hip) normally takes only large problems; FOD_NT_BIG=2 routes every legal
+# problem through it so that ragged tiles, every conv mode and every epilogue variant are checked on small shapes.
+BIG_CONV_CASES = [  # (Nimg, H, W, Cin, Cout, k, stride, pad)
+    (2, 15, 20, 64, 64, 3, 1, 1),
+    (1, 15, 21, 64, 128, 3, 2, 1),
+    (3, 9, 11, 128, 72, 1, 1, 0),
+    (2, 9, 12, 256, 512, 1, 2, 0),
+    (1, 33, 47, 128, 136, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", BIG_CONV_CASES)
+def test_big_tile_kernel_conv_modes(monkeypatch, case):
+    monkeypatch.setenv("FOD_NT_BIG", "2")
+    dtype = torch.bfloat16
+    n, h, w_, cin, cout, k, stride, pad = case
+    x = rnd((n, h, w_, cin), dtype, 1)
+    w = rnd((cout, k, k, cin), dtype, 2, scale=1.0 / math.sqrt(k * k * cin))
+    scale, shift = torch.rand(cout) + 0.5, torch.randn(cout) * 0.1
+    geom = ops.conv_geom(x.shape, cout, k, stride, pad)
+    x32 = x.float().requires_grad_(True)
+    w32 = w.float().requires_grad_(True)
+    y_lin = _conv_ref(x32, w32, stride, pad)
+    res = rnd((n, geom.Ho, geom.Wo, cout), dtype, 3)
+    y_ref = (y_lin * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res.float().permute(0, 3, 1, 2)).clamp(min=0)
+    y = ops.conv2d_fwd(x.to(DEV), w.to(DEV), geom, scale=scale.to(DEV), shift=shift.to(DEV), residual=res.to(DEV),
+                       relu=True)
+    check(y, y_ref.permute(0, 2, 3, 1), dtype, 2, f"big conv fwd {case}")
+    monkeypatch.setenv("FOD_NT_BIG", "0")
+    y_small = ops.conv2d_fwd(x.to(DEV), w.to(DEV), geom, scale=scale.to(DEV), shift=shift.to(DEV),
+                             residual=res.to(DEV), relu=True)
+    monkeypatch.setenv("FOD_NT_BIG", "2")
+    assert torch.equal(y, y_small), "both tilings accumulate k in the same order: identical results expected"
+    dy = rnd((n, geom.Ho, geom.Wo, cout), dtype, 4)
+    y_lin.backward(dy.float().permute(0, 3, 1, 2))
+    w_t = w.permute(3, 1, 2, 0).contiguous()
+    dres = rnd((n, h, w_, cin), dtype, 5)
+    mask = rnd((n, h, w_, cin), dtype, 6)
+    dx = ops.conv2d_dgrad(dy.to(DEV), w_t.to(DEV), geom, residual=dres.to(DEV), relu_mask=mask.to(DEV))
+    dx_ref = torch.where(mask.float() > 0, x32.grad + dres.float(), torch.zeros(()))
+    check(dx, dx_ref, dtype, 4, f"big conv dgrad {case}")
+
+
+@pytest.mark.parametrize("mnk", [(300, 128, 128), (1000, 40, 72), (257, 132, 256), (513, 64, 96), (4097, 8, 64)])
+def test_big_tile_kernel_dense(monkeypatch, mnk):
+    monkeypatch.setenv("FOD_NT_BIG", "2")
+    monkeypatch.setenv("FOD_NT_SMALL", "0")
+    dtype = torch.bfloat16
+    M, N, K = mnk
+    a, b = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2)
+    shift = torch.randn(N)
+    res = rnd((50, N), dtype, 3)
+    mask = rnd((M, N), dtype, 4)
+    acc = (a.float() @ b.float().t()) + shift + res.float().repeat(M // 50 + 1, 1)[:M]
+    ref = torch.where(mask.float() > 0, acc.clamp(min=0), torch.zeros(()))
+    out = ops.gemm_nt(a.to(DEV), b.to(DEV), shift=shift.to(DEV), residual=res.to(DEV), residual_row_mod=50, relu=True,
+                      relu_mask=mask.to(DEV))
+    check(out, ref, dtype, math.sqrt(K), f"big dense {mnk}")
+    out32 = ops.gemm_nt(a.to(DEV), b.to(DEV), shift=shift.to(DEV), out_f32=True)
+    check(out32, a.float() @ b.float().t() + shift, dtype, math.sqrt(K), f"big dense f32 out {mnk}")
