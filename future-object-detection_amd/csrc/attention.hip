@@ -390,6 +390,172 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 forward for long query sequences with BLOCK-SHARED K / V tiles and a softmax that leaves the vector unit
+// little to do.  attn_fwd_kernel above is bound by the vector unit at head dim 32 (per 32 x 32 score tile 4 MFMAs
+// = 128 cycles against ~330 cycles of exp / fma / max / add / convert issue), and every wave streams all of K and V
+// from L2 itself (the encoder shape re-reads them 46 times per (frame, head)).  Here, per block of 8 waves = 256 queries:
+//   * K / V tiles of 64 keys are staged ONCE per block into double-buffered LDS slabs (register-staged cooperative
+//     copy, one barrier per tile, next tile's global loads in flight during the current tile's arithmetic); K
+//     fragments are ds_read_b128 of the XOR-swizzled [32][64 B] slabs, V^T fragments ds_read_b64_tr_b16 of the same
+//     image -- the tile is fetched from L2 once instead of eight times;
+//   * the queries are pre-multiplied by scale * log2(e) and the running maximum enters the score MFMA as its
+//     ACCUMULATOR INPUT (C = -m, per lane = per query): the MFMA result is already score2 - m, the argument of
+//     v_exp_f32 -- no multiply, no subtract;
+//   * the running maximum is deferred: the rescale of O / l (and the re-bias of the tile) happens only when a tile's
+//     maximum exceeds the running one by more than 2^6 (first tile always); probabilities then lie in [0, 64];
+//   * the row sums come out of the matrix pipe: one extra MFMA per k-step with an A operand whose row 0 is ones
+//     accumulates l = sum_k P[k, q] (of the same bf16-rounded P that multiplies V) -- no 16 adds + cross-half
+//     shuffle per tile on the vector pipe.
+// Per 64 keys and wave: 32 v_exp_f32 + 16 v_max3 + 16 v_cvt_pk on the vector pipe (~420 issue cycles) against 12
+// MFMAs (384 cycles): the two pipes are balanced instead of 3 : 1.
+template <int PARTS, int NW>
+__global__ __launch_bounds__(NW * 64, PARTS == 1 ? 4 : 3) void attn_fwd_lds_kernel(const AttnParams p) {
+  typedef __bf16 T;
+  constexpr float THR = 6.f;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int q0 = (blockIdx.x * NW + wave) * 32;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const bool active = q0 < p.Tq;                      // a trailing wave has no queries but still helps staging
+  const int q = min(q0 + fr, p.Tq - 1);
+  __shared__ __attribute__((aligned(16))) unsigned char tiles[2][PARTS + 1][2][2048];
+
+  const float c = p.scale * LOG2E;
+  const T* Qp[2] = {reinterpret_cast<const T*>(p.q1), reinterpret_cast<const T*>(p.q2)};
+  Frag<T> fq[PARTS][2];
+#pragma unroll
+  for (int pt = 0; pt < PARTS; ++pt)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      Frag<T> f;
+      frag_load_contig(f, Qp[pt] + (long)b * p.q_bs + (long)q * p.q_ts + h * 32 + 16 * s + 8 * fh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) fq[pt][s].v[j] = (T)((float)f.v[j] * c);
+    }
+  Frag<T> fones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) fones.v[j] = (T)(fr == 0 ? 1.f : 0.f);
+
+  // ---- staging: a tile is 256 16-byte chunks of K1, 256 of V (and 256 of K2).  Chunk cid = row * 4 + chunk.  With 4
+  // waves every thread copies chunk `tid` of each operand; with 8 waves threads 0..255 copy K1 (and K2), threads
+  // 256..511 copy V.  Every load is UNCONDITIONAL (roles are picked by pointer selection before the loop): a branch
+  // around a global load makes hipcc wait for it at the join, which would expose the prefetch's latency every tile.
+  const int cid = tid & 255;
+  const int srow = cid >> 2;
+  const unsigned co = (unsigned)(cid & 3) * 16u;
+  const unsigned char* kb1 = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(p.k1) + (long)b * p.k_bs + h * 32) + co;
+  const unsigned char* vb = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(p.v) + (long)b * p.v_bs + h * 32) + co;
+  const unsigned char* kb2 = PARTS == 2 ? reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(p.k2) + (long)b * p.k2_bs + h * 32) + co : kb1;
+  const bool v_role = NW == 8 && tid >= 256;
+  const unsigned char* srcA = v_role ? vb : kb1;                 // NW == 8: K1 or V by role; NW == 4: K1
+  const unsigned tsA = v_role ? (unsigned)p.v_ts * 2u : (unsigned)p.k_ts * 2u;
+  const unsigned tsV = (unsigned)p.v_ts * 2u, ts2 = (unsigned)(PARTS == 2 ? p.k2_ts : p.k_ts) * 2u;
+  const int dst_off = (srow >> 5) * 2048 + slab_at(srow & 31, cid & 3);
+  unsigned char* dstA0 = &tiles[0][v_role ? PARTS : 0][0][0] + dst_off;
+  constexpr int BUF_BYTES = (PARTS + 1) * 2 * 2048;
+  uint4 preA, preV = make_uint4(0, 0, 0, 0), pre2 = make_uint4(0, 0, 0, 0);
+  auto request = [&](int kt) {
+    const unsigned row = (unsigned)min(kt * 64 + srow, p.S - 1);          // rows past S: finite duplicates, masked below
+    preA = *reinterpret_cast<const uint4*>(srcA + (size_t)row * tsA);
+    if (NW == 4) preV = *reinterpret_cast<const uint4*>(vb + (size_t)row * tsV);
+    if (PARTS == 2) pre2 = *reinterpret_cast<const uint4*>(kb2 + (size_t)row * ts2);
+  };
+  auto commit = [&](int buf) {
+    *reinterpret_cast<uint4*>(dstA0 + buf * BUF_BYTES) = preA;
+    if (NW == 4) *reinterpret_cast<uint4*>(&tiles[buf][PARTS][0][0] + dst_off) = preV;
+    if (PARTS == 2 && !v_role) *reinterpret_cast<uint4*>(&tiles[buf][1][0][0] + dst_off) = pre2;
+  };
+
+  float negm = 0.f;                        // minus the running maximum (log2 units) the accumulators are biased by
+  f32x16 NEGM, oacc, lacc;
+  zero_acc<T>(NEGM);
+  zero_acc<T>(oacc);
+  zero_acc<T>(lacc);
+
+  const int nkt = (p.S + 63) >> 6;
+  request(0);
+  commit(0);
+  if (nkt > 1) request(1);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (active) {
+      const int k0 = kt * 64;
+      f32x16 sacc[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        sacc[t] = NEGM;
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            Frag<T> fk;
+            const uint4 v = *reinterpret_cast<const uint4*>(&tiles[buf][pt][t][0] + slab_at(fr, 2 * s + fh));
+            __builtin_memcpy(&fk, &v, 16);
+            mma16(fk, fq[pt][s], sacc[t]);
+          }
+      }
+      if (k0 + 64 > p.S) {                         // last tile only: keys past S
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (k0 + 32 * t + acc_row(r, lane) >= p.S) sacc[t][r] = -INFINITY;
+      }
+      float mxa[4];                                 // four independent v_max3 chains (a single one is 17 deep)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) mxa[u] = fmaxf(sacc[0][u], sacc[1][u]);
+#pragma unroll
+      for (int r = 4; r < 16; ++r) mxa[r & 3] = fmaxf(fmaxf(mxa[r & 3], sacc[0][r]), sacc[1][r]);
+      float mx = fmaxf(fmaxf(mxa[0], mxa[1]), fmaxf(mxa[2], mxa[3]));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (kt == 0 || __any(mx > THR)) {
+        // raise the running maximum of the lanes that need it (all of them on the first tile): everything that is
+        // biased by the old maximum -- O, l, the bias itself and this tile's scores -- moves by the same amount
+        const float d = kt == 0 ? mx : fmaxf(mx, 0.f);
+        const float alpha = ex2(-d);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+        lacc[0] *= alpha;
+        negm -= d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) NEGM[r] = negm;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[t][r] -= d;
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[t][r] = ex2(sacc[t][r]);
+      TransTile<T> tv;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        tv.adopt(&tiles[buf][PARTS][t][0]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          Frag<T> fp, fv;
+          frag_from_acc(fp, sacc[t], s);
+          tv.frag(fv, s, lane);
+          mma16(fv, fp, oacc);
+          mma16(fones, fp, lacc);                   // row 0 of lacc: l[q] += sum of this k-step's probabilities
+        }
+      }
+    }
+    if (kt + 1 < nkt) commit(buf ^ 1);              // tile kt + 1 (requested one trip ago) into the idle buffer
+    if (kt + 2 < nkt) request(kt + 2);
+    __syncthreads();
+  }
+  if (active && q0 + fr < p.Tq) {
+    const float l = __shfl(lacc[0], fr);            // row 0 of the l tile lives in register 0 of lanes 0..31
+    T* op = reinterpret_cast<T*>(p.o) + (long)b * p.o_bs + (long)q * p.o_ts + h * 32;
+    store_acc_t<T>(op, oacc, fh, 1.f / l);
+    if (fh == 0) p.lse2[((long)b * p.H + h) * p.Tq + q] = log2f(l) - negm;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // dq pass: wave owns 32 queries.  Also writes delta[q] = sum_d dO[q,d] * O[q,d].
 template <typename T, int PARTS, bool SPLIT, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
@@ -424,6 +590,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   if (fh == 0 && q0 + fr < p.Tq && (!SPLIT || wave == 0)) p.delta[sidx] = dl;
 
   const float c = p.scale * LOG2E;
+  // bf16 without dropout: the row constants ride in the MFMAs' accumulator inputs.  With the queries pre-multiplied
+  // by scale * log2(e) and C = -lse2 (per lane = per query) the score MFMA returns the argument of v_exp_f32; with
+  // C = -delta the dP MFMA returns dP - delta; `scale` is applied once to the finished dQ.  Per score element the
+  // vector pipe is left with one exp, one multiply and the bf16 convert (was fma + exp + sub + mul + mul + convert).
+  constexpr bool BIAS = sizeof(T) == 2 && !DROP;
+  f32x16 NEGL, NEGD;
+  if constexpr (BIAS) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      NEGL[r] = -lse2;
+      NEGD[r] = -dl;
+    }
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fq[pt][s].v[j] = (T)(to_f32(fq[pt][s].v[j]) * c);
+  }
   const unsigned bh_seed = p.drop_seed_lo + (unsigned)(b * p.H + h) * 0x9E3779B9u;
   f32x16 dq[PARTS];
 #pragma unroll
@@ -475,19 +660,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
     }
     request();                                 // past the end: clamped re-reads of the last row, unused
     f32x16 sacc, dpacc;
-    zero_acc<T>(sacc);
-    zero_acc<T>(dpacc);
+    if constexpr (BIAS) {
+      sacc = NEGL;
+      dpacc = NEGD;
+    } else {
+      zero_acc<T>(sacc);
+      zero_acc<T>(dpacc);
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
       for (int pt = 0; pt < PARTS; ++pt) mma16(fk[pt][s], fq[pt][s], sacc);
       mma16(fv[s], fdo[s], dpacc);          // dP^T[k, q] = sum_d V[k,d] dO[q,d]
     }
+    if constexpr (BIAS) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float pr = ex2(fmaf(sacc[r], c, -lse2));
-      const float dp = DROP ? dpacc[r] * drop_gain(p, bh_seed, q0 + fr, k0 + acc_row(r, lane)) : dpacc[r];
-      sacc[r] = pr * (dp - dl) * p.scale;            // dS^T
+      for (int r = 0; r < 16; ++r) sacc[r] = ex2(sacc[r]) * dpacc[r];          // dS^T / scale
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pr = ex2(fmaf(sacc[r], c, -lse2));
+        const float dp = DROP ? dpacc[r] * drop_gain(p, bh_seed, q0 + fr, k0 + acc_row(r, lane)) : dpacc[r];
+        sacc[r] = pr * (dp - dl) * p.scale;            // dS^T
+      }
     }
     if (k0 + 32 > p.S) {                             // last tile only: keys past S (clamped duplicates) add nothing
 #pragma unroll
@@ -533,11 +728,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
                      s_dq[2][pt][acc_row(r, lane)][fr];
   }
   if (q0 + fr < p.Tq) {
+    const float fin = BIAS ? p.scale : 1.f;
     T* d1 = reinterpret_cast<T*>(p.dq1) + (long)b * p.q_bs + (long)q * p.q_ts + h * 32;
-    store_acc_t<T>(d1, dq[0], fh, 1.f);
+    store_acc_t<T>(d1, dq[0], fh, fin);
     if (PARTS == 2) {
       T* d2 = reinterpret_cast<T*>(p.dq2) + (long)b * p.q_bs + (long)q * p.q_ts + h * 32;
-      store_acc_t<T>(d2, dq[PARTS - 1], fh, 1.f);
+      store_acc_t<T>(d2, dq[PARTS - 1], fh, fin);
     }
   }
 }
@@ -668,6 +864,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_pf_kernel(const AttnParams p
       frag_load_contig(fk[pt][s], Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)key * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
   }
   const float c = p.scale * LOG2E;
+  // without dropout the row constants ride in the accumulator inputs (see attn_bwd_dq_kernel): this wave's 32 keys are
+  // pre-multiplied by scale * log2(e) ONCE, -lse and -delta (negated when they are staged through LDS) initialise the
+  // S and dP accumulators, `scale` is applied to the finished dK
+  constexpr bool BIAS = !DROP;
+  if constexpr (BIAS) {
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fk[pt][s].v[j] = (T)((float)fk[pt][s].v[j] * c);
+  }
   const unsigned bh_seed = p.drop_seed_lo + (unsigned)(b * p.H + h) * 0x9E3779B9u;
   f32x16 dk[PARTS], dv;
   zero_acc<T>(dv);
@@ -716,29 +924,51 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_pf_kernel(const AttnParams p
 #pragma unroll
       for (int pt = 0; pt < PARTS; ++pt) *reinterpret_cast<Frag<T>*>(slab_q[wave][pt] + slab_off[s]) = cur.q[pt][s];
     }
-    stat[wave][fh][fr] = cur.st;
+    stat[wave][fh][fr] = BIAS ? -cur.st : cur.st;
     f32x16 sacc, dpacc;
-    zero_acc<T>(sacc);
-    zero_acc<T>(dpacc);
+    if constexpr (BIAS) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private LDS: the writes above are visible to the reads
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(&stat[wave][0][8 * g + 4 * fh]);
+        const f32x4 de = *reinterpret_cast<const f32x4*>(&stat[wave][1][8 * g + 4 * fh]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sacc[4 * g + e] = ls[e];                          // -lse2 of query row 8 g + 4 fh + e
+          dpacc[4 * g + e] = de[e];                         // -delta
+        }
+      }
+    } else {
+      zero_acc<T>(sacc);
+      zero_acc<T>(dpacc);
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
       for (int pt = 0; pt < PARTS; ++pt) mma16(cur.q[pt][s], fk[pt][s], sacc);      // S[q, key]
       mma16(cur.d[s], fv[s], dpacc);                                                // dP[q, key]
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private LDS: the writes above are visible to the reads
+    if constexpr (BIAS) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 ls = *reinterpret_cast<const f32x4*>(&stat[wave][0][8 * g + 4 * fh]);
-      const f32x4 de = *reinterpret_cast<const f32x4*>(&stat[wave][1][8 * g + 4 * fh]);
+      for (int r = 0; r < 16; ++r) {
+        sacc[r] = ex2(sacc[r]);                              // P
+        dpacc[r] *= sacc[r];                                 // dS / scale
+      }
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private LDS: the writes above are visible to the reads
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * g + e;
-        const int qq = q0 + 8 * g + 4 * fh + e;
-        const float pr = ex2(fmaf(sacc[r], c, -ls[e]));
-        const float gain = DROP ? drop_gain(p, bh_seed, qq, k0 + fr) : 1.f;
-        dpacc[r] = pr * (dpacc[r] * gain - de[e]) * p.scale;   // dS
-        sacc[r] = pr * gain;                                    // P after dropout (for dV)
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(&stat[wave][0][8 * g + 4 * fh]);
+        const f32x4 de = *reinterpret_cast<const f32x4*>(&stat[wave][1][8 * g + 4 * fh]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const int qq = q0 + 8 * g + 4 * fh + e;
+          const float pr = ex2(fmaf(sacc[r], c, -ls[e]));
+          const float gain = DROP ? drop_gain(p, bh_seed, qq, k0 + fr) : 1.f;
+          dpacc[r] = pr * (dpacc[r] * gain - de[e]) * p.scale;   // dS
+          sacc[r] = pr * gain;                                    // P after dropout (for dV)
+        }
       }
     }
     if (q0 + 32 > p.Tq) {                        // last tile only: queries past Tq (clamped duplicates) add nothing
@@ -766,11 +996,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_pf_kernel(const AttnParams p
   if (k0 + fr < p.S) {
     T* o = reinterpret_cast<T*>(p.dv) + (long)b * p.v_bs + (long)key * p.v_ts + h * 32;
     store_acc_t<T>(o, dv, fh, 1.f);
+    const float fin = BIAS ? p.scale : 1.f;
     T* d1 = reinterpret_cast<T*>(p.dk1) + (long)b * p.k_bs + (long)key * p.k_ts + h * 32;
-    store_acc_t<T>(d1, dk[0], fh, 1.f);
+    store_acc_t<T>(d1, dk[0], fh, fin);
     if (PARTS == 2) {
       T* d2 = reinterpret_cast<T*>(p.dk2) + (long)b * p.dk2_bs + (long)key * p.dk2_ts + h * 32;
-      store_acc_t<T>(d2, dk[PARTS - 1], fh, 1.f);
+      store_acc_t<T>(d2, dk[PARTS - 1], fh, fin);
     }
   }
 }
@@ -781,7 +1012,13 @@ int launch_all(int which, const AttnParams& p, hipStream_t stream) {
   // few queries: spend the block's four waves on the key dimension instead (see attn_fwd_kernel)
   const bool split = p.Tq <= 512 && p.S >= 128;
   if (which == 0) {
-    if (split)
+    static const char* env_lds = getenv("FOD_ATTN_LDS");
+    if (sizeof(T) == 2 && !DROP && !split && !(env_lds && env_lds[0] == '0')) {
+      if (env_lds && env_lds[0] == '8')
+        hipLaunchKernelGGL((attn_fwd_lds_kernel<PARTS, 8>), dim3(ceil_div(p.Tq, 256), p.H, p.B), dim3(512), 0, stream, p);
+      else
+        hipLaunchKernelGGL((attn_fwd_lds_kernel<PARTS, 4>), dim3(ceil_div(p.Tq, 128), p.H, p.B), dim3(256), 0, stream, p);
+    } else if (split)
       hipLaunchKernelGGL((attn_fwd_kernel<T, PARTS, true, DROP>), dim3(ceil_div(p.Tq, 32), p.H, p.B), block, 0, stream, p);
     else
       hipLaunchKernelGGL((attn_fwd_kernel<T, PARTS, false, DROP>), dim3(ceil_div(p.Tq, 128), p.H, p.B), block, 0, stream, p);

@@ -283,6 +283,47 @@ def test_attention_fwd_bwd(dtype, shape):
         check(dk2, leaves[4].grad, dtype, sc, "dk2")
 
 
+@pytest.mark.parametrize("parts", [1, 2])
+def test_attention_forward_deferred_max_and_extreme_scores(parts):
+    """The bf16 forward for long sequences (attn_fwd_lds_kernel) rescales its running maximum only when a tile exceeds
+    it by 2^6, and biases its score accumulators by that maximum: force the rare branches.  Keys whose scores jump
+    by far more than the threshold at several tiles (for some queries only), rows of hugely negative and hugely
+    positive scores, and a check of the log-sum-exp itself."""
+    dtype = torch.bfloat16
+    B, H, Tq, S = 1, 2, 300, 460
+    E = H * 32
+    g = torch.Generator().manual_seed(77)
+    q1 = torch.randn(B, Tq, E, generator=g)
+    k1 = torch.randn(B, S, E, generator=g)
+    v = torch.randn(B, S, E, generator=g)
+    # spikes: key rows aligned with a few query rows, growing along the sequence (max jumps at tiles 1, 3, 5, 7)
+    for key, query, gain in ((70, 3, 4.0), (200, 3, 9.0), (333, 40, 14.0), (459, 299, 25.0), (130, 131, 6.0)):
+        k1[0, key] = q1[0, query] * gain / 5.0
+    q1[0, 10] = 6.0                                   # all scores of this query are large and positive ...
+    q1[0, 11] = -6.0                                  # ... and of this one large and negative, for keys 0..63
+    k1[0, :64] = k1[0, :64].abs() + 2.0
+    q1, k1, v = q1.to(dtype), k1.to(dtype), v.to(dtype)
+    q2 = k2 = None
+    if parts == 2:
+        q2, k2 = rnd((B, Tq, E), dtype, 4), rnd((B, S, E), dtype, 5)
+    scale = 1.0 / math.sqrt(32 * parts)
+    gdev = lambda t: None if t is None else t.to(DEV)
+    o, lse2 = ops.attn_fwd(gdev(q1), gdev(k1), gdev(v), scale, gdev(q2), gdev(k2))
+    heads = lambda t: t.float().view(B, -1, H, 32).transpose(1, 2)
+    sc = heads(q1) @ heads(k1).transpose(-1, -2)
+    if parts == 2:
+        sc = sc + heads(q2) @ heads(k2).transpose(-1, -2)
+    sc = sc.double() * scale
+    assert float((sc.max(-1).values - sc[..., :64].max(-1).values).max()) > 20.0      # the forcing did happen
+    ref = (torch.softmax(sc, -1) @ heads(v).double()).transpose(1, 2).reshape(B, Tq, E).float()
+    assert torch.isfinite(o.float()).all()
+    check(o, ref, dtype, 2, f"attn fwd forced rescale parts={parts}")
+    lse_ref = (torch.logsumexp(sc, -1) / math.log(2.0)).float()
+    # the kernel rounds the pre-scaled queries to bf16: the scores move by up to ~2^-8 relative
+    err = (lse2.cpu() - lse_ref).abs()
+    assert float((err / (lse_ref.abs() * 8e-3 + 0.05)).max()) < 1.0, float(err.max())
+
+
 def _drop_keep_mask(B, H, Tq, S, seed, p):
     """The attention kernels' stateless keep decision, restated in numpy (include/fod.h: fod_attn_shape.drop_*)."""
     M = np.uint64(0xFFFFFFFF)

@@ -19,7 +19,9 @@ for d in ("pmc1", "pmc2"):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             if "attn" not in k: continue
-            key = (k.split("(")[0][-60:], r.get("Grid_Size"))
+            import re
+            m_ = re.search(r"(attn_\w+<[^>]*>)", k)
+            key = (m_.group(1) if m_ else k[:60], r.get("Grid_Size"))
             agg[key][r["Counter_Name"]] += float(r["Counter_Value"])
     for key, c in agg.items():
         n = None
