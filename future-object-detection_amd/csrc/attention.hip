@@ -739,6 +739,301 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 dq pass with BLOCK-SHARED K / V tiles (long query sequences, no dropout).  The streaming dq kernel above spent
+// 58 % of its wave cycles in s_waitcnt (profiles/r02g_attention_sq_counters_fwd_lds.txt: every wave fetches each
+// 32-key tile from L2 itself, one tile ahead).  Same staging as attn_fwd_lds_kernel: 64-key tiles of K1 (K2) and V
+// copied once per block into double-buffered XOR-swizzled slabs, one barrier per tile.  The K slab serves both the
+// score product (row fragments, ds_read_b128) and dQ^T += K^T dS^T (transposing reads of the same image); -lse and
+// -delta enter as accumulator inputs, the queries are pre-multiplied by scale * log2(e), `scale` is applied to the
+// finished dQ.
+template <int PARTS, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_lds_kernel(const AttnParams p) {
+  typedef __bf16 T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int q0 = (blockIdx.x * NW + wave) * 32;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const bool active = q0 < p.Tq;
+  const int q = min(q0 + fr, p.Tq - 1);
+  __shared__ __attribute__((aligned(16))) unsigned char tiles[2][PARTS + 1][2][2048];
+
+  const float c = p.scale * LOG2E;
+  const T* Qp[2] = {reinterpret_cast<const T*>(p.q1), reinterpret_cast<const T*>(p.q2)};
+  const T* dOp = reinterpret_cast<const T*>(p.dout) + (long)b * p.o_bs + (long)q * p.o_ts + h * 32;
+  const T* Op = reinterpret_cast<const T*>(p.out) + (long)b * p.o_bs + (long)q * p.o_ts + h * 32;
+  Frag<T> fq[PARTS][2], fdo[2];
+  float dl = 0.f;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    Frag<T> fo;
+    frag_load_contig(fdo[s], dOp + 16 * s + 8 * fh);
+    frag_load_contig(fo, Op + 16 * s + 8 * fh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dl += (float)fdo[s].v[j] * (float)fo.v[j];
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt) {
+      Frag<T> f;
+      frag_load_contig(f, Qp[pt] + (long)b * p.q_bs + (long)q * p.q_ts + h * 32 + 16 * s + 8 * fh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) fq[pt][s].v[j] = (T)((float)f.v[j] * c);
+    }
+  }
+  dl += __shfl_xor(dl, 32);
+  const long sidx = ((long)b * p.H + h) * p.Tq + q;
+  const float lse2 = p.lse2[sidx];
+  if (fh == 0 && active && q0 + fr < p.Tq) p.delta[sidx] = dl;
+  f32x16 NEGL, NEGD;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    NEGL[r] = -lse2;
+    NEGD[r] = -dl;
+  }
+
+  // ---- staging (see attn_fwd_lds_kernel): unconditional loads, roles by pointer selection
+  const int cid = tid & 255;
+  const int srow = cid >> 2;
+  const unsigned co = (unsigned)(cid & 3) * 16u;
+  const unsigned char* kb1 = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(p.k1) + (long)b * p.k_bs + h * 32) + co;
+  const unsigned char* vb = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(p.v) + (long)b * p.v_bs + h * 32) + co;
+  const unsigned char* kb2 = PARTS == 2 ? reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(p.k2) + (long)b * p.k2_bs + h * 32) + co : kb1;
+  const bool v_role = NW == 8 && tid >= 256;
+  const unsigned char* srcA = v_role ? vb : kb1;
+  const unsigned tsA = v_role ? (unsigned)p.v_ts * 2u : (unsigned)p.k_ts * 2u;
+  const unsigned tsV = (unsigned)p.v_ts * 2u, ts2 = (unsigned)(PARTS == 2 ? p.k2_ts : p.k_ts) * 2u;
+  const int dst_off = (srow >> 5) * 2048 + slab_at(srow & 31, cid & 3);
+  unsigned char* dstA0 = &tiles[0][v_role ? PARTS : 0][0][0] + dst_off;
+  constexpr int BUF_BYTES = (PARTS + 1) * 2 * 2048;
+  uint4 preA, preV = make_uint4(0, 0, 0, 0), pre2 = make_uint4(0, 0, 0, 0);
+  auto request = [&](int kt) {
+    const unsigned row = (unsigned)min(kt * 64 + srow, p.S - 1);
+    preA = *reinterpret_cast<const uint4*>(srcA + (size_t)row * tsA);
+    if (NW == 4) preV = *reinterpret_cast<const uint4*>(vb + (size_t)row * tsV);
+    if (PARTS == 2) pre2 = *reinterpret_cast<const uint4*>(kb2 + (size_t)row * ts2);
+  };
+  auto commit = [&](int buf) {
+    *reinterpret_cast<uint4*>(dstA0 + buf * BUF_BYTES) = preA;
+    if (NW == 4) *reinterpret_cast<uint4*>(&tiles[buf][PARTS][0][0] + dst_off) = preV;
+    if (PARTS == 2 && !v_role) *reinterpret_cast<uint4*>(&tiles[buf][1][0][0] + dst_off) = pre2;
+  };
+
+  f32x16 dq[PARTS];
+#pragma unroll
+  for (int pt = 0; pt < PARTS; ++pt) zero_acc<T>(dq[pt]);
+
+  const int nkt = (p.S + 63) >> 6;
+  request(0);
+  commit(0);
+  if (nkt > 1) request(1);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (active) {
+      const int k0 = kt * 64;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x16 sacc = NEGL, dpacc = NEGD;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+          for (int pt = 0; pt < PARTS; ++pt) {
+            Frag<T> fk;
+            const uint4 v = *reinterpret_cast<const uint4*>(&tiles[buf][pt][t][0] + slab_at(fr, 2 * s + fh));
+            __builtin_memcpy(&fk, &v, 16);
+            mma16(fk, fq[pt][s], sacc);
+          }
+          Frag<T> fvv;
+          const uint4 v = *reinterpret_cast<const uint4*>(&tiles[buf][PARTS][t][0] + slab_at(fr, 2 * s + fh));
+          __builtin_memcpy(&fvv, &v, 16);
+          mma16(fvv, fdo[s], dpacc);              // dP^T[k, q] - delta[q]
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = ex2(sacc[r]) * dpacc[r];          // dS^T / scale
+        if (k0 + 32 * t + 32 > p.S) {              // keys past S (clamped duplicates) add nothing
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (k0 + 32 * t + acc_row(r, lane) >= p.S) sacc[r] = 0.f;
+        }
+        TransTile<T> tk;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          Frag<T> fds;
+          frag_from_acc(fds, sacc, s);
+#pragma unroll
+          for (int pt = 0; pt < PARTS; ++pt) {
+            Frag<T> fkt;
+            tk.adopt(&tiles[buf][pt][t][0]);
+            tk.frag(fkt, s, lane);
+            mma16(fkt, fds, dq[pt]);              // dQ^T[d, q] += sum_k K[k,d] dS^T[k,q]
+          }
+        }
+      }
+    }
+    if (kt + 1 < nkt) commit(buf ^ 1);
+    if (kt + 2 < nkt) request(kt + 2);
+    __syncthreads();
+  }
+  if (active && q0 + fr < p.Tq) {
+    T* d1 = reinterpret_cast<T*>(p.dq1) + (long)b * p.q_bs + (long)q * p.q_ts + h * 32;
+    store_acc_t<T>(d1, dq[0], fh, p.scale);
+    if (PARTS == 2) {
+      T* d2 = reinterpret_cast<T*>(p.dq2) + (long)b * p.q_bs + (long)q * p.q_ts + h * 32;
+      store_acc_t<T>(d2, dq[PARTS - 1], fh, p.scale);
+    }
+  }
+}
+
+// bf16 dk / dv pass with BLOCK-SHARED Q / dO tiles (no dropout): a wave owns 32 keys (pre-multiplied by scale *
+// log2(e) once), the block walks the queries in tiles of 64 staged once per block -- Q1 (Q2), dO slabs and the
+// negated lse / delta rows -- double-buffered, one barrier per tile.  The Q / dO slabs serve S = Q K^T and dP = dO V^T
+// by rows and dK^T += Q^T dS, dV^T += dO^T P by transposing reads.
+template <int PARTS, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_lds_kernel(const AttnParams p) {
+  typedef __bf16 T;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int k0 = (blockIdx.x * NW + wave) * 32;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const bool active = k0 < p.S;
+  const int key = min(k0 + fr, p.S - 1);
+  __shared__ __attribute__((aligned(16))) unsigned char tiles[2][PARTS + 1][2][2048];     // Q1, (Q2), dO
+  __shared__ __attribute__((aligned(16))) float stat[2][2][64];                            // -lse2, -delta
+
+  const float c = p.scale * LOG2E;
+  const T* Kp[2] = {reinterpret_cast<const T*>(p.k1), reinterpret_cast<const T*>(p.k2)};
+  const T* Vp = reinterpret_cast<const T*>(p.v) + (long)b * p.v_bs + (long)key * p.v_ts + h * 32;
+  Frag<T> fk[PARTS][2], fv[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    frag_load_contig(fv[s], Vp + 16 * s + 8 * fh);
+#pragma unroll
+    for (int pt = 0; pt < PARTS; ++pt) {
+      Frag<T> f;
+      frag_load_contig(f, Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)key * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) fk[pt][s].v[j] = (T)((float)f.v[j] * c);
+    }
+  }
+
+  // ---- staging: chunk cid of Q1 (Q2) and dO per thread (NW == 4) or by role (NW == 8); threads 0..127 also the
+  // tile's 64 lse2 / 64 delta values
+  const int cid = tid & 255;
+  const int srow = cid >> 2;
+  const unsigned co = (unsigned)(cid & 3) * 16u;
+  const unsigned char* qb1 = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(p.q1) + (long)b * p.q_bs + h * 32) + co;
+  const unsigned char* ob = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(p.dout) + (long)b * p.o_bs + h * 32) + co;
+  const unsigned char* qb2 = PARTS == 2 ? reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(p.q2) + (long)b * p.q_bs + h * 32) + co : qb1;
+  const bool o_role = NW == 8 && tid >= 256;
+  const unsigned char* srcA = o_role ? ob : qb1;
+  const unsigned tsA = o_role ? (unsigned)p.o_ts * 2u : (unsigned)p.q_ts * 2u;
+  const unsigned tsO = (unsigned)p.o_ts * 2u, ts2 = (unsigned)p.q_ts * 2u;
+  const int dst_off = (srow >> 5) * 2048 + slab_at(srow & 31, cid & 3);
+  unsigned char* dstA0 = &tiles[0][o_role ? PARTS : 0][0][0] + dst_off;
+  constexpr int BUF_BYTES = (PARTS + 1) * 2 * 2048;
+  const float* st_src = (tid < 64 ? p.lse2 : p.delta) + ((long)b * p.H + h) * p.Tq;
+  const int st_row = tid & 63;
+  uint4 preA, preO = make_uint4(0, 0, 0, 0), pre2 = make_uint4(0, 0, 0, 0);
+  float pre_st = 0.f;
+  auto request = [&](int qt) {
+    const unsigned row = (unsigned)min(qt * 64 + srow, p.Tq - 1);          // rows past Tq: duplicates, zeroed below
+    preA = *reinterpret_cast<const uint4*>(srcA + (size_t)row * tsA);
+    if (NW == 4) preO = *reinterpret_cast<const uint4*>(ob + (size_t)row * tsO);
+    if (PARTS == 2) pre2 = *reinterpret_cast<const uint4*>(qb2 + (size_t)row * ts2);
+    pre_st = st_src[min(qt * 64 + st_row, p.Tq - 1)];
+  };
+  auto commit = [&](int buf) {
+    *reinterpret_cast<uint4*>(dstA0 + buf * BUF_BYTES) = preA;
+    if (NW == 4) *reinterpret_cast<uint4*>(&tiles[buf][PARTS][0][0] + dst_off) = preO;
+    if (PARTS == 2 && !o_role) *reinterpret_cast<uint4*>(&tiles[buf][1][0][0] + dst_off) = pre2;
+    if (tid < 128) stat[buf][tid >> 6][st_row] = -pre_st;
+  };
+
+  f32x16 dk[PARTS], dv;
+  zero_acc<T>(dv);
+#pragma unroll
+  for (int pt = 0; pt < PARTS; ++pt) zero_acc<T>(dk[pt]);
+
+  const int nqt = (p.Tq + 63) >> 6;
+  request(0);
+  commit(0);
+  if (nqt > 1) request(1);
+  __syncthreads();
+  for (int qt = 0; qt < nqt; ++qt) {
+    const int buf = qt & 1;
+    if (active) {
+      const int q0 = qt * 64;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x16 sacc, dpacc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 ls = *reinterpret_cast<const f32x4*>(&stat[buf][0][32 * t + 8 * g + 4 * fh]);
+          const f32x4 de = *reinterpret_cast<const f32x4*>(&stat[buf][1][32 * t + 8 * g + 4 * fh]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            sacc[4 * g + e] = ls[e];
+            dpacc[4 * g + e] = de[e];
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+          for (int pt = 0; pt < PARTS; ++pt) {
+            Frag<T> fqa;
+            const uint4 v = *reinterpret_cast<const uint4*>(&tiles[buf][pt][t][0] + slab_at(fr, 2 * s + fh));
+            __builtin_memcpy(&fqa, &v, 16);
+            mma16(fqa, fk[pt][s], sacc);            // S[q, key] - lse[q]
+          }
+          Frag<T> fdoa;
+          const uint4 v = *reinterpret_cast<const uint4*>(&tiles[buf][PARTS][t][0] + slab_at(fr, 2 * s + fh));
+          __builtin_memcpy(&fdoa, &v, 16);
+          mma16(fdoa, fv[s], dpacc);                // dP[q, key] - delta[q]
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          sacc[r] = ex2(sacc[r]);                   // P
+          dpacc[r] *= sacc[r];                      // dS / scale
+        }
+        if (q0 + 32 * t + 32 > p.Tq) {             // queries past Tq (clamped duplicates) add nothing
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (q0 + 32 * t + acc_row(r, lane) >= p.Tq) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+        }
+        TransTile<T> tt;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          Frag<T> fp, fds, fdot;
+          frag_from_acc(fp, sacc, s);
+          frag_from_acc(fds, dpacc, s);
+          tt.adopt(&tiles[buf][PARTS][t][0]);
+          tt.frag(fdot, s, lane);
+          mma16(fdot, fp, dv);                      // dV^T[d, key] += sum_q dO[q,d] P[q,key]
+#pragma unroll
+          for (int pt = 0; pt < PARTS; ++pt) {
+            Frag<T> fqt;
+            tt.adopt(&tiles[buf][pt][t][0]);
+            tt.frag(fqt, s, lane);
+            mma16(fqt, fds, dk[pt]);                // dK^T[d, key] += sum_q Q[q,d] dS[q,key]
+          }
+        }
+      }
+    }
+    if (qt + 1 < nqt) commit(buf ^ 1);
+    if (qt + 2 < nqt) request(qt + 2);
+    __syncthreads();
+  }
+  if (active && k0 + fr < p.S) {
+    T* o = reinterpret_cast<T*>(p.dv) + (long)b * p.v_bs + (long)key * p.v_ts + h * 32;
+    store_acc_t<T>(o, dv, fh, 1.f);
+    T* d1 = reinterpret_cast<T*>(p.dk1) + (long)b * p.k_bs + (long)key * p.k_ts + h * 32;
+    store_acc_t<T>(d1, dk[0], fh, p.scale);
+    if (PARTS == 2) {
+      T* d2 = reinterpret_cast<T*>(p.dk2) + (long)b * p.dk2_bs + (long)key * p.dk2_ts + h * 32;
+      store_acc_t<T>(d2, dk[PARTS - 1], fh, p.scale);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // dk/dv pass: wave owns 32 keys (key on the lane); needs lse2 and delta from the passes above.
 template <typename T, int PARTS, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
@@ -1014,23 +1309,30 @@ int launch_all(int which, const AttnParams& p, hipStream_t stream) {
   if (which == 0) {
     static const char* env_lds = getenv("FOD_ATTN_LDS");
     if (sizeof(T) == 2 && !DROP && !split && !(env_lds && env_lds[0] == '0')) {
-      if (env_lds && env_lds[0] == '8')
-        hipLaunchKernelGGL((attn_fwd_lds_kernel<PARTS, 8>), dim3(ceil_div(p.Tq, 256), p.H, p.B), dim3(512), 0, stream, p);
-      else
+      if (env_lds && env_lds[0] == '4')
         hipLaunchKernelGGL((attn_fwd_lds_kernel<PARTS, 4>), dim3(ceil_div(p.Tq, 128), p.H, p.B), dim3(256), 0, stream, p);
+      else
+        hipLaunchKernelGGL((attn_fwd_lds_kernel<PARTS, 8>), dim3(ceil_div(p.Tq, 256), p.H, p.B), dim3(512), 0, stream, p);
     } else if (split)
       hipLaunchKernelGGL((attn_fwd_kernel<T, PARTS, true, DROP>), dim3(ceil_div(p.Tq, 32), p.H, p.B), block, 0, stream, p);
     else
       hipLaunchKernelGGL((attn_fwd_kernel<T, PARTS, false, DROP>), dim3(ceil_div(p.Tq, 128), p.H, p.B), block, 0, stream, p);
   } else if (which == 1) {
-    if (split)
+    static const char* env_lds = getenv("FOD_ATTN_LDS");
+    if (sizeof(T) == 2 && !DROP && !split && !(env_lds && env_lds[0] == '0'))
+      hipLaunchKernelGGL((attn_bwd_dq_lds_kernel<PARTS, 4>), dim3(ceil_div(p.Tq, 128), p.H, p.B), dim3(256), 0, stream, p);
+    else if (split)
       hipLaunchKernelGGL((attn_bwd_dq_kernel<T, PARTS, true, DROP>), dim3(ceil_div(p.Tq, 32), p.H, p.B), block, 0, stream, p);
     else
       hipLaunchKernelGGL((attn_bwd_dq_kernel<T, PARTS, false, DROP>), dim3(ceil_div(p.Tq, 128), p.H, p.B), block, 0, stream, p);
   } else {
     const dim3 grid(ceil_div(p.S, 128), p.H, p.B);
     static const char* env_pf = getenv("FOD_ATTN_PF");
-    if (sizeof(T) == 2 && !(env_pf && env_pf[0] == '0'))
+    static const char* env_lds = getenv("FOD_ATTN_LDS");
+    // (short query sequences keep the streaming kernel: a 64-query tile per barrier is most of such a problem)
+    if (sizeof(T) == 2 && !DROP && p.Tq > 512 && !(env_lds && env_lds[0] == '0'))
+      hipLaunchKernelGGL((attn_bwd_dkv_lds_kernel<PARTS, 4>), grid, block, 0, stream, p);
+    else if (sizeof(T) == 2 && !(env_pf && env_pf[0] == '0'))
       hipLaunchKernelGGL((attn_bwd_dkv_pf_kernel<PARTS, DROP>), grid, block, 0, stream, p);
     else
       hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, PARTS, DROP>), grid, block, 0, stream, p);

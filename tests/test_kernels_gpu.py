@@ -257,7 +257,8 @@ def _attn_ref(q1, k1, v, scale, q2=None, k2=None):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 4, 77, 150, 1), (1, 8, 128, 49, 2), (2, 2, 33, 1, 2), (1, 8, 200, 200, 1),
-                                   (2, 8, 128, 1450, 2), (1, 2, 600, 333, 1), (1, 1, 40, 130, 2)])
+                                   (2, 8, 128, 1450, 2), (1, 2, 600, 333, 1), (1, 1, 40, 130, 2), (1, 2, 700, 650, 2),
+                                   (2, 1, 513, 64, 1)])
 def test_attention_fwd_bwd(dtype, shape):
     B, H, Tq, S, parts = shape
     E = H * 32
