@@ -512,11 +512,15 @@ __global__ __launch_bounds__(NW * 64, PARTS == 1 ? 4 : 3) void attn_fwd_lds_kern
       if (kt == 0 || __any(mx > THR)) {
         // raise the running maximum of the lanes that need it (all of them on the first tile): everything that is
         // biased by the old maximum -- O, l, the bias itself and this tile's scores -- moves by the same amount
+        // (first tile: O and l are still zero and are NOT scaled -- its maximum may lie far below zero, 2^-d would
+        // overflow to inf and 0 * inf would poison the row; later d >= 0, the factor is <= 1)
         const float d = kt == 0 ? mx : fmaxf(mx, 0.f);
-        const float alpha = ex2(-d);
+        if (kt != 0) {
+          const float alpha = ex2(-d);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
-        lacc[0] *= alpha;
+          for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+          lacc[0] *= alpha;
+        }
         negm -= d;
 #pragma unroll
         for (int r = 0; r < 16; ++r) NEGM[r] = negm;
@@ -594,7 +598,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   // by scale * log2(e) and C = -lse2 (per lane = per query) the score MFMA returns the argument of v_exp_f32; with
   // C = -delta the dP MFMA returns dP - delta; `scale` is applied once to the finished dQ.  Per score element the
   // vector pipe is left with one exp, one multiply and the bf16 convert (was fma + exp + sub + mul + mul + convert).
-  constexpr bool BIAS = sizeof(T) == 2 && !DROP;
+  // NOT enabled here: a backward pass must form its scores with exactly the arithmetic (and roundings) of the forward
+  // pass that produced lse2 -- pre-scaled bf16 queries change a score by ~2^-9 of its magnitude, and exp2(score - lse)
+  // of a saturated softmax then explodes.  The LDS kernels below use the bias form consistently in all three passes;
+  // these streaming kernels pair with attn_fwd_kernel and keep its arithmetic.
+  constexpr bool BIAS = false;
   f32x16 NEGL, NEGD;
   if constexpr (BIAS) {
 #pragma unroll
@@ -895,7 +903,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_lds_kernel(const AttnPar
   const int h = blockIdx.y, b = blockIdx.z;
   const bool active = k0 < p.S;
   const int key = min(k0 + fr, p.S - 1);
-  __shared__ __attribute__((aligned(16))) unsigned char tiles[2][PARTS + 1][2][2048];     // Q1, (Q2), dO
+  // slots: Q1, (Q2), dO, then Q1', (Q2') = the queries pre-multiplied by scale * log2(e) and rounded to bf16 EXACTLY as
+  // attn_fwd_lds_kernel / attn_bwd_dq_lds_kernel do: the scores must be the forward's to the last bit of rounding
+  __shared__ __attribute__((aligned(16))) unsigned char tiles[2][2 * PARTS + 1][2][2048];
   __shared__ __attribute__((aligned(16))) float stat[2][2][64];                            // -lse2, -delta
 
   const float c = p.scale * LOG2E;
@@ -906,12 +916,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_lds_kernel(const AttnPar
   for (int s = 0; s < 2; ++s) {
     frag_load_contig(fv[s], Vp + 16 * s + 8 * fh);
 #pragma unroll
-    for (int pt = 0; pt < PARTS; ++pt) {
-      Frag<T> f;
-      frag_load_contig(f, Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)key * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) fk[pt][s].v[j] = (T)((float)f.v[j] * c);
-    }
+    for (int pt = 0; pt < PARTS; ++pt)
+      frag_load_contig(fk[pt][s], Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)key * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
   }
 
   // ---- staging: chunk cid of Q1 (Q2) and dO per thread (NW == 4) or by role (NW == 8); threads 0..127 also the
@@ -928,7 +934,16 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_lds_kernel(const AttnPar
   const unsigned tsO = (unsigned)p.o_ts * 2u, ts2 = (unsigned)p.q_ts * 2u;
   const int dst_off = (srow >> 5) * 2048 + slab_at(srow & 31, cid & 3);
   unsigned char* dstA0 = &tiles[0][o_role ? PARTS : 0][0][0] + dst_off;
-  constexpr int BUF_BYTES = (PARTS + 1) * 2 * 2048;
+  constexpr int BUF_BYTES = (2 * PARTS + 1) * 2 * 2048;
+  auto scaled = [&](const uint4& raw) {
+    Frag<T> f, g;
+    __builtin_memcpy(&f, &raw, 16);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g.v[j] = (T)((float)f.v[j] * c);
+    uint4 out;
+    __builtin_memcpy(&out, &g, 16);
+    return out;
+  };
   const float* st_src = (tid < 64 ? p.lse2 : p.delta) + ((long)b * p.H + h) * p.Tq;
   const int st_row = tid & 63;
   uint4 preA, preO = make_uint4(0, 0, 0, 0), pre2 = make_uint4(0, 0, 0, 0);
@@ -943,7 +958,13 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_lds_kernel(const AttnPar
   auto commit = [&](int buf) {
     *reinterpret_cast<uint4*>(dstA0 + buf * BUF_BYTES) = preA;
     if (NW == 4) *reinterpret_cast<uint4*>(&tiles[buf][PARTS][0][0] + dst_off) = preO;
-    if (PARTS == 2 && !o_role) *reinterpret_cast<uint4*>(&tiles[buf][1][0][0] + dst_off) = pre2;
+    if (!o_role) {
+      *reinterpret_cast<uint4*>(&tiles[buf][PARTS + 1][0][0] + dst_off) = scaled(preA);
+      if (PARTS == 2) {
+        *reinterpret_cast<uint4*>(&tiles[buf][1][0][0] + dst_off) = pre2;
+        *reinterpret_cast<uint4*>(&tiles[buf][PARTS + 2][0][0] + dst_off) = scaled(pre2);
+      }
+    }
     if (tid < 128) stat[buf][tid >> 6][st_row] = -pre_st;
   };
 
@@ -979,9 +1000,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_lds_kernel(const AttnPar
 #pragma unroll
           for (int pt = 0; pt < PARTS; ++pt) {
             Frag<T> fqa;
-            const uint4 v = *reinterpret_cast<const uint4*>(&tiles[buf][pt][t][0] + slab_at(fr, 2 * s + fh));
+            const uint4 v = *reinterpret_cast<const uint4*>(&tiles[buf][PARTS + 1 + pt][t][0] + slab_at(fr, 2 * s + fh));
             __builtin_memcpy(&fqa, &v, 16);
-            mma16(fqa, fk[pt][s], sacc);            // S[q, key] - lse[q]
+            mma16(fqa, fk[pt][s], sacc);            // S'[q, key] - lse[q], S' from the pre-scaled queries
           }
           Frag<T> fdoa;
           const uint4 v = *reinterpret_cast<const uint4*>(&tiles[buf][PARTS][t][0] + slab_at(fr, 2 * s + fh));
@@ -1162,7 +1183,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_pf_kernel(const AttnParams p
   // without dropout the row constants ride in the accumulator inputs (see attn_bwd_dq_kernel): this wave's 32 keys are
   // pre-multiplied by scale * log2(e) ONCE, -lse and -delta (negated when they are staged through LDS) initialise the
   // S and dP accumulators, `scale` is applied to the finished dK
-  constexpr bool BIAS = !DROP;
+  constexpr bool BIAS = false;          // see attn_bwd_dq_kernel: this kernel pairs with attn_fwd_kernel's arithmetic
   if constexpr (BIAS) {
 #pragma unroll
     for (int pt = 0; pt < PARTS; ++pt)
@@ -1329,8 +1350,8 @@ int launch_all(int which, const AttnParams& p, hipStream_t stream) {
     const dim3 grid(ceil_div(p.S, 128), p.H, p.B);
     static const char* env_pf = getenv("FOD_ATTN_PF");
     static const char* env_lds = getenv("FOD_ATTN_LDS");
-    // (short query sequences keep the streaming kernel: a 64-query tile per barrier is most of such a problem)
-    if (sizeof(T) == 2 && !DROP && p.Tq > 512 && !(env_lds && env_lds[0] == '0'))
+    // the three LDS kernels go together (same predicate as the forward and dq passes): they share the score arithmetic
+    if (sizeof(T) == 2 && !DROP && !split && !(env_lds && env_lds[0] == '0'))
       hipLaunchKernelGGL((attn_bwd_dkv_lds_kernel<PARTS, 4>), grid, block, 0, stream, p);
     else if (sizeof(T) == 2 && !(env_pf && env_pf[0] == '0'))
       hipLaunchKernelGGL((attn_bwd_dkv_pf_kernel<PARTS, DROP>), grid, block, 0, stream, p);

@@ -259,7 +259,13 @@ __global__ __launch_bounds__(64) void od_map_kernel(const float* __restrict__ sc
   const float thr = (float)(0.5 + (double)t * 0.05);
   const float s0 = (float)((1.0 / 24) * (1.0 / 64) * (double)H * (double)W);
   const float s1 = (float)((1.0 / 4) * (1.0 / 12) * (double)H * (double)W);
-  for (int m = lane; m < M; m += 64) s_score[m] = scores[((long)b * M + m) * C1 + c];
+  // (a NaN score -- a diverged model -- ranks last instead of breaking the ranking: with unordered comparisons
+  // every NaN would claim rank 0 and leave the other slots of s_order uninitialised, i.e. wild box indices)
+  for (int m = lane; m < M; m += 64) {
+    const float sc = scores[((long)b * M + m) * C1 + c];
+    s_score[m] = sc == sc ? sc : -INFINITY;
+  }
+  s_order[lane] = 0;
   for (int n = lane; n < N; n += 64) {
     const long i = (long)b * N + n;
     s_free[n] = (aa[i] == 1) && (ac[i] == c || c == C1 - 1);

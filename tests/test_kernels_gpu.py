@@ -302,6 +302,8 @@ def test_attention_forward_deferred_max_and_extreme_scores(parts):
         k1[0, key] = q1[0, query] * gain / 5.0
     q1[0, 10] = 6.0                                   # all scores of this query are large and positive ...
     q1[0, 11] = -6.0                                  # ... and of this one large and negative, for keys 0..63
+    q1[0, 12] = -30.0                                 # first-tile maximum far below -127 in log2 units (2^-m overflows)
+    q1[0, 13] = 30.0
     k1[0, :64] = k1[0, :64].abs() + 2.0
     q1, k1, v = q1.to(dtype), k1.to(dtype), v.to(dtype)
     q2 = k2 = None
@@ -323,6 +325,54 @@ def test_attention_forward_deferred_max_and_extreme_scores(parts):
     # the kernel rounds the pre-scaled queries to bf16: the scores move by up to ~2^-8 relative
     err = (lse2.cpu() - lse_ref).abs()
     assert float((err / (lse_ref.abs() * 8e-3 + 0.05)).max()) < 1.0, float(err.max())
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 600, 200, 1), (1, 2, 128, 49, 2), (1, 1, 600, 330, 2)])   # the LDS kernel family
+def test_attention_saturated_softmax_forward_backward_consistency(shape):
+    """Scores of magnitude ~100 (a saturated softmax, as random-init backbones produce): the bf16 LDS kernels form
+    their scores from queries pre-multiplied by scale * log2(e) and rounded to bf16 -- all three passes must use the
+    SAME rounded scores, or exp2(score - lse) in the backward explodes (observed: NaN loss at the headline size).
+    Reference: the same rounding with a straight-through gradient, in float64."""
+    dtype = torch.bfloat16
+    B, H, Tq, S, parts = shape
+    E = H * 32
+    mag = 8.0
+    q1, k1, v = rnd((B, Tq, E), dtype, 1, mag), rnd((B, S, E), dtype, 2, mag), rnd((B, S, E), dtype, 3)
+    q2 = rnd((B, Tq, E), dtype, 4, mag) if parts == 2 else None
+    k2 = rnd((B, S, E), dtype, 5, mag) if parts == 2 else None
+    scale = 1.0 / math.sqrt(32 * parts)
+    c = np.float32(scale) * np.float32(1.4426950408889634)
+    leaves = [t.double().requires_grad_(True) if t is not None else None for t in (q1, k1, v, q2, k2)]
+    heads = lambda t: t.view(B, -1, H, 32).transpose(1, 2)
+
+    def ste(q):                                        # bf16(c * q) with the gradient of c * q
+        exact = q * float(c)
+        rounded = (q.detach().float() * torch.tensor(c)).to(dtype).double()
+        return exact + (rounded - exact).detach()
+
+    s2 = heads(ste(leaves[0])) @ heads(leaves[1]).transpose(-1, -2)
+    if parts == 2:
+        s2 = s2 + heads(ste(leaves[3])) @ heads(leaves[4]).transpose(-1, -2)
+    prob = torch.softmax(s2 * math.log(2.0), dim=-1)
+    assert float(prob.detach().max(-1).values.median()) > 0.9          # saturated indeed
+    o_ref = (prob @ heads(leaves[2])).transpose(1, 2).reshape(B, Tq, E)
+    dout = rnd((B, Tq, E), dtype, 6)
+    g = lambda t: None if t is None else t.to(DEV)
+    o, lse2 = ops.attn_fwd(g(q1), g(k1), g(v), scale, g(q2), g(k2))
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse2).all()
+    check(o, o_ref.float(), dtype, 2, f"saturated attn fwd {shape}")
+    # the backward consumes the forward's own rounded output (delta = rowsum(dO * O)), as in the model
+    o_ref.backward(dout.double())
+    grads = ops.attn_bwd(g(q1), g(k1), g(v), o, g(dout), lse2, scale, g(q2), g(k2))
+    names = ("dq1", "dk1", "dq2", "dk2", "dv")
+    refs = (leaves[0].grad, leaves[1].grad, None if parts == 1 else leaves[3].grad,
+            None if parts == 1 else leaves[4].grad, leaves[2].grad)
+    for name, got, want in zip(names, grads, refs):
+        if want is None:
+            continue
+        assert torch.isfinite(got.float()).all(), name
+        err = float((got.float().cpu() - want.float()).norm() / (want.float().norm() + 1e-12))
+        assert err < 3e-2, (name, err)
 
 
 def _drop_keep_mask(B, H, Tq, S, seed, p):
