@@ -89,9 +89,11 @@ class GradientReducer:
                                f"min {both[0].tolist()}, max {both[1].tolist()}): the autograd graphs differ between ranks")
 
     def _reset(self):
+        self.start = 0                   # arena offset when this backward started: only [start, flushed) is ever averaged in place
         self.flushed = 0                 # arena elements already queued for reduction in this backward
         self.arena_buf = None
         self.armed = False               # end-of-backward callback queued
+        self.accumulating = False        # gradients from an earlier (un-synchronised) backward are still in place
         self._unpack = []
 
     # ---- called during backward (native/backbone.py, the hook FodDataParallel puts on the loss) -------
@@ -100,6 +102,13 @@ class GradientReducer:
         if self.enabled and not self.armed:
             self.armed = True
             self._stats = {"arena_flushes": 0, "arena_elems": 0, "stragglers": 0}
+            # Gradient accumulation (a backward under no_sync(), then this one, no zero_grad in between): the arena
+            # still holds the earlier gradients and autograd will ADD this pass's into the same slices at its own
+            # pace -- an in-place flush would average slices that are not final yet and race with those adds.  Then
+            # nothing is averaged in place: every gradient goes through the packed path at the end of backward.
+            self.accumulating = any(p.grad is not None for p in self.params)
+            from future_od.native import functional as Fn
+            self.start = self.flushed = Fn.ARENA.off if Fn.ARENA.active else 0
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
 
     def _all_reduce(self, t):
@@ -132,7 +141,7 @@ class GradientReducer:
         if not self.enabled or not arena.active or arena.buf is None:
             return
         self.arm()
-        if arena.off - self.flushed < min_elems:
+        if self.accumulating or arena.off - self.flushed < min_elems:
             return
         self.arena_buf = arena.buf
         region = arena.buf[self.flushed:arena.off]
@@ -149,7 +158,7 @@ class GradientReducer:
         if self.arena_buf is None or not g.is_cuda or g.dtype != torch.float32:
             return False
         lo = self.arena_buf.data_ptr()
-        return lo <= g.data_ptr() < lo + 4 * self.flushed
+        return lo + 4 * self.start <= g.data_ptr() < lo + 4 * self.flushed
 
     def _reduce_stragglers(self):
         todo = [p.grad for p in self.params if p.grad is not None and not self._in_flushed_arena(p.grad)]

@@ -1,5 +1,6 @@
-"""Loaders with the reference's call shape (reference runs/_loader.py:78-124 `get_nusc_loaders(size, offsets, config,
-args, train_batch_size)`), drawing SYNTHETIC NuScenes-shaped batches: there is no dataset and no network on the
+"""Loaders with the reference's call shape (reference runs/_loader.py:10-95: `get_nusc_loaders(img_size, offsets, args,
+config, train_batch_size, random_aug, val_annotated_frame_override, filter_offsets)` and `get_nuim_loaders(...)`),
+drawing SYNTHETIC NuScenes-shaped batches: there is no dataset and no network on the
 build / GPU boxes (BASELINE.json configs[3]: "random-init weights, synthetic NuScenes-shaped batches").
 
 Sharding follows the reference (`runs/_loader.py:110-112`): the per-GPU batch is the global batch divided by the world
@@ -9,9 +10,7 @@ import torch
 
 from future_od.datasets.synthetic import make_batch
 
-# future_od/datasets/nu_scenes.py:29-38
-CATEGORY_DICT = {0: "Vehicle", 1: "Truck", 2: "Trailer", 3: "Pedestrian", 4: "Bus", 5: "Motorcyclist", 6: "Bicyclist",
-                 7: "ConstructionVehicle"}
+from future_od.datasets.nu_scenes import CATEGORY_DICT      # noqa: F401  (reference nu_scenes.py:29-38)
 
 
 class SyntheticNuScenes:
@@ -47,9 +46,18 @@ class SyntheticLoader:
             yield b
 
 
-def get_nusc_loaders(size, offsets, config, args, train_batch_size, val_batch_size=None, steps_per_epoch=None,
+def get_nusc_loaders(img_size, offsets, args, config, train_batch_size, random_aug=None,
+                     val_annotated_frame_override=None, filter_offsets=None, val_batch_size=None, steps_per_epoch=None,
                      val_steps=None):
-    """-> (train_loader, {"val": val_loader}); `train_batch_size` is GLOBAL (reference :110-112)."""
+    """-> (train_loader, {"val": val_loader}); `train_batch_size` is GLOBAL (reference :110-112).  `offsets` may be a
+    dict {"train": ..., "val": ...} (reference :64-68); the augmentation / filter arguments exist for call
+    compatibility and are ignored by the synthetic source."""
+    size = img_size
+    if isinstance(offsets, dict):
+        assert "train" in offsets and "val" in offsets
+        offsets, val_offsets = offsets["train"], offsets["val"]
+    else:
+        val_offsets = offsets
     world = getattr(args, "world_size", 1) if getattr(args, "distributed", False) else 1
     rank = getattr(args, "world_rank", 0)
     assert train_batch_size % world == 0, "global batch must divide over the ranks"
@@ -57,5 +65,13 @@ def get_nusc_loaders(size, offsets, config, args, train_batch_size, val_batch_si
     steps = steps_per_epoch or getattr(args, "steps_per_epoch", 8)
     vsteps = val_steps or getattr(args, "val_steps", 2)
     train = SyntheticLoader(size, offsets, per_gpu, steps, rank, world, seed=1234)
-    val = SyntheticLoader(size, offsets, val_batch_size or per_gpu, vsteps, rank, world, seed=99991)
+    val = SyntheticLoader(size, val_offsets, val_batch_size or per_gpu, vsteps, rank, world, seed=99991)
     return train, {"val": val}
+
+
+def get_nuim_loaders(img_size, offsets, args, config, train_batch_size, random_aug=None,
+                     val_annotated_frame_override=None, **kw):
+    """Reference runs/_loader.py:10-50: NuImages clips are addressed by FRAME INDEX offsets around the annotated frame
+    (`nu_images.ANNOTATED_FRAME + offset`); only their count matters to the synthetic source."""
+    return get_nusc_loaders(img_size, offsets, args, config, train_batch_size, random_aug,
+                            val_annotated_frame_override, **kw)

@@ -68,6 +68,32 @@ def _worker(rank, world, port, q):
         for n in ref:
             worst = max(worst, float((got[n] - ref[n]).abs().max() / (ref[n].abs().max() + 1e-12)))
         opt.step()
+    # gradient accumulation: a backward under no_sync(), then a synchronised one WITHOUT zero_grad in between must
+    # leave avg_ranks(g1 + g2) everywhere (torch DDP's contract); the second batch differs from the first
+    data2 = make_batch(1, 3, 64, 96, seed=200 + rank, device=dev, max_boxes=7)
+    opt.zero_grad()
+    with model.no_sync():
+        _, _, loss, _, _ = model(data=data, distributed=True)
+        loss.backward()
+    _, _, loss, _, _ = model(data=data2, distributed=True)
+    loss.backward()
+    torch.cuda.synchronize()
+    got = {n: p.grad.detach().clone() for n, p in model.module.named_parameters() if p.grad is not None}
+    acc_stats = dict(model.grad_reducer.stats)
+    opt.zero_grad()
+    with model.no_sync():
+        _, _, loss, _, _ = model(data=data, distributed=True)
+        loss.backward()
+        _, _, loss, _, _ = model(data=data2, distributed=True)
+        loss.backward()
+    worst_acc = 0.0
+    for n, p in model.module.named_parameters():
+        if p.grad is not None:
+            g = p.grad.detach().clone().contiguous()
+            dist.all_reduce(g)
+            g /= world
+            worst_acc = max(worst_acc, float((got[n] - g).abs().max() / (g.abs().max() + 1e-12)))
+    report.append({"accumulate": acc_stats, "worst": worst_acc})
     q.put((rank, worst, report, len(ref)))
     dist.barrier()
     dist.destroy_process_group()
@@ -90,5 +116,8 @@ def test_two_ranks_average_gradients():
         assert worst < 1e-5, (rank, worst, report)            # fp32: same sums, different order of two addends
         # first step: no arena yet, everything goes through the packed path; later: arena regions, few stragglers
         assert report[0]["arena_flushes"] == 0 and report[0]["stragglers"] == nref
-        assert report[-1]["arena_flushes"] >= 1 and report[-1]["stragglers"] < 16, report
-    assert res[0][2] == res[1][2]                               # same layout on both ranks
+        assert report[2]["arena_flushes"] >= 1 and report[2]["stragglers"] < 16, report
+        # accumulation: nothing averaged in place, everything through the packed path, and the right values
+        assert report[3]["accumulate"]["arena_flushes"] == 0 and report[3]["accumulate"]["stragglers"] == nref, report[3]
+        assert report[3]["worst"] < 1e-5, report[3]
+    assert res[0][2][:3] == res[1][2][:3]                       # same layout on both ranks
