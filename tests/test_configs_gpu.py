@@ -1,0 +1,137 @@
+"""The BASELINE.json configurations at their REAL extents (not stand-ins) through size-independent properties, the
+bf16 mode against the REFERENCE fixture, and the reference's stored matcher indices on the device path.
+
+  cfg2            configs[1]: T=4, 800x1333, B=2 (maps 400x667 .. 25x42: ragged in every stage)
+  nusc500-stage1  configs[3]: T=3, 448x800, B=4      nusc500-stage2  configs[3]: T=3, 896x1600, B=2
+  t8              configs[4]'s shape in bf16: T=8, 900x1600, B=1, num_images=7 (all seven past frames live)
+"""
+import numpy as np
+import pytest
+import torch
+from types import SimpleNamespace
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+CONFIGS = {"cfg2": (4, 800, 1333, 2, 2), "nusc500-stage1": (3, 448, 800, 4, 2), "nusc500-stage2": (3, 896, 1600, 2, 2),
+           "t8": (8, 900, 1600, 1, 7)}
+
+
+def _build(num_images, seed=0):
+    from future_od.models.st_detr import SpatioTemporalDETRArgs
+    from runs._model import build_model
+    torch.manual_seed(seed)
+    args = SimpleNamespace(device=DEV, distributed=False, compute_dtype="bf16", num_images=num_images)
+    detr = SpatioTemporalDETRArgs(num_classes=8, num_queries=128, lr_backbone=1e-4, pretrained_backbone=False)
+    return build_model(args, detr).eval()
+
+
+def _core(model, data):
+    imu = torch.cat([data[k] for k in model._imu_keys], dim=2)
+    with torch.no_grad():
+        out, _ = model._model(data["video"], imu=imu)
+    return out["pred_logits"].float(), out["pred_boxes"].float()
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_config_at_real_extent(name):
+    from scipy.optimize import linear_sum_assignment
+    from future_od.datasets.synthetic import make_batch
+    from future_od.native import ops
+    T, H, W, B, K = CONFIGS[name]
+    model = _build(K)
+    data = make_batch(B, T, H, W, seed=31, device=DEV)
+    la, ba = _core(model, data)
+    lb, bb = _core(model, data)
+    assert torch.equal(la, lb) and torch.equal(ba, bb)                          # the forward pass is deterministic
+    assert torch.isfinite(la).all() and (ba >= 0).all() and (ba <= 1).all()
+    # a sample's detections do not depend on the rest of the batch (tile choices differ: bf16 rounding only)
+    if B > 1:
+        one = {k: (v[:1] if isinstance(v, torch.Tensor) else v) for k, v in data.items() if k != "_host_annotations"}
+        l1, b1 = _core(model, one)
+        assert float((l1[0] - la[0]).abs().max()) <= 0.05 * float(la[0].abs().max())
+        assert float((b1[0] - ba[0]).abs().max()) <= 2e-2
+    # past frames that cannot reach the output are skipped: same result with them computed
+    if T - 1 > K:
+        model._model.skip_dead_frames = False
+        lf, bf = _core(model, data)
+        model._model.skip_dead_frames = True
+        assert float((la - lf).abs().max()) <= 0.05 * float(lf.abs().max()) and float((ba - bf).abs().max()) <= 2e-2
+    # the device-side matcher on this configuration's outputs = scipy on the same cost matrix, index for index
+    packed = ops.pack_targets_dev(data["boxes"].float().contiguous(), data["classes"].contiguous(),
+                                  data["active"].contiguous(), H, W)
+    cost = ops.match_cost(la[None].contiguous(), ba[None].contiguous(), packed["labels"], packed["boxes"],
+                          packed["offset"], packed["ld"], 2.0, 5.0, 2.0)
+    status = torch.zeros(1, dtype=torch.int32, device=DEV)
+    match = ops.lap_solve_batch_dev(cost, packed["offset"], status).cpu()
+    off = packed["offset"].cpu().tolist()
+    assert int(status.item()) == 0
+    for b in range(B):
+        n = off[b + 1] - off[b]
+        r, c = linear_sum_assignment(cost[0, b, :, :n].cpu().numpy())
+        want = np.full(128, -1, dtype=np.int64)
+        want[r] = c + off[b]
+        assert np.array_equal(match[0, b].numpy().astype(np.int64), want), b
+    # one full step: finite loss, a finite gradient on every trainable parameter, none on the frozen front
+    model.zero_grad(set_to_none=True)
+    _, _, loss, stats, od = model(data=data, distributed=False)
+    loss.backward()
+    assert torch.isfinite(loss)
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        else:
+            assert p.grad is None, n
+
+
+def test_bf16_mode_against_the_reference_fixture(golden):
+    """bf16 MFMA mode against the fixture generated from the REFERENCE's own files (g5_r50_2x2: ResNet-50, 2+2
+    layers): a precision trade, not the parity mode.  Stated tolerance: logits within 6e-2 of their range, boxes within
+    2e-2 absolute, total loss within 5 %, every loss term within 10 % (or 2e-2 absolute), AP bookkeeping counts equal."""
+    from test_model_gpu import CASES, build_product
+    from future_od.datasets.synthetic import make_batch
+    g = golden("g5_r50_2x2")
+    cfg = CASES["g5_r50_2x2"]
+    B, L, H, W, seed = (int(v) for v in g["meta"])
+    model, _ = build_product(cfg, torch.bfloat16, seed)
+    data = make_batch(B, L, H, W, seed=seed, max_boxes=12, device=DEV)
+    out, _, loss, stats, od = model(data=data, distributed=False)
+    with torch.no_grad():
+        raw, _ = model._model(data["video"], imu=torch.cat([data[k] for k in model._imu_keys], dim=2))
+    lg, bx = raw["pred_logits"].float().cpu().numpy(), raw["pred_boxes"].float().cpu().numpy()
+    assert np.abs(lg - g["pred_logits"]).max() <= 6e-2 * np.abs(g["pred_logits"]).max()
+    assert np.abs(bx - g["pred_boxes"]).max() <= 2e-2
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 5e-2 * abs(float(g["loss"]))
+    for k, v in stats.items():
+        ref = float(g["stat_" + k])
+        assert abs(float(v) - ref) <= max(0.1 * abs(ref), 2e-2), (k, float(v), ref)
+    assert np.array_equal(od[3].cpu().numpy(), g["od_num_annos"])
+
+
+def test_reference_matcher_indices_on_the_device_path(golden):
+    """g67_criterion holds logits / boxes / targets and the assignments the REFERENCE's matcher (scipy) produced:
+    the device-side cost + assignment kernels must return exactly those pairs."""
+    from future_od.native import ops
+    g = golden("g67_criterion")
+    case = 0
+    while f"c{case}_logits" in g.files:
+        pre = f"c{case}_"
+        logits, boxes = torch.from_numpy(g[pre + "logits"]), torch.from_numpy(g[pre + "boxes"])
+        nbs = [int(v) for v in g[pre + "nbs"]]
+        B, M, _ = logits.shape
+        off = torch.tensor([0] + list(np.cumsum(nbs)), dtype=torch.int32, device=DEV)
+        tl, tb = torch.from_numpy(g[pre + "tlabels"]).to(DEV), torch.from_numpy(g[pre + "tboxes"]).to(DEV)
+        if tl.numel() == 0:
+            tl, tb = torch.zeros(1, dtype=torch.int64, device=DEV), torch.zeros(1, 4, device=DEV)
+        ld = max(max(nbs), 1)
+        cost = ops.match_cost(logits[None].to(DEV).contiguous(), boxes[None].to(DEV).contiguous(), tl.long(), tb.float(),
+                              off, ld, 2.0, 5.0, 2.0)
+        status = torch.zeros(1, dtype=torch.int32, device=DEV)
+        match = ops.lap_solve_batch_dev(cost, off, status).cpu()[0]
+        assert int(status.item()) == 0
+        for b in range(B):
+            qi = torch.nonzero(match[b] >= 0).flatten()
+            assert np.array_equal(qi.numpy(), g[f"{pre}i{b}"]), (case, b)
+            assert np.array_equal((match[b][qi] - int(off[b])).numpy(), g[f"{pre}j{b}"]), (case, b)
+        case += 1
+    assert case >= 2
