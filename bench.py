@@ -34,6 +34,7 @@ WORKLOADS = {
     "cfg2": (4, 800, 1333, 2, 2, 1.187e12),             # configs[1]: T=4, 800x1333
     "nusc500-stage1": (3, 448, 800, 4, 2, 0.395e12),    # configs[3], runs/nusc_spatiotemporal_imu_500ms.py: 32 / 8 GPUs
     "nusc500-stage2": (3, 896, 1600, 2, 2, 1.601e12),   # configs[3], second stage: 16 / 8 GPUs
+    "t8": (8, 900, 1600, 2, 7, 5.712e12),               # configs[4]'s shape (T=8, all 7 past frames live) in bf16
 }
 LIVE_FLOPS = WORKLOADS["headline"][5]
 
@@ -224,7 +225,7 @@ def main():
         dt = float(t.item())
         summ, nprof = None, 2
         if profile and rank != 0:
-            for _ in range(nprof):                   # the steps hold collectives: every rank runs them, rank 0 measures
+            for _ in range(nprof + 1):               # the steps hold collectives: every rank runs them, rank 0 measures
                 eager_step()
         if profile and rank == 0:
             # every entry point timed with events on the launching stream for a few more (eagerly launched) steps
@@ -235,6 +236,30 @@ def main():
             L.PROFILER.stop()
             summ = L.PROFILER.summary()
         final = float(loss.detach())
+        if distributed and profile:
+            # what the first real multi-GPU run needs to be diagnosable: who took part, how many gradient bytes were
+            # averaged and how, and how much of the communication was NOT hidden behind the backbone's backward
+            seen = torch.ones(1, device=device)
+            dist.all_reduce(seen)
+            red = model.grad_reducer
+            st = dict(red.stats)
+            nbytes = 4 * sum(p.numel() for p in model.module.parameters() if p.requires_grad)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                opt.zero_grad()
+                with model.no_sync():
+                    _o, _s, l2, _st, _od = model(data=data, distributed=distributed)
+                    l2.backward()
+                opt.step()
+            fence()
+            t_ns = torch.tensor([(time.perf_counter() - t1) / 3], device=device)
+            dist.all_reduce(t_ns, op=dist.ReduceOp.MAX)
+            ddp_info.update({"n_ranks_seen": int(seen.item()), "backend": dist.get_backend(),
+                             "grad_allreduce_bytes_per_step": nbytes, "arena_flushes": st["arena_flushes"],
+                             "arena_bytes_in_place": 4 * st["arena_elems"], "straggler_tensors": st["stragglers"],
+                             "ms_per_step_without_comm": 1e3 * float(t_ns.item()),
+                             "exposed_comm_ms_per_step": 1e3 * (dt / steps - float(t_ns.item()))})
         del model, opt, data
         import gc
         gc.collect()
@@ -242,6 +267,7 @@ def main():
         return dt, final, summ, nprof
 
     use_graph = (not distributed) and (not a.no_graph) and (not a.rehearse)
+    ddp_info = {}
     dt, final_loss, summ, nprof = measure(a.num_images, a.dtype, a.steps, a.warmup, not a.no_roofline)
     seqs = BATCH_PER_GPU * world * a.steps
     value = seqs / dt
@@ -261,6 +287,8 @@ def main():
         "final_loss": final_loss,
         "launch_mode": "hipgraph replay (one graph per step)" if use_graph else "eager (one Python call per kernel)",
     }
+    if ddp_info:
+        result["ddp"] = ddp_info
     fl = live_flops_per_sequence(a.num_images)
     if fl:
         result["model_tflops_per_gpu"] = fl * BATCH_PER_GPU * a.steps / dt / 1e12

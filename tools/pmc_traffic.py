@@ -9,6 +9,10 @@ hits are included in both.  Kernels are keyed by the C-ABI entry point they impl
 import collections, csv, glob, json, re, sys
 
 ENTRY = [  # (substring of the kernel name, entry point)
+    ("nt_big_kernel<0>", "fod_gemm_nt"), ("nt_big_kernel<1>", "fod_conv2d_fwd"), ("nt_big_kernel<2>", "fod_conv2d_dgrad"),
+    ("nt_big_kernel<3>", "fod_conv2d_dgrad"), ("conv_stem_fwd_kernel", "fod_conv2d_fwd"),
+    ("stem_layout_kernel", "fod_clip_to_stem_layout"), ("lap_dev_kernel", "fod_lap_solve_batch_dev"),
+    ("pack_targets_kernel", "fod_pack_targets"), ("attn_fwd_lds_kernel", "fod_attn_fwd"),
     ("conv2d_fwd_kernel", "fod_conv2d_fwd"), ("conv2d_dgrad", "fod_conv2d_dgrad"),
     ("conv2d_wgrad_kernel", "fod_conv2d_wgrad_acc"), ("gemm_nt_small_kernel", "fod_gemm_nt"),
     ("gemm_nt_kernel", "fod_gemm_nt"), ("gemm_tn_small_kernel", "fod_gemm_tn_acc"), ("gemm_tn_kernel", "fod_gemm_tn_acc"),
