@@ -281,14 +281,44 @@ class JointEncoderSequential(nn.Module):
         return outs
 
 
+class JointEncoderF2F(nn.Module):
+    """The F2F-style baseline encoder (reference paper.py:237-277; https://arxiv.org/abs/1803.11496): the past frames'
+    feature maps stacked on the channel axis run through seven convolutions (1x1, then 3x3 with dilations 2, 2, 4, 8,
+    2, then 7x7), ReLU between them, and come out as ONE frame.  Same parameter names as the reference's
+    `nn.Sequential` (`f2f_model.{0,2,...,12}.{weight,bias}`); activations stay NHWC = the token layout [B, h*w, D]."""
+
+    LAYERS = ((1, 1), (3, 2), (3, 2), (3, 4), (3, 8), (3, 2), (7, 1))          # (kernel, dilation)
+
+    def __init__(self, hidden_dim, num_frames):
+        super().__init__()
+        from future_od.native.backbone import ConvWeight
+        p, n = hidden_dim, num_frames
+        widths = ((n * p, 2 * p), (2 * p, 2 * p), (2 * p, 2 * p), (2 * p, p), (p, p), (p, p), (p, p))
+        mods = []
+        for (cin, cout), (k, _d) in zip(widths, self.LAYERS):
+            mods += [ConvWeight(cin, cout, k, 1, k // 2, bias=True), nn.ReLU()]
+        self.f2f_model = nn.Sequential(*mods[:-1])
+        self.num_frames = num_frames
+
+    def forward(self, frames, h, w):
+        """frames: list of `num_frames` tensors [B, h*w, D], oldest first -> [B, h*w, D]."""
+        assert len(frames) == self.num_frames, (len(frames), self.num_frames)
+        B, N, D = frames[0].shape
+        x = torch.cat([f.reshape(B, h, w, D) for f in frames], dim=-1)             # channels ordered (l c)
+        convs = [m for m in self.f2f_model if not isinstance(m, nn.ReLU)]
+        for j, (cw, (k, d)) in enumerate(zip(convs, self.LAYERS)):
+            x = Fn.conv2d_same(x, cw.weight, cw.bias, relu=j < len(convs) - 1, dilation=d)
+        return x.reshape(B, N, D)
+
+
 class FuturePredCore(nn.Module):
     """Drop the future frame, encode the past frames, decode the future detections (reference :432-485)."""
 
     def __init__(self, separate_encoder: SeparateEncoder, joint_encoder, detector: CDetrDetectorSpatioTemporal,
                  pos_encoder: PositionalEncoder):
         super().__init__()
-        if joint_encoder is not None and not isinstance(joint_encoder, (JointEncoder, JointEncoderSequential)):
-            raise NotImplementedError("JointEncoderF2F is not instantiated by the reference's runs/ (SURVEY.md 8f-2)")
+        if joint_encoder is not None and not isinstance(joint_encoder, (JointEncoder, JointEncoderSequential, JointEncoderF2F)):
+            raise TypeError(f"unknown joint encoder {type(joint_encoder).__name__}")
         self.separate_encoder = separate_encoder
         self.joint_encoder = joint_encoder
         self.detector = detector
@@ -324,6 +354,13 @@ class FuturePredCore(nn.Module):
             pos_all = lambda: spatial.repeat(keep, 1)                                             # [keep*N, D]
             pos_at = lambda l: spatial
         pos_last = lambda: pos_at(keep - 1)
+        if isinstance(self.joint_encoder, JointEncoderF2F):
+            # all past frames -> ONE frame (reference paper.py:273-277); the detector then runs its first-frame pass with
+            # the LAST frame's positional encoding and, as the reference's loop does, the FIRST frame's IMU token
+            out_tokens = self.joint_encoder(frames, h, w)
+            e = _ego.view(keep, B, D)[0] if (_ego is not None and self.detector.use_egodeep) else None
+            out = self.detector([out_tokens], pos_last(), num_frames_total=1, egodeep=e)
+            return out, [["model happy" for _ in range(L)] for _ in range(B)]
         if isinstance(self.joint_encoder, JointEncoderSequential):
             frames = self.joint_encoder(frames, pos_at, _ego.view(keep, B, D) if _ego is not None else None)
         elif self.joint_encoder is not None:

@@ -496,6 +496,84 @@ def linear_add_norm(a, x, weight, bias, gamma, beta):
 
 
 # ------------------------------------------------------------------------------------------------
+class ConvFn(Function):
+    """y = act(conv2d(x, W) + b) on NHWC activations: a stand-alone trainable convolution (the backbone has its own
+    whole-network node, native/backbone.py).  W is an OIHW parameter (any strides with a dense tap plane), stride 1,
+    padding k // 2.  Backward: ReLU mask, input gradient, weight gradient (f32 atomics into a [Cout][kh][kw][Cin]
+    buffer returned as an OIHW view), bias gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        co, ci, kh, kw = weight.shape
+        geom = ops.conv_geom(x.shape, co, kh, 1, kh // 2)
+        y = ops.conv2d_fwd(x, prep_conv(weight, x.dtype, None, False), geom, shift=bias, relu=relu)
+        ctx.save_for_backward(x, y if relu else None)
+        ctx.weight, ctx.geom, ctx.relu, ctx.has_bias = weight, geom, relu, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        weight, geom = ctx.weight, ctx.geom
+        co, ci, kh, kw = weight.shape
+        g = dy.contiguous()
+        if ctx.relu:
+            g = ops.eltwise(L.EW_RELU_MASK, g.view(-1, co), y.view(-1, co)).view(dy.shape)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_dgrad(g, prep_conv(weight, x.dtype, None, True), geom)
+        if ctx.needs_input_grad[1]:
+            buf = zeros_f32((co, kh, kw, ci), x.device)
+            ops.conv2d_wgrad_acc(g, x, buf, geom, zeroed=True)
+            dw = buf.view(co, ci, 1, 1) if kh == 1 and kw == 1 else buf.permute(0, 3, 1, 2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = zeros_f32((co,), x.device)
+            ops.colsum_acc(g.view(-1, co), db)
+        return dx, dw, db, None
+
+
+def conv2d_same(x, weight, bias=None, relu=False, dilation=1):
+    """NHWC convolution with padding="same", odd kernel, stride 1 and an optional dilation d.  The conv kernels have
+    no dilation argument; a d-dilated convolution IS d*d ordinary convolutions on the pixel-parity sub-grids
+    x[:, i::d, j::d] -> y[:, i::d, j::d] (each sub-grid sees its neighbours at distance d as adjacent; zero padding
+    k // 2 on the sub-grid = d * (k // 2) on the image), so that is what runs -- exact, launch-heavy, and only used
+    by the F2F baseline encoder (reference paper.py:245-261)."""
+    x = x.contiguous()
+    if dilation == 1:
+        return ConvFn.apply(x, weight, bias, relu)
+    B, H, W, _ = x.shape
+    y = torch.empty((B, H, W, weight.shape[0]), dtype=x.dtype, device=x.device)
+    parts = []
+    for i in range(min(dilation, H)):
+        for j in range(min(dilation, W)):
+            parts.append((i, j, ConvFn.apply(x[:, i::dilation, j::dilation].contiguous(), weight, bias, relu)))
+    return _ScatterGridFn.apply(y, dilation, *[t for _, _, t in parts])
+
+
+class _ScatterGridFn(Function):
+    """Interleave the d*d sub-grid results back into one image (parts ordered (i, j) row-major); the gradient of a
+    part is the matching strided slice."""
+
+    @staticmethod
+    def forward(ctx, y, d, *parts):
+        ctx.d = d
+        k = 0
+        H, W = y.shape[1], y.shape[2]
+        for i in range(min(d, H)):
+            for j in range(min(d, W)):
+                y[:, i::d, j::d] = parts[k]
+                k += 1
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        d = ctx.d
+        H, W = g.shape[1], g.shape[2]
+        out = [g[:, i::d, j::d].contiguous() for i in range(min(d, H)) for j in range(min(d, W))]
+        return (None, None) + tuple(out)
+
+
+# ------------------------------------------------------------------------------------------------
 # Dropout (train mode only; eval and p = 0 never reach these).  No mask tensor: the kernel hashes (seed, index),
 # and the backward is the same call on the gradient.  Seeds advance with every call; data-parallel ranks are offset.
 class _DropSeeds:

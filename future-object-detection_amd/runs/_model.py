@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 import future_od.models.transformer as transformer
-from future_od.models.paper import (JointEncoder, JointEncoderSequential, SingleFrameCore, CDetrBackbone, CDetrDetectorSpatioTemporal, FuturePredCore,
+from future_od.models.paper import (JointEncoder, JointEncoderF2F, JointEncoderSequential, SingleFrameCore, CDetrBackbone, CDetrDetectorSpatioTemporal, FuturePredCore,
                                     PositionalEncoder, SeparateEncoder)
 from future_od.models.st_detr import SpatioTemporalDETR, SpatioTemporalDETRArgs
 from future_od.native import functional as Fn
@@ -27,6 +27,8 @@ def _joint_encoder(args, detr_args):
     paper.py's JointEncoder (`joint_mode="joint"`: all frames' tokens at once) or JointEncoderSequential
     (`joint_mode="sequential"`: frame by frame, `joint_prevout` / `joint_previmages` / `joint_egodeep` choosing
     the cross-attention blocks of its layers, reference transformer.py:422-447)."""
+    if getattr(args, "joint_mode", "joint") == "f2f":                      # paper.py:237-277, the F2F baseline encoder
+        return JointEncoderF2F(detr_args.hidden_dim, int(getattr(args, "joint_f2f_frames", 2)))
     n = getattr(args, "joint_layers", 0)
     if not n:
         return None

@@ -51,6 +51,7 @@ class Config:
     joint_previmages: int = 0           # sequential only: transformer.py:439-441 previmage_attn blocks per layer
     joint_prevout: bool = False         # sequential only: transformer.py:435-438 prevout_attn
     joint_egodeep: bool = False         # transformer.py:442-447 IMU attention in the joint layers (keys: 1 token sequential, L tokens joint)
+    joint_f2f_frames: int = 0           # paper.py:237-277 JointEncoderF2F(hidden_dim, num_frames): > 0 = that encoder, for clips of this many past frames
     dec_slotstates: bool = False        # transformer.py:210-215 decoder layers attend to the previous frame's final queries
     dec_egodeep: bool = False           # transformer.py:217-222 decoder layers attend to the frame's IMU token
     single_frame: bool = False          # paper.py:488-528 SingleFrameCore: no frame is dropped, no joint encoder; its
@@ -82,6 +83,15 @@ P_DEC = P_DET + "decoder."
 # ======================================================================================
 # key schema
 # ======================================================================================
+F2F_SLOTS = (0, 2, 4, 6, 8, 10, 12)          # positions of the Conv2d modules in the nn.Sequential (ReLUs between)
+
+
+def f2f_layers(p, n):
+    """(Cin, Cout, kernel, dilation) of JointEncoderF2F's seven convolutions, all padding="same" (paper.py:245-261)."""
+    return [(n * p, 2 * p, 1, 1), (2 * p, 2 * p, 3, 2), (2 * p, 2 * p, 3, 2), (2 * p, p, 3, 4), (p, p, 3, 8),
+            (p, p, 3, 2), (p, p, 7, 1)]
+
+
 def _lin(spec, key, n_out, n_in):
     spec[key + ".weight"] = ((n_out, n_in), "param")
     spec[key + ".bias"] = ((n_out,), "param")
@@ -155,6 +165,11 @@ def param_spec(cfg: Config) -> Dict[str, tuple]:
         _lin(spec, p + "mlp.3", D, Dff)
         _ln(spec, p + "norm2", D)
 
+    if cfg.joint_f2f_frames:                                                        # paper.py:245-261
+        pD, n = cfg.hidden_dim, cfg.joint_f2f_frames
+        for idx, (cin, cout, k, _dil) in zip(F2F_SLOTS, f2f_layers(pD, n)):
+            spec[f"{P_CORE}joint_encoder.f2f_model.{idx}.weight"] = ((cout, cin, k, k), "param")
+            spec[f"{P_CORE}joint_encoder.f2f_model.{idx}.bias"] = ((cout,), "param")
     seq = cfg.joint_mode == "sequential"
     for i in range(cfg.joint_layers):                                               # paper.py:180-183, 206
         p = f"{P_JOINT}{i}."
@@ -590,7 +605,18 @@ def core_forward(sd, cfg, images, imu=None, temporal_offsets=None, skip_dead=Fal
     pos = spatial_pos_table(h, w, D, feat.device)[None, None].expand(B, L, -1, -1, -1)
     if not cfg.no_temporal:
         pos = pos + temporal_pos_table(B, L, h, w, D, temporal_offsets, device=feat.device)
-    if cfg.joint_layers and cfg.joint_mode == "sequential":           # paper.py:219-234
+    if cfg.joint_f2f_frames:                                           # paper.py:263-277: frames stacked on channels
+        assert L == cfg.joint_f2f_frames
+        x = feat.reshape(B, L * D, h, w)                               # "b l c h w -> b (l c) h w"
+        layers = f2f_layers(D, L)
+        for j, (idx, (cin, cout, k, dil)) in enumerate(zip(F2F_SLOTS, layers)):
+            x = F.conv2d(x, sd[f"{P_CORE}joint_encoder.f2f_model.{idx}.weight"],
+                         sd[f"{P_CORE}joint_encoder.f2f_model.{idx}.bias"], 1, dil * (k // 2), dil)
+            if j < len(layers) - 1:
+                x = F.relu(x)
+        feat = x[:, None]                                              # (B, 1, D, h, w); the detector sees ONE frame
+        pos = pos[:, -1:]
+    elif cfg.joint_layers and cfg.joint_mode == "sequential":         # paper.py:219-234
         xs = feat.permute(1, 3, 4, 0, 2).flatten(1, 2)                 # l (h w) b c
         ps = pos.permute(1, 3, 4, 0, 2).flatten(1, 2)
         outs, out, memory = [], None, []

@@ -55,6 +55,8 @@ def import_reference():
 def joint_encoder(cfg: Config, paper, transformer):
     """None (runs/_model.py:52), paper.JointEncoder, or paper.JointEncoderSequential with the reference's own
     TransformerEncoderLayer options (transformer.py:423-447)."""
+    if cfg.joint_f2f_frames:
+        return paper.JointEncoderF2F(cfg.hidden_dim, cfg.joint_f2f_frames)
     if not cfg.joint_layers:
         return None
     seq = cfg.joint_mode == "sequential"
@@ -202,6 +204,10 @@ def main():
         # (the first frame is dead work with num_images = 2)
         "g17_single_frame_core": (Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2,
                                          single_frame=True), 2, 3, 64, 96, 20),
+        # JointEncoderF2F (paper.py:237-277): the frames' feature maps stacked on channels through seven dilated
+        # convolutions; the detector then sees one frame
+        "g19_joint_f2f": (Config(backbone="resnet18", enc_layers=1, dec_layers=1, num_images=2, joint_f2f_frames=2),
+                          2, 3, 96, 160, 21),
         "g16_multikey_egodeep": (Config(backbone="resnet18", enc_layers=1, joint_layers=1, joint_egodeep=True,
                                         dec_layers=2, num_images=1, image_memory_mode="attend all at once",
                                         dec_egodeep=True, no_temporal=False), 2, 4, 64, 96, 19),
@@ -257,6 +263,8 @@ def main():
             "imu_layers.0.weight", "egodeep_attend.value.weight"))]
         named = dict(model.named_parameters())
         for n in picks:
+            if named[n].grad is None:                     # e.g. the second image's attention when the detector sees one frame
+                continue
             idx, val = subsample(named[n].grad, 2048)
             arrays["gidx:" + n], arrays["gval:" + n] = idx, val
         save(name, **arrays)

@@ -584,3 +584,33 @@ def test_big_tile_kernel_dense(monkeypatch, mnk):
     check(out, ref, dtype, math.sqrt(K), f"big dense {mnk}")
     out32 = ops.gemm_nt(a.to(DEV), b.to(DEV), shift=shift.to(DEV), out_f32=True)
     check(out32, a.float() @ b.float().t() + shift, dtype, math.sqrt(K), f"big dense f32 out {mnk}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 9, 13, 64, 64, 3, 2), (1, 12, 10, 64, 128, 3, 4), (1, 7, 11, 128, 64, 3, 8),
+                                  (2, 6, 9, 64, 64, 7, 1), (1, 8, 8, 128, 64, 1, 1)])
+def test_same_padded_dilated_conv_with_gradients(dtype, case):
+    """Fn.conv2d_same: padding="same" convolutions with dilation (as d*d ordinary convolutions on the parity sub-grids)
+    against F.conv2d(dilation=d), forward and all three gradients (the F2F baseline encoder's layers,
+    reference paper.py:245-261)."""
+    from future_od.native import functional as Fn
+    n, h, w_, cin, cout, k, d = case
+    x = rnd((n, h, w_, cin), dtype, 21)
+    wt = rnd((cout, cin, k, k), torch.float32, 22, scale=1.0 / math.sqrt(k * k * cin))
+    b = torch.randn(cout, generator=torch.Generator().manual_seed(23)) * 0.1
+    xg = x.to(DEV).requires_grad_(True)
+    wg = torch.nn.Parameter(wt.contiguous(memory_format=torch.channels_last).to(DEV))
+    bg = torch.nn.Parameter(b.to(DEV))
+    y = Fn.conv2d_same(xg, wg, bg, relu=True, dilation=d)
+    dy = rnd((n, h, w_, cout), dtype, 24)
+    y.backward(dy.to(DEV))
+    x32 = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    w32 = wt.to(dtype).float().requires_grad_(True)          # the kernel sees the weight rounded to the compute dtype
+    b32 = b.clone().requires_grad_(True)
+    ref = F.relu(F.conv2d(x32, w32, b32, 1, d * (k // 2), d))
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    check(y, ref.permute(0, 2, 3, 1), dtype, 2, f"dilated conv fwd {case}")
+    check(xg.grad, x32.grad.permute(0, 2, 3, 1), dtype, 4, f"dilated conv dx {case}")
+    gt = torch.float32 if dtype == torch.float32 else dtype
+    check(wg.grad, w32.grad, gt, math.sqrt(n * h * w_), f"dilated conv dw {case}")
+    check(bg.grad, b32.grad, gt, math.sqrt(n * h * w_), f"dilated conv db {case}")

@@ -19,13 +19,15 @@ DEV = "cuda:0"
 
 if torch.cuda.is_available():
     import future_od.models.transformer as T
-    from future_od.models.paper import (CDetrBackbone, CDetrDetectorSpatioTemporal, FuturePredCore, JointEncoder, JointEncoderSequential, SingleFrameCore,
+    from future_od.models.paper import (CDetrBackbone, CDetrDetectorSpatioTemporal, FuturePredCore, JointEncoder, JointEncoderF2F, JointEncoderSequential, SingleFrameCore,
                                         PositionalEncoder, SeparateEncoder)
     from future_od.models.st_detr import SpatioTemporalDETR, SpatioTemporalDETRArgs
     from future_od.native import functional as Fn
 
 
 def build_joint(cfg: Config):
+    if cfg.joint_f2f_frames:
+        return JointEncoderF2F(cfg.hidden_dim, cfg.joint_f2f_frames)
     if not cfg.joint_layers:
         return None
     seq = cfg.joint_mode == "sequential"
@@ -82,6 +84,7 @@ CASES = {
                                        image_memory_mode="attend all at once", no_temporal=False),
     "g12_one_at_a_time_temporal": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2,
                                          no_temporal=False),
+    "g19_joint_f2f": Config(backbone="resnet18", enc_layers=1, dec_layers=1, num_images=2, joint_f2f_frames=2),
     "g13_joint_encoder": Config(backbone="resnet18", enc_layers=1, joint_layers=1, dec_layers=1, num_images=2,
                                 no_temporal=False),
     "g14_joint_sequential": Config(backbone="resnet18", enc_layers=1, joint_layers=2, joint_mode="sequential",

@@ -72,6 +72,7 @@ CASES = {
                                        image_memory_mode="attend all at once", no_temporal=False),
     "g12_one_at_a_time_temporal": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2,
                                          no_temporal=False),
+    "g19_joint_f2f": Config(backbone="resnet18", enc_layers=1, dec_layers=1, num_images=2, joint_f2f_frames=2),
     "g13_joint_encoder": Config(backbone="resnet18", enc_layers=1, joint_layers=1, dec_layers=1, num_images=2,
                                 no_temporal=False),
     "g14_joint_sequential": Config(backbone="resnet18", enc_layers=1, joint_layers=2, joint_mode="sequential",
