@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   const int fr = lane & 31, fh = lane >> 5;
   const int q0 = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + wave) * 32;
   if (q0 >= p.Tq) return;
+  BLK_STAMP(0);
   const int h = blockIdx.y, b = blockIdx.z;
   const int q = min(q0 + fr, p.Tq - 1);
   const T* Qp[2] = {reinterpret_cast<const T*>(p.q1), reinterpret_cast<const T*>(p.q2)};
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char slab_v[4][2][2048];
   TransTile<T> tv;
 
+  BLK_STAMP(1);
   // (Requesting the next key tile one trip ahead, as the two backward passes do, was measured SLOWER here: at 4
   // waves per SIMD the other waves already cover the L2 round trip, the extra register copies and waits do not.)
   if constexpr (!SPLIT) {
@@ -306,18 +308,44 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
       if (sizeof(T) == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next commit
     }
   } else {
-    for (int k0 = SPLIT ? wave * 32 : 0; k0 < p.S; k0 += SPLIT ? 128 : 32) {
+    // One wave per SIMD here (64 blocks of 4 waves on 256 CUs): nothing else hides a load, and a trip that fetches its
+    // K fragments and then its V rows pays two L2 / HBM round trips (the key / value tensors of the hoisted decoder
+    // layout are 6 KB-strided rows that no other launch has touched).  The next tile's K fragments and V rows are
+    // therefore requested one trip ahead into registers; every request is unconditional (past the end: clamped
+    // re-reads of the last row, masked or unused below), see attn_fwd_lds_kernel.
+    constexpr int KSTEP = SPLIT ? 128 : 32;
+    auto load_k = [&](int k0, Frag<T> (&f)[PARTS][2]) {
       const int kr = min(k0 + fr, p.S - 1);
+#pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+          frag_load_contig(f[pt][s], Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)kr * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
+    };
+    Frag<T> fk_next[PARTS][2];
+    const int kfirst = SPLIT ? wave * 32 : 0;
+    if (kfirst < p.S) {
+      load_k(kfirst, fk_next);
+      if constexpr (sizeof(T) == 2) tv.prefetch(Vp + (long)kfirst * p.v_ts, p.v_ts, p.S - kfirst, lane);
+    }
+    for (int k0 = kfirst; k0 < p.S; k0 += KSTEP) {
+      Frag<T> fk[PARTS][2];
+#pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) fk[pt][s] = fk_next[pt][s];
+      if constexpr (sizeof(T) == 2) tv.commit(slab_v[wave][0], lane);        // V rows of THIS tile: registers -> slab
+      {
+        const int kn = min(k0 + KSTEP, p.S - 1);
+        load_k(kn, fk_next);
+        if constexpr (sizeof(T) == 2) tv.prefetch(Vp + (long)kn * p.v_ts, p.v_ts, p.S - kn, lane);
+      }
       f32x16 sacc;
       zero_acc<T>(sacc);
   #pragma unroll
       for (int pt = 0; pt < PARTS; ++pt)
   #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          Frag<T> fk;
-          frag_load_contig(fk, Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)kr * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
-          mma16(fk, fq[pt][s], sacc);
-        }
+        for (int s = 0; s < 2; ++s) mma16(fk[pt][s], fq[pt][s], sacc);
       float mx = -INFINITY;
   #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -343,7 +371,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] *= drop_gain(p, bh_seed, q0 + fr, k0 + acc_row(r, lane));
       }
-      tv.stage(Vp + (long)k0 * p.v_ts, p.v_ts, p.S - k0, slab_v[wave][0], lane);
+      if constexpr (sizeof(T) == 4) tv.stage(Vp + (long)k0 * p.v_ts, p.v_ts, p.S - k0, slab_v[wave][0], lane);
   #pragma unroll
       for (int s = 0; s < 2; ++s) {
         Frag<T> fp, fv;
@@ -351,8 +379,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         tv.frag(fv, s, lane);
         mma16(fv, fp, oacc);
       }
+      if (sizeof(T) == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next commit
     }
   }
+  BLK_STAMP(2);
   if (SPLIT) {
     __shared__ float s_m[4][32], s_l[4][32], s_o[4][32][33];
     if (fh == 0) {
@@ -387,6 +417,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     store_acc_t<T>(op, oacc, fh, 1.f / l);
     if (fh == 0) p.lse2[((long)b * p.H + h) * p.Tq + q] = m + log2f(l);
   }
+  BLK_STAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------------

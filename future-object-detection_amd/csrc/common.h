@@ -48,8 +48,18 @@ __device__ long long fod_stamps[32];
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)            \
       fod_stamps[i] = wall_clock64();                                                         \
   } while (0)
+// per-block phase stamps (every block, thread 0): tools/probe_tn_big.hip, tools/probe_attn.hip
+__device__ long long fod_blk_stamps[1024][4];
+#define BLK_STAMP(i)                                                                                   \
+  do {                                                                                                 \
+    const int blk__ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                  \
+    if (threadIdx.x == 0 && blk__ < 1024) fod_blk_stamps[blk__][i] = wall_clock64();                   \
+  } while (0)
 #else
 #define FOD_STAMP(i) \
+  do {               \
+  } while (0)
+#define BLK_STAMP(i) \
   do {               \
   } while (0)
 #endif

@@ -23,6 +23,7 @@
 
 #include "common.h"
 #include "gemm_nt.h"
+#include "lds_dma.h"
 
 namespace {
 
@@ -32,28 +33,6 @@ constexpr int BMB = 256, BNB = 128, BKB_EL = 64;
 constexpr int NSTAGE = 3;
 constexpr int STAGE_BYTES = (BMB + BNB) * ROW_BYTES;      // 48 KiB
 constexpr int A_DMA = BMB / 64, B_DMA = BNB / 64;          // DMA instructions per wave and tile (8 waves x 8 rows each)
-typedef __attribute__((address_space(3))) unsigned char* lds_ptr;
-typedef int v4i __attribute__((ext_vector_type(4)));
-
-// One LDS-DMA piece: lane l's 16 bytes at buffer offset `voff` (out of range = zeros) land at LDS byte address
-// lds_addr + 16 l.  Inline asm on purpose: when hipcc sees an LDS-DMA it waits vmcnt(0) before the next ds_read that
-// MAY alias it (any read of the staging ring), which drains the two tiles this loop keeps in flight; the asm form is
-// invisible to that pass, and the loop's own counted s_waitcnt vmcnt(6) + s_barrier order the reads.
-FOD_DEVINL void dma16(v4i rsrc, unsigned lds_addr, unsigned voff) {
-  asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc)
-               : "memory", "m0");
-}
-
-FOD_DEVINL v4i make_rsrc(const void* base, unsigned bytes) {
-  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
-  v4i r;
-  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-  r.y = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xFFFFu));      // stride 0
-  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
-  r.w = 0x00020000;
-  return r;
-}
-
 template <int MODE>
 __global__ __launch_bounds__(512) void nt_big_kernel(const NtParams p) {
   typedef __bf16 T;

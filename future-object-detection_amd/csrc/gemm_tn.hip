@@ -18,27 +18,11 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gemm_tn.h"
 
 namespace {
 
-enum { MODE_DENSE = 0, MODE_CONV = 1 };
-
-struct TnParams {
-  const void* G;
-  const void* X;
-  float* dW;
-  long ldg, ldx, ldw;
-  int M, N1, K2;
-  const float* rscale;
-  float* colsum;     // optional f32 [N1]: += column sums of G (bias gradient), done by the blockIdx.x == 0 blocks
-  int accumulate;    // 0: outputs are all-zero on entry (caller's guarantee) -> a single M-split may plain-store
-  int m_per_split;
-  int tj, ti, nsplit, xcd_order;   // tile grid, number of M-splits, 1 = XCD-grouped 1-D launch
-  unsigned g_bytes, x_bytes;       // operand extents for the buffer descriptors (< 4 GiB, host-checked)
-  int g_seg_cols;                  // short-reduction kernel: G's columns in segments g_seg_stride elements apart
-  long g_seg_stride;               //   (P same-shaped gradient tensors side by side); 0 = plain [M, N1]
-  int Hs, Ws, Cs, Hd, Wd, kh, kw, stride, pad;
-};
+using namespace fodtn;
 
 constexpr int MSTEP = 32;
 
@@ -593,6 +577,13 @@ int pick_splits(int tiles, int M) {
 
 template <int MODE>
 int launch_tn(int dtype, TnParams& p, hipStream_t stream) {
+  if (big_applies(MODE, dtype, p)) {        // long bf16 reductions: the 8-wave LDS-DMA kernel (gemm_tn_big.hip)
+    if (p.colsum) {
+      const int rc = fod_colsum_acc(dtype, p.G, p.ldg, p.M, p.N1, 0, p.colsum, stream);
+      if (rc != FOD_OK) return rc;
+    }
+    return launch_big_mode(MODE, p, stream);
+  }
   const int tj = ceil_div(p.K2, 128), ti = ceil_div(p.N1, 128);
   int splits = pick_splits(ti * tj, p.M);
   static const char* env_rows = getenv("FOD_TN_ROWS");       // experiment knobs (tools/): rows per split, XCD order

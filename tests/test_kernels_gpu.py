@@ -614,3 +614,58 @@ def test_same_padded_dilated_conv_with_gradients(dtype, case):
     gt = torch.float32 if dtype == torch.float32 else dtype
     check(wg.grad, w32.grad, gt, math.sqrt(n * h * w_), f"dilated conv dw {case}")
     check(bg.grad, b32.grad, gt, math.sqrt(n * h * w_), f"dilated conv db {case}")
+
+
+# The 8-wave LDS-DMA weight-gradient kernel (gemm_tn_big.hip) normally takes only long reductions; FOD_TN_BIG=2 routes
+# every legal bf16 problem through it: ragged tiles in both tile shapes, M-splits (plain and XCD-grouped order), the
+# conv gather with stride / padding / image wrap inside a stage, row scales, accumulation into a non-zero buffer.
+@pytest.mark.parametrize("splits", [0, 3, 8])
+@pytest.mark.parametrize("mnk", [(1000, 40, 72), (4097, 8, 64), (777, 264, 136), (3000, 384, 520), (130, 256, 128),
+                                 (64, 128, 256), (2111, 512, 128)])
+def test_tn_big_kernel_dense(monkeypatch, mnk, splits):
+    monkeypatch.setenv("FOD_TN_BIG", "2")
+    monkeypatch.setenv("FOD_TN_SMALL", "0")
+    if splits:
+        monkeypatch.setenv("FOD_TN_BIG_SPLITS", str(splits))
+    dtype = torch.bfloat16
+    M, N1, K2 = mnk
+    g, x = rnd((M, N1), dtype, 1), rnd((M, K2), dtype, 2)
+    rs = torch.rand(N1) + 0.5
+    dw0 = torch.randn(N1, K2)
+    ref = dw0 + (g.float().t() @ x.float()) * rs[:, None]
+    dw = dw0.clone().to(DEV)
+    ops.gemm_tn_acc(g.to(DEV), x.to(DEV), dw, row_scale=rs.to(DEV))
+    check(dw, ref, dtype, math.sqrt(M), f"tn big {mnk}")
+    dw2, cs = torch.zeros(N1, K2, device=DEV), torch.zeros(N1, device=DEV)
+    ops.gemm_tn_acc(g.to(DEV), x.to(DEV), dw2, colsum=cs, zeroed=True)
+    check(dw2, g.float().t() @ x.float(), dtype, math.sqrt(M), f"tn big {mnk} zeroed")
+    check(cs, g.float().sum(0), torch.float32, math.sqrt(M), "tn big colsum")
+
+
+TN_BIG_CONV_CASES = BIG_CONV_CASES + [(2, 17, 23, 8, 64, 7, 2, 3), (1, 29, 50, 32, 40, 3, 1, 1), (2, 57, 100, 256, 256, 3, 1, 1),
+                                      (3, 7, 5, 64, 128, 3, 1, 1), (2, 30, 41, 128, 256, 1, 2, 0)]
+
+
+@pytest.mark.parametrize("splits", [0, 5])
+@pytest.mark.parametrize("case", TN_BIG_CONV_CASES)
+def test_tn_big_kernel_conv(monkeypatch, case, splits):
+    dtype = torch.bfloat16
+    n, h, w_, cin, cout, k, stride, pad = case
+    x = rnd((n, h, w_, cin), dtype, 1)
+    geom = ops.conv_geom(x.shape, cout, k, stride, pad)
+    dy = rnd((n, geom.Ho, geom.Wo, cout), dtype, 4)
+    x32 = x.float().permute(0, 3, 1, 2)
+    w32 = torch.zeros(cout, cin, k, k, requires_grad=True)
+    F.conv2d(x32, w32, None, stride, pad).backward(dy.float().permute(0, 3, 1, 2))
+    rs = torch.rand(cout) + 0.5
+    ref = (w32.grad * rs.view(-1, 1, 1, 1)).permute(0, 2, 3, 1)
+    monkeypatch.setenv("FOD_TN_BIG", "2")
+    if splits:
+        monkeypatch.setenv("FOD_TN_BIG_SPLITS", str(splits))
+    dw = torch.zeros((cout, k, k, cin), device=DEV)
+    ops.conv2d_wgrad_acc(dy.to(DEV), x.to(DEV), dw, geom, row_scale=rs.to(DEV))
+    check(dw, ref, dtype, math.sqrt(n * geom.Ho * geom.Wo), f"tn big conv wgrad {case}")
+    monkeypatch.setenv("FOD_TN_BIG", "0")
+    dw_small = torch.zeros((cout, k, k, cin), device=DEV)
+    ops.conv2d_wgrad_acc(dy.to(DEV), x.to(DEV), dw_small, geom, row_scale=rs.to(DEV))
+    check(dw, dw_small, torch.float32, math.sqrt(n * geom.Ho * geom.Wo) * 8, "tn big vs 128 x 128 kernel (f32 summation order only)")
