@@ -314,59 +314,71 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     // therefore requested one trip ahead into registers; every request is unconditional (past the end: clamped
     // re-reads of the last row, masked or unused below), see attn_fwd_lds_kernel.
     constexpr int KSTEP = SPLIT ? 128 : 32;
-    auto load_k = [&](int k0, Frag<T> (&f)[PARTS][2]) {
+    Frag<T> fk_next[PARTS][2];
+    uint4 v_next0 = make_uint4(0, 0, 0, 0), v_next1 = make_uint4(0, 0, 0, 0);   // (two scalars: an array went to scratch)
+    auto request = [&](int k0) {           // tile at k0 (< S): K row fragments and the 32 x 64 B V rows, into registers
       const int kr = min(k0 + fr, p.S - 1);
 #pragma unroll
       for (int pt = 0; pt < PARTS; ++pt)
 #pragma unroll
         for (int s = 0; s < 2; ++s)
-          frag_load_contig(f[pt][s], Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)kr * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
+          frag_load_contig(fk_next[pt][s], Kp[pt] + (long)b * (pt ? p.k2_bs : p.k_bs) + (long)kr * (pt ? p.k2_ts : p.k_ts) + h * 32 + 16 * s + 8 * fh);
+      if constexpr (sizeof(T) == 2) {
+        const int r0 = min(k0 + (lane >> 2), p.S - 1), r1 = min(k0 + (lane >> 2) + 16, p.S - 1);   // past S: finite
+        v_next0 = *reinterpret_cast<const uint4*>(Vp + (long)r0 * p.v_ts + (lane & 3) * 8);       // duplicates, P = 0
+        v_next1 = *reinterpret_cast<const uint4*>(Vp + (long)r1 * p.v_ts + (lane & 3) * 8);
+      }
     };
-    Frag<T> fk_next[PARTS][2];
     const int kfirst = SPLIT ? wave * 32 : 0;
-    if (kfirst < p.S) {
-      load_k(kfirst, fk_next);
-      if constexpr (sizeof(T) == 2) tv.prefetch(Vp + (long)kfirst * p.v_ts, p.v_ts, p.S - kfirst, lane);
-    }
+    if (kfirst < p.S) request(kfirst);
     for (int k0 = kfirst; k0 < p.S; k0 += KSTEP) {
       Frag<T> fk[PARTS][2];
 #pragma unroll
       for (int pt = 0; pt < PARTS; ++pt)
 #pragma unroll
         for (int s = 0; s < 2; ++s) fk[pt][s] = fk_next[pt][s];
-      if constexpr (sizeof(T) == 2) tv.commit(slab_v[wave][0], lane);        // V rows of THIS tile: registers -> slab
-      {
-        const int kn = min(k0 + KSTEP, p.S - 1);
-        load_k(kn, fk_next);
-        if constexpr (sizeof(T) == 2) tv.prefetch(Vp + (long)kn * p.v_ts, p.v_ts, p.S - kn, lane);
+      if constexpr (sizeof(T) == 2) {                                    // V rows of THIS tile: registers -> slab
+        *reinterpret_cast<uint4*>(slab_v[wave][0] + slab_at(lane >> 2, lane & 3)) = v_next0;
+        *reinterpret_cast<uint4*>(slab_v[wave][0] + slab_at((lane >> 2) + 16, lane & 3)) = v_next1;
+        tv.adopt(slab_v[wave][0]);
       }
+      request(min(k0 + KSTEP, p.S - 1));
       f32x16 sacc;
       zero_acc<T>(sacc);
   #pragma unroll
       for (int pt = 0; pt < PARTS; ++pt)
   #pragma unroll
         for (int s = 0; s < 2; ++s) mma16(fk[pt][s], fq[pt][s], sacc);
-      float mx = -INFINITY;
+      // The loop is bound by the vector unit (one wave per SIMD, ~190 vector instructions per 32 keys against 6 MFMAs):
+      // keys past S are masked on the wave's last tile only, the scale rides in the exponent's fma (as in the other
+      // path and in the backward passes), O is rescaled only when some row's maximum moved.
+      if (k0 + 32 > p.S) {
   #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool ok = (k0 + acc_row(r, lane)) < p.S;
-        sacc[r] = ok ? sacc[r] * c : -INFINITY;
-        mx = fmaxf(mx, sacc[r]);
+        for (int r = 0; r < 16; ++r)
+          if (k0 + acc_row(r, lane) >= p.S) sacc[r] = -INFINITY;
       }
+      float mxa[4];
+  #pragma unroll
+      for (int u4 = 0; u4 < 4; ++u4) mxa[u4] = sacc[u4];
+  #pragma unroll
+      for (int r = 4; r < 16; ++r) mxa[r & 3] = fmaxf(mxa[r & 3], sacc[r]);
+      float mx = fmaxf(fmaxf(mxa[0], mxa[1]), fmaxf(mxa[2], mxa[3]));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m, mx);
+      const float m_new = fmaxf(m, mx * c);        // c > 0: the max of the scaled scores
       const float alpha = ex2(m - m_new);
       float rs = 0.f;
   #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        sacc[r] = ex2(sacc[r] - m_new);
+        sacc[r] = ex2(fmaf(sacc[r], c, -m_new));
         rs += sacc[r];
       }
       rs += __shfl_xor(rs, 32);
       l = l * alpha + rs;
       m = m_new;
+      if (__any(alpha != 1.f)) {
   #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+        for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+      }
       if (DROP) {                                  // the row sums above are of the undropped probabilities
   #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] *= drop_gain(p, bh_seed, q0 + fr, k0 + acc_row(r, lane));
@@ -439,6 +451,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 //     shuffle per tile on the vector pipe.
 // Per 64 keys and wave: 32 v_exp_f32 + 16 v_max3 + 16 v_cvt_pk on the vector pipe (~420 issue cycles) against 12
 // MFMAs (384 cycles): the two pipes are balanced instead of 3 : 1.
+// tools/probe_attn.hip builds this kernel once more with FOD_PROBE_KSTEPS = 1: HALF of every matrix product (wrong results,
+// same loads, softmax, LDS traffic and barriers) -- how much of the kernel's time the matrix pipe accounts for, i.e.
+// what a faster (fp8) MFMA could buy at best.  2 = the product.
+#ifndef FOD_PROBE_KSTEPS
+#define FOD_PROBE_KSTEPS 2
+#endif
 template <int PARTS, int NW>
 __global__ __launch_bounds__(NW * 64, PARTS == 1 ? 4 : 3) void attn_fwd_lds_kernel(const AttnParams p) {
   typedef __bf16 T;
@@ -519,7 +537,7 @@ __global__ __launch_bounds__(NW * 64, PARTS == 1 ? 4 : 3) void attn_fwd_lds_kern
 #pragma unroll
         for (int pt = 0; pt < PARTS; ++pt)
 #pragma unroll
-          for (int s = 0; s < 2; ++s) {
+          for (int s = 0; s < FOD_PROBE_KSTEPS; ++s) {
             Frag<T> fk;
             const uint4 v = *reinterpret_cast<const uint4*>(&tiles[buf][pt][t][0] + slab_at(fr, 2 * s + fh));
             __builtin_memcpy(&fk, &v, 16);
@@ -569,7 +587,7 @@ __global__ __launch_bounds__(NW * 64, PARTS == 1 ? 4 : 3) void attn_fwd_lds_kern
       for (int t = 0; t < 2; ++t) {
         tv.adopt(&tiles[buf][PARTS][t][0]);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < FOD_PROBE_KSTEPS; ++s) {
           Frag<T> fp, fv;
           frag_from_acc(fp, sacc[t], s);
           tv.frag(fv, s, lane);

@@ -248,6 +248,18 @@ def _async_lap(device):
     return _ASYNC_LAP[key]
 
 
+def join_matchers():
+    """Surface a matcher failure NOW instead of at the next submission: joins every parked host job and reads the device
+    solver's status word after a stream sync.  The reference (scipy) raises inside the step; here the error normally
+    arrives one step late, so the LAST iteration of an epoch or an evaluation would otherwise never report it
+    (Trainer._run_epoch calls this when its loop ends)."""
+    for lap in list(_ASYNC_LAP.values()):
+        lap.join()
+    for st in list(_LAP_STATUS.values()):
+        st.publish()
+        st.check(wait=True)
+
+
 _WAIT_SUPPORT = {}
 
 
@@ -327,11 +339,20 @@ def _host_group():
         if dist.get_backend() == "gloo":
             _HOST_GROUP.append(None)
         else:
+            group, err = "device", None
             try:
-                _HOST_GROUP.append(dist.new_group(backend="gloo"))
-            except Exception as e:                       # no usable host transport: fall back to the device group
-                print(f"[fod] no gloo group for host-side scalars ({e}); using a device all-reduce (one host stall per step)")
-                _HOST_GROUP.append("device")
+                group = dist.new_group(backend="gloo")
+            except Exception as e:                       # no usable host transport on THIS rank
+                err = e
+            # new_group is a collective but fails rank by rank: a rank that fell back to the device group while the
+            # others all-reduce on gloo would hang the first forward.  Agree on the outcome over the default group.
+            ok = torch.tensor([0.0 if err is not None else 1.0], device=torch.device("cuda", torch.cuda.current_device()))
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) < 1.0:
+                print(f"[fod] no gloo group for host-side scalars on every rank ({err}); "
+                      "using a device all-reduce (one host stall per step)")
+                group = "device"
+            _HOST_GROUP.append(group)
     return _HOST_GROUP[0]
 
 

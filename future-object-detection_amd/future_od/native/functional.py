@@ -589,7 +589,18 @@ class _DropSeeds:
                 rank = dist.get_rank()
         except Exception:
             rank = 0
-        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + (rank << 40) + self.count) & 0xFFFFFFFFFFFFFFFF
+        return mix64(torch.initial_seed() * 0x9E3779B97F4A7C15 + (rank << 40) + self.count)
+
+
+def mix64(x):
+    """splitmix64 finaliser.  The kernels hash (index ^ seed_lo) * C + seed_hi: seeds that differ only in their low
+    word (a plain call counter) give masks that are index-XOR permutations of one another -- adjacent dropout sites
+    and consecutive steps would share one mask up to a neighbour swap.  Every bit of the mixed seed depends on every
+    bit of the counter, so consecutive calls differ in both words."""
+    x &= 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return x ^ (x >> 31)
 
 
 DROP_SEEDS = _DropSeeds()

@@ -93,10 +93,9 @@ class FusedAdamW(torch.optim.Optimizer):
                 bc.append(c)
         up = [self._upload(x, dev) for x in (ptrs, numel, lr_wd, torch.tensor(bt, dtype=torch.int32),
                                              torch.tensor(bc, dtype=torch.int32))]
-        # pinned copies of the pointer table, used in turn when only gradient addresses move between steps; the
-        # launching thread runs at most one step ahead of the GPU (the matcher joins its previous job at each
-        # submission, or blocks on the cost matrices in the host-synchronous mode), so three buffers are never in
-        # flight at once
+        # pinned copies of the pointer table, used in turn when only gradient addresses move between steps; each slot
+        # carries an event recorded after its upload (see _refresh_grad_pointers), so a slot is never rewritten while
+        # a copy that reads it is still queued
         ring = [up[0][1], up[0][1].clone().pin_memory(), up[0][1].clone().pin_memory()]
         self._keep = [u[1] for u in up]
         return tuple(u[0] for u in up), ring
@@ -123,9 +122,18 @@ class FusedAdamW(torch.optim.Optimizer):
             return False
         if gptrs != plan["gptrs"]:
             plan["turn"] = (plan["turn"] + 1) % len(plan["ring"])
-            host = plan["ring"][plan["turn"]]
+            turn = plan["turn"]
+            # the ring is safe by itself: a slot is rewritten only after the upload that last read it has executed (the
+            # event is normally long complete; a loop without the matcher's one-step bound simply waits here)
+            done = plan.setdefault("ring_events", [None] * len(plan["ring"]))
+            if done[turn] is not None:
+                done[turn].synchronize()
+            host = plan["ring"][turn]
             host[:, 1] = torch.tensor(gptrs, dtype=torch.int64)
             plan["tab"][0].copy_(host, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            done[turn] = ev
             plan["gptrs"] = gptrs
         return True
 

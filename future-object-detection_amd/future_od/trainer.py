@@ -6,6 +6,7 @@ import os
 import torch
 import torch.distributed as distrib
 
+from future_od.models.set_criterion import join_matchers
 from future_od.utils.distributed import EXIT, gather_distrib_od_map_stuffs, reduce_distrib_loss
 from future_od.utils.od_map import aggregate_mean_average_precision
 from future_od.utils.prefetch import DevicePrefetcher
@@ -178,6 +179,7 @@ class Trainer:
                 print(f"[{mode}: {self._epoch}, {i + 1:4d}/{len(data_loader)}] Loss: {msg}.")
         if pending is not None:
             consume(pending)
+        join_matchers()                    # a matcher failure of the last iteration is raised here, not lost
         msg = "  ".join(f"{self._stats[f'{mode} {k} loss'].avg:.5f} ({k})" for k in stat_keys)
         print(f"[{mode}: {self._epoch}] Loss: {msg}")
         if not od_lists[0]:

@@ -669,3 +669,23 @@ def test_tn_big_kernel_conv(monkeypatch, case, splits):
     dw_small = torch.zeros((cout, k, k, cin), device=DEV)
     ops.conv2d_wgrad_acc(dy.to(DEV), x.to(DEV), dw_small, geom, row_scale=rs.to(DEV))
     check(dw, dw_small, torch.float32, math.sqrt(n * geom.Ho * geom.Wo) * 8, "tn big vs 128 x 128 kernel (f32 summation order only)")
+
+
+def test_dropout_masks_of_consecutive_calls_are_not_index_permutations():
+    """the kernels hash (index ^ seed_lo) * C + seed_hi, so seeds that differ only in the low word give masks
+    that are XOR-index permutations of each other.  The call counter now goes through a 64-bit mixer: masks of
+    consecutive calls must agree with every XOR-shifted copy of their predecessor only at the chance rate."""
+    from future_od.native import functional as Fn
+    n, p = 1 << 16, 0.3
+    ones = torch.ones(n // 8, 8, device=DEV, dtype=torch.bfloat16)
+    seeds = [Fn.DROP_SEEDS.next() for _ in range(4)]
+    assert len({s & 0xFFFFFFFF for s in seeds}) == 4 and len({s >> 32 for s in seeds}) == 4
+    masks = [(ops.dropout(ones, p, s).flatten() != 0).cpu() for s in seeds]
+    keep = 1.0 - p
+    chance = keep * keep + p * p
+    idx = torch.arange(n)
+    for a, b in zip(masks, masks[1:]):
+        assert abs(float(a.float().mean()) - keep) < 0.01
+        for d in (0, 1, 2, 3, 4, 7, 8, 255):
+            agree = float((b == a[idx ^ d]).float().mean())
+            assert abs(agree - chance) < 0.02, (d, agree, chance)

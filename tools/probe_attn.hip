@@ -24,7 +24,7 @@ int main() {
   hipEventCreate(&e0); hipEventCreate(&e1);
   struct Case { const char* name; int B, H, Tq, S, parts; long kts; };
   const Case cases[] = {{"cross compact", 2, 8, 128, 1450, 2, 256}, {"cross hoisted (6 KB rows)", 2, 8, 128, 1450, 2, 3072},
-                        {"self 128x128", 2, 8, 128, 128, 1, 256}};
+                        {"self 128x128", 2, 8, 128, 128, 1, 256}, {"encoder self 10x8x1450x1450", 10, 8, 1450, 1450, 1, 256}};
   for (auto& c : cases)
     for (int rep = 0; rep < 3; ++rep) {
       fod_attn_shape s = {};
@@ -41,6 +41,16 @@ int main() {
       hipDeviceSynchronize();
       float ms; hipEventElapsedTime(&ms, e0, e1);
       if (rep < 2) continue;
+      if (c.Tq > 512) {                      // LDS kernel (no block stamps): event time over 10 launches
+        hipEventRecord(e0, 0);
+        for (int it = 0; it < 10; ++it)
+          fod_attn_fwd(FOD_BF16, q, k, c.parts == 2 ? q : nullptr, c.parts == 2 ? k2 : nullptr, v, o, lse, &s, 0);
+        hipEventRecord(e1, 0);
+        hipDeviceSynchronize();
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("%-28s k-steps per product %d of 2: %.1f us per launch\n", c.name, FOD_PROBE_KSTEPS, ms * 100.f);
+        continue;
+      }
       static long long h[1024][4];
       hipMemcpyFromSymbol(h, HIP_SYMBOL(fod_blk_stamps), sizeof(h));
       const int nb = (c.Tq / 32) * c.H * c.B;
