@@ -190,7 +190,9 @@ def main():
     def measure(num_images, dtype, steps, warmup, profile):
         """Build the model, run `warmup` untimed and exactly `steps` timed steps between fences; returns
         (seconds over the timed steps -- max over ranks, final loss, profiler summary or None, profiled steps)."""
-        model, detr = build(a, device, distributed, num_images, dtype)
+        # data parallel + graphs: the bare model (GraphedStep averages the gradients itself between its two graphs);
+        # data parallel, eager: the FodDataParallel wrapper with its side-stream reducer
+        model, detr = build(a, device, distributed and not use_graph, num_images, dtype)
         model.eval()     # BASELINE.md: forward + backward in model.eval() with autograd on (dropout off, FrozenBN)
         opt = FusedAdamW(model.parameters(), lr=detr.lr, weight_decay=detr.weight_decay, max_norm=detr.max_norm)
         data = make_batch(BATCH_PER_GPU, T_FRAMES, HEIGHT, WIDTH, seed=1234 + rank, device=device)
@@ -207,7 +209,9 @@ def main():
             # the same step -- same kernels, same order -- captured once and replayed (future_od/graph.py); the
             # capture and its eager warm-up steps happen before the timed region
             from future_od.graph import GraphedStep
-            graphed = GraphedStep(model, opt, warmup=2)
+            graphed = GraphedStep(model, opt, warmup=2, data_parallel=distributed)
+            if distributed:
+                graphed.broadcast_parameters()
             graphed(data)
             step = lambda: graphed(data)[1]
 
@@ -241,32 +245,45 @@ def main():
             # averaged and how, and how much of the communication was NOT hidden behind the backbone's backward
             seen = torch.ones(1, device=device)
             dist.all_reduce(seen)
-            red = model.grad_reducer
-            st = dict(red.stats)
-            nbytes = 4 * sum(p.numel() for p in model.module.parameters() if p.requires_grad)
+            st = dict(model.grad_reducer.stats) if not use_graph else {}
+            nbytes = 4 * sum(p.numel() for p in getattr(model, "module", model).parameters() if p.requires_grad)
             fence()
             t1 = time.perf_counter()
             for _ in range(3):
-                opt.zero_grad()
-                with model.no_sync():
-                    _o, _s, l2, _st, _od = model(data=data, distributed=distributed)
-                    l2.backward()
-                opt.step()
+                if use_graph:
+                    graphed(data, sync=False)        # same graphs, no gradient average (the LAST thing this model does)
+                else:
+                    opt.zero_grad()
+                    with model.no_sync():
+                        _o, _s, l2, _st, _od = model(data=data, distributed=distributed)
+                        l2.backward()
+                    opt.step()
             fence()
             t_ns = torch.tensor([(time.perf_counter() - t1) / 3], device=device)
             dist.all_reduce(t_ns, op=dist.ReduceOp.MAX)
             ddp_info.update({"n_ranks_seen": int(seen.item()), "backend": dist.get_backend(),
-                             "grad_allreduce_bytes_per_step": nbytes, "arena_flushes": st["arena_flushes"],
-                             "arena_bytes_in_place": 4 * st["arena_elems"], "straggler_tensors": st["stragglers"],
+                             "grad_allreduce_bytes_per_step": nbytes,
                              "ms_per_step_without_comm": 1e3 * float(t_ns.item()),
                              "exposed_comm_ms_per_step": 1e3 * (dt / steps - float(t_ns.item()))})
+            if use_graph:
+                ddp_info.update({"mode": "graph A (forward + backward) -> eager all-reduce -> graph B (clip + AdamW)",
+                                 "allreduce_tensors": graphed.comm_stats["tensors"],
+                                 "allreduce_bytes": graphed.comm_stats["bytes"]})
+            else:
+                ddp_info.update({"mode": "eager launches, arena regions all-reduced in place on a side stream during "
+                                         "the backbone's backward",
+                                 "arena_flushes": st["arena_flushes"], "arena_bytes_in_place": 4 * st["arena_elems"],
+                                 "straggler_tensors": st["stragglers"]})
         del model, opt, data
         import gc
         gc.collect()
         torch.cuda.empty_cache()
         return dt, final, summ, nprof
 
-    use_graph = (not distributed) and (not a.no_graph) and (not a.rehearse)
+    # N = 1: the whole step is one hipGraph.  N > 1: two graphs (forward + backward, clip + AdamW) with the gradient
+    # all-reduce launched eagerly between them (future_od/graph.py); --no-graph: every kernel launched from Python with
+    # the all-reduces overlapped with the backbone's backward (future_od/parallel.py)
+    use_graph = not a.no_graph
     ddp_info = {}
     dt, final_loss, summ, nprof = measure(a.num_images, a.dtype, a.steps, a.warmup, not a.no_roofline)
     seqs = BATCH_PER_GPU * world * a.steps
@@ -285,7 +302,9 @@ def main():
                    "global_batch": BATCH_PER_GPU * world, "frames": T_FRAMES, "resolution": [HEIGHT, WIDTH],
                    "num_images": a.num_images, "parallelism": f"dp{world}"},
         "final_loss": final_loss,
-        "launch_mode": "hipgraph replay (one graph per step)" if use_graph else "eager (one Python call per kernel)",
+        "launch_mode": ("eager (one Python call per kernel)" if not use_graph else
+                        "hipgraph replay (one graph per step)" if not distributed else
+                        "hipgraph replay (forward + backward graph, eager gradient all-reduce, optimizer graph)"),
     }
     if ddp_info:
         result["ddp"] = ddp_info

@@ -43,6 +43,53 @@ __global__ __launch_bounds__(256) void multi_sqnorm_kernel(const long* __restric
   if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+// The same sum with a FIXED summation order: every block stores its partial, takes a ticket, and the block that draws
+// the last ticket adds the partials in index order (no spinning: nobody waits for anybody).  Data-parallel ranks that
+// hold equal gradients then compute bit-equal norms -- with the atomic form above the clip factor differs in its last
+// bit from rank to rank and the replicas drift apart (tests/test_parallel_gpu.py measured 1 ulp after 7 steps).
+__global__ __launch_bounds__(256) void multi_sqnorm_det_kernel(const long* __restrict__ ptrs, const long* __restrict__ numel,
+                                                               const int* __restrict__ blk_tensor,
+                                                               const int* __restrict__ blk_chunk, float* __restrict__ out,
+                                                               float* __restrict__ partial, unsigned* __restrict__ ticket) {
+  __shared__ float red[4];
+  __shared__ bool last;
+  const int t = blk_tensor[blockIdx.x];
+  const long base = (long)blk_chunk[blockIdx.x] * CHUNK;
+  const long end = min(numel[t], base + CHUNK);
+  const float* g = reinterpret_cast<const float*>(ptrs[t * 4 + 1]);
+  float s = 0.f;
+  if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+    const long end4 = base + ((end - base) & ~3L);
+    for (long i = base + 4 * threadIdx.x; i < end4; i += 1024) {
+      const float4 q = *reinterpret_cast<const float4*>(g + i);
+      s += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    }
+    for (long i = end4 + threadIdx.x; i < end; i += 256) s += g[i] * g[i];
+  } else {
+    for (long i = base + threadIdx.x; i < end; i += 256) s += g[i] * g[i];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    __threadfence();                                   // the partial is visible device-wide before the ticket is
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();                                     // acquire: every other block's partial
+  float a = 0.f;
+  for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) a += __builtin_nontemporal_load(partial + i);
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+    *ticket = 0u;                                      // ready for the next launch (stream-ordered)
+  }
+}
+
 __global__ __launch_bounds__(256) void multi_adamw_kernel(const long* __restrict__ ptrs, const long* __restrict__ numel,
                                                           const float* __restrict__ lr_wd,
                                                           const int* __restrict__ blk_tensor,
@@ -100,6 +147,15 @@ extern "C" int fod_multi_sqnorm_acc(const long* ptrs, const long* numel, const i
                                     int nblocks, float* out, hipStream_t stream) {
   FOD_REQUIRE(ptrs && numel && blk_tensor && blk_chunk && out && nblocks > 0, "multi_sqnorm: bad args");
   hipLaunchKernelGGL(multi_sqnorm_kernel, dim3(nblocks), dim3(256), 0, stream, ptrs, numel, blk_tensor, blk_chunk, out);
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
+}
+
+extern "C" int fod_multi_sqnorm_det(const long* ptrs, const long* numel, const int* blk_tensor, const int* blk_chunk,
+                                    int nblocks, float* out, float* scratch, hipStream_t stream) {
+  FOD_REQUIRE(ptrs && numel && blk_tensor && blk_chunk && out && scratch && nblocks > 0, "multi_sqnorm_det: bad args");
+  hipLaunchKernelGGL(multi_sqnorm_det_kernel, dim3(nblocks), dim3(256), 0, stream, ptrs, numel, blk_tensor, blk_chunk, out,
+                     scratch + 1, reinterpret_cast<unsigned*>(scratch));
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }

@@ -12,11 +12,20 @@ costs the host one call.  What made the step capturable:
     are read from a device table that `sync_hyperparams` rewrites in place;
   * every kernel takes raw pointers + the stream, allocates nothing and keeps no state (include/fod.h conventions).
 
-Restrictions (checked): one device, no data-parallel gradient reducer (its side-stream collectives are not captured),
-dropout inactive (eval-mode math or p = 0: a captured kernel would replay the same mask), static shapes -- a batch
-with other shapes is re-captured.
+Data parallel (`GraphedStep(bare_model, opt, data_parallel=True)`): the step is TWO graphs with the collectives between them, launched eagerly --
+    [graph A: zero_grad, forward, backward]  ->  all_reduce(AVG) of the flat gradient arena (one large message, plus the
+    few gradients autograd allocated itself)  ->  [graph B: clip + AdamW].
+No collective is captured (RCCL inside a hipGraph could not be verified on the one-GPU boxes this was built on; a hang
+there would void a whole scaling run): the loss normaliser `num_boxes`, the only collective of the forward pass, is
+all-reduced from the batch's annotations BEFORE graph A and fed in as an input (`data["_num_boxes"]`).  The gradient
+average is therefore not overlapped with the backward pass (215 MB over xGMI, ~1-2 ms at 8 GPUs), which costs less than
+the ~6 ms per step the eagerly launched data-parallel step loses to the launching thread (bench.py --no-graph).
+
+Restrictions (checked): one device per process, dropout inactive (eval-mode math or p = 0: a captured kernel would
+replay the same mask), static shapes -- a batch with other shapes is re-captured.
 """
 import torch
+import torch.distributed as dist
 
 from future_od.native import functional as Fn
 
@@ -28,10 +37,25 @@ class GraphedStep:
     rolled back) and captures one more; later calls copy the batch into the captured input buffers and replay.
     Returned tensors are the graph's static outputs: valid until the next call."""
 
-    def __init__(self, model, optimizer, warmup=2):
+    def __init__(self, model, optimizer, warmup=2, process_group=None, data_parallel=False):
+        """`data_parallel=True` (or a `process_group`): `model` is the BARE model of this rank -- not a
+        DistributedDataParallel wrapper: torch's wrapper stashes every parameter's AccumulateGrad node at construction,
+        on the default stream, and a backward pass captured on another stream must not touch the default stream.  The
+        ranks' parameters must be equal on entry (`broadcast_parameters`)."""
         self.model, self.opt, self.warmup = model, optimizer, max(int(warmup), 2)
+        self.core = model
+        self.group = process_group
+        self.ddp = bool(data_parallel or process_group is not None)
+        self.world = dist.get_world_size(process_group) if self.ddp else 1
         self._graphs = {}
         self.replays = 0
+        self.comm_stats = {"tensors": 0, "bytes": 0}           # what one step all-reduces (data parallel)
+
+    def broadcast_parameters(self, src=0):
+        """Rank `src`'s parameters and buffers to every rank (what DistributedDataParallel's constructor does)."""
+        with torch.no_grad():
+            for t in list(self.core.parameters()) + list(self.core.buffers()):
+                dist.broadcast(t.data, src=src, group=self.group)
 
     # ------------------------------------------------------------------------------------------
     @staticmethod
@@ -39,9 +63,10 @@ class GraphedStep:
         return tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in data.items() if isinstance(v, torch.Tensor)))
 
     def _check(self, data):
-        core = getattr(self.model, "module", self.model)
-        if core is not self.model or Fn.GRAD_SYNC is not None:
-            raise RuntimeError("GraphedStep: data-parallel wrappers are not captured; use the eager step")
+        if isinstance(self.model, torch.nn.parallel.DistributedDataParallel) or Fn.GRAD_SYNC is not None:
+            raise RuntimeError("GraphedStep: pass the bare model (data_parallel=True / process_group=...), not a "
+                               "DistributedDataParallel wrapper: its stashed AccumulateGrad nodes live on the default "
+                               "stream and its reducer's collectives are not captured")
         if self.model.training:
             drops = [m.p for m in self.model.modules() if isinstance(m, torch.nn.Dropout)]
             rates = [float(getattr(m, "droprate", 0.0) or 0.0) for m in self.model.modules()]
@@ -52,12 +77,64 @@ class GraphedStep:
             if isinstance(v, torch.Tensor) and not v.is_cuda:
                 raise RuntimeError(f"GraphedStep: batch entry {k!r} is not on the device")
 
+    # ---- the step, eager (warm-up; data parallel: the same pieces as the replayed step, so the ranks stay in step) ----
     def _eager(self, data):
-        self.opt.zero_grad()
-        post, _state, loss, stats, od = self.model(data=data, distributed=False)
-        loss.backward()
+        if self.ddp:
+            if "_num_boxes" not in data:
+                dev = data["active"].device
+                data["_num_boxes"] = torch.ones(1, dtype=torch.float32, device=dev)
+            self._global_num_boxes(data, data["_num_boxes"])
+        outs = self._forward_backward(data)
+        if self.ddp:
+            for t in self._reduce_targets():
+                self._all_reduce(t)
         self.opt.step()
+        return outs
+
+    # ---- the pieces that are captured ------------------------------------------------------------------------------
+    def _forward_backward(self, data):
+        self.opt.zero_grad()
+        post, _state, loss, stats, od = self.core(data=data, distributed=False)
+        loss.backward()
         return post, loss, stats, od
+
+    def _global_num_boxes(self, data, out):
+        """reference set_criterion.py:185-193: the number of target boxes averaged over the ranks, at least 1 -- from the
+        batch's annotations, on the device, nothing read back."""
+        n = (data["active"] == 1).sum().to(torch.float32).view(1)
+        self._all_reduce(n, average=True)
+        out.copy_(n.clamp_(min=1.0))
+
+    def _all_reduce(self, t, average=True):
+        group = self.group
+        if average and dist.get_backend(group) == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+        else:                                                   # gloo (rehearsal on one GPU): sum, then scale
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            if average:
+                t.div_(self.world)
+
+    def _reduce_targets(self):
+        """What graph A leaves to be averaged: the arena region that holds gradients as ONE flat tensor (everything in
+        it that is not a gradient is a dead temporary: averaging it is harmless) plus the gradients that live elsewhere
+        (sums autograd allocated itself).  Static addresses: every replay rewrites the same memory."""
+        grads = [p.grad for p in self.core.parameters() if p.requires_grad and p.grad is not None]
+        buf = Fn.ARENA.buf if Fn.ARENA.active else None
+        targets, lo, hi = [], None, None
+        for g in grads:
+            inside = (buf is not None and g.is_cuda and g.dtype == torch.float32
+                      and buf.data_ptr() <= g.data_ptr() < buf.data_ptr() + 4 * buf.numel())
+            if inside:
+                # the extent of the gradient's storage footprint inside the arena (channels_last views included)
+                first = (g.data_ptr() - buf.data_ptr()) // 4
+                last = first + sum((n - 1) * s for n, s in zip(g.shape, g.stride())) + 1
+                lo = first if lo is None else min(lo, first)
+                hi = last if hi is None else max(hi, last)
+            else:
+                targets.append(g)
+        if lo is not None:
+            targets.insert(0, buf[lo:hi])
+        return targets
 
     def _capture(self, data):
         self._check(data)
@@ -74,28 +151,53 @@ class GraphedStep:
                 self._eager(static)               # one eager step through the device-side bias corrections
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            outs = self._eager(static)
+        if not self.ddp:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = self._forward_backward(static)
+                self.opt.step()
+            torch.cuda.synchronize(dev)
+            # the capture itself executed nothing: parameters, moments and the device step count are those after the
+            # warm-up steps; python's step counter ran one ahead during capture
+            self.opt._step_no -= 1
+            return {"graph": graph, "static": static, "outs": outs}
+        # data parallel: the collectives stay outside the two graphs
+        self._global_num_boxes(static, static["_num_boxes"])
         torch.cuda.synchronize(dev)
-        # the capture itself executed nothing: parameters, moments and the device step count are those after the
-        # warm-up steps; python's step counter ran one ahead during capture
+        graph_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph_a):
+            outs = self._forward_backward(static)
+        targets = self._reduce_targets()
+        graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph_b, pool=graph_a.pool()):
+            self.opt.step()
+        torch.cuda.synchronize(dev)
         self.opt._step_no -= 1
-        return {"graph": graph, "static": static, "outs": outs}
+        self.comm_stats = {"tensors": len(targets), "bytes": sum(t.numel() * t.element_size() for t in targets)}
+        return {"graph": graph_a, "graph_opt": graph_b, "targets": targets, "static": static, "outs": outs}
 
     # ------------------------------------------------------------------------------------------
-    def __call__(self, data):
+    def __call__(self, data, sync=True):
+        """One optimizer step on `data`.  `sync=False` (data parallel only) skips the gradient average -- the ranks'
+        parameters then DIVERGE; it exists to time the step without communication."""
         sig = self._signature(data)
         g = self._graphs.get(sig)
         if g is None:
             g = self._graphs[sig] = self._capture(data)
         for k, v in g["static"].items():
-            if isinstance(v, torch.Tensor):
+            if isinstance(v, torch.Tensor) and k in data:
                 src = data[k]
                 if src.data_ptr() != v.data_ptr():
                     v.copy_(src, non_blocking=True)
         self.opt.sync_hyperparams()
+        if self.ddp:
+            self._global_num_boxes(g["static"], g["static"]["_num_boxes"])
         g["graph"].replay()
+        if self.ddp:
+            if sync:
+                for t in g["targets"]:
+                    self._all_reduce(t)
+            g["graph_opt"].replay()
         self.opt._step_no += 1
         self.replays += 1
         Fn.PREP.mark_stale()          # the replay changed the parameters without bumping their python-side versions

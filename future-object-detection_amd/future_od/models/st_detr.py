@@ -93,7 +93,11 @@ class SpatioTemporalDETR(nn.Module):
             targets = None
             packed = ops.pack_targets_dev(data["boxes"].float().contiguous(), data["classes"].contiguous(),
                                           data["active"].contiguous(), H, W)
-            num_boxes = self._criterion.device_num_boxes(packed["count"], distributed)
+            # a data-parallel captured step (future_od/graph.py) feeds the normaliser in: it all-reduces the target
+            # count BEFORE replaying the graph, so that no collective sits inside the captured region
+            num_boxes = data.get("_num_boxes")
+            if num_boxes is None:
+                num_boxes = self._criterion.device_num_boxes(packed["count"], distributed)
         else:
             anno = data.get("_host_annotations") or data
             targets = to_detr_targets(H=H, W=W, anno_active=anno["active"], anno_boxes=anno["boxes"],

@@ -106,6 +106,7 @@ SIGNATURES = {
     "fod_tracker_cost": [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "fod_tracker_extrapolate": [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "fod_multi_sqnorm_acc": [_p, _p, _p, _p, _i, _p, _p],
+    "fod_multi_sqnorm_det": [_p, _p, _p, _p, _i, _p, _p, _p],
     "fod_multi_adamw": [_p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p, _p, _f, _p],
 }
 EXPORTS = sorted(list(SIGNATURES) + ["fod_last_error", "fod_abi_version", "fod_multi_chunk"])

@@ -80,6 +80,7 @@ class FusedAdamW(torch.optim.Optimizer):
         dev = params[0].device
         tab, ring = self._tables_for(entries, dev)
         return {"params": params, "gptrs": [e[1] for e in entries], "tab": tab, "ring": ring, "turn": 0,
+                "spares": [ring[0].clone().pin_memory() for _ in range(4)],
                 "lrs": [(g["lr"], g["weight_decay"]) for g in self.param_groups], "dev": dev}
 
     def _tables_for(self, entries, dev):
@@ -126,14 +127,27 @@ class FusedAdamW(torch.optim.Optimizer):
             # the ring is safe by itself: a slot is rewritten only after the upload that last read it has executed (the
             # event is normally long complete; a loop without the matcher's one-step bound simply waits here)
             done = plan.setdefault("ring_events", [None] * len(plan["ring"]))
-            if done[turn] is not None:
+            capturing = torch.cuda.is_current_stream_capturing()
+            if done[turn] is not None and not capturing:
                 done[turn].synchronize()
             host = plan["ring"][turn]
             host[:, 1] = torch.tensor(gptrs, dtype=torch.int64)
             plan["tab"][0].copy_(host, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            done[turn] = ev
+            if capturing:
+                # the copy becomes a graph node that re-reads this slot at every replay: the slot is retired from the
+                # ring's rotation for good (a captured step never comes back here; a later capture builds a new plan)
+                # (its replacement was pinned when the plan was built: no host allocation may happen inside a capture)
+                done[turn] = None
+                spares = plan.setdefault("spares", [])
+                if spares:
+                    plan["ring"][turn] = spares.pop()
+                    plan.setdefault("captured_slots", []).append(host)
+                else:
+                    self._plan = None      # out of spare slots: the next eager step rebuilds the plan (and its ring)
+            else:
+                ev = torch.cuda.Event()
+                ev.record()
+                done[turn] = ev
             plan["gptrs"] = gptrs
         return True
 
@@ -179,8 +193,11 @@ class FusedAdamW(torch.optim.Optimizer):
         nblocks = bt.numel()
         sq = None
         if self.max_norm > 0:
-            self._sq.zero_()
-            L.call("fod_multi_sqnorm_acc", ptr(ptrs), ptr(numel), ptr(bt), ptr(bc), nblocks, ptr(self._sq), stream())
+            # fixed summation order: data-parallel replicas with equal gradients get bit-equal clip factors
+            scr = getattr(self, "_sq_scratch", None)
+            if scr is None or scr.device != dev or scr.numel() < nblocks + 1:
+                scr = self._sq_scratch = torch.zeros(nblocks + 1, dtype=torch.float32, device=dev)
+            L.call("fod_multi_sqnorm_det", ptr(ptrs), ptr(numel), ptr(bt), ptr(bc), nblocks, ptr(self._sq), ptr(scr), stream())
             sq = self._sq
             self.last_grad_norm = self._sq      # device scalar holding the squared norm
         bc1 = 1.0 - betas[0] ** self._step_no

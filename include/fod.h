@@ -366,6 +366,10 @@ int fod_post_proc(const float* logits, const float* boxes, float* class_scores, 
  *   keeps its step count on the device. */
 int fod_multi_sqnorm_acc(const long* ptrs, const long* numel, const int* blk_tensor, const int* blk_chunk,
                          int nblocks, float* out, fod_stream_t stream);
+/* sum g^2 with a fixed summation order (run-to-run and rank-to-rank identical for identical gradients): out = the sum
+ * (overwritten); scratch = f32 [nblocks + 1], word 0 zero before the first launch (the kernel leaves it zero). */
+int fod_multi_sqnorm_det(const long* ptrs, const long* numel, const int* blk_tensor, const int* blk_chunk,
+                         int nblocks, float* out, float* scratch, fod_stream_t stream);
 int fod_multi_adamw(const long* ptrs, const long* numel, const float* lr_wd, const int* blk_tensor,
                     const int* blk_chunk, int nblocks, float beta1, float beta2, float eps, float bias_c1,
                     float bias_c2, const float* bias_dev, const float* sqnorm, float max_norm, fod_stream_t stream);

@@ -121,3 +121,100 @@ def test_two_ranks_average_gradients():
         assert report[3]["accumulate"]["arena_flushes"] == 0 and report[3]["accumulate"]["stragglers"] == nref, report[3]
         assert report[3]["worst"] < 1e-5, report[3]
     assert res[0][2][:3] == res[1][2][:3]                       # same layout on both ranks
+
+
+def _graph_worker(rank, world, port, q):
+    """Data-parallel captured step (graph A: forward + backward, eager all-reduce of the flat gradient arena, graph B:
+    clip + AdamW) against the eagerly launched data-parallel step, from equal weights, on different shards per rank."""
+    import faulthandler
+    faulthandler.dump_traceback_later(150, exit=True)          # a hung collective says where and ends the test
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "future-object-detection_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from types import SimpleNamespace
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from future_od.datasets.synthetic import make_batch
+        from future_od.graph import GraphedStep
+        from future_od.models.st_detr import SpatioTemporalDETRArgs
+        from future_od.optim import FusedAdamW
+        from runs._model import build_model
+        dev = torch.device("cuda", 0)
+        detr = SpatioTemporalDETRArgs(num_classes=8, num_queries=16, lr_backbone=1e-4, pretrained_backbone=False,
+                                      backbone="resnet18", enc_layers=1, dec_layers=2)
+
+        def fresh(wrapped):
+            torch.manual_seed(11)
+            args = SimpleNamespace(device=dev, distributed=wrapped, compute_dtype="fp32", num_images=2, backbone="resnet18")
+            m = build_model(args, detr)
+            m.eval()
+            return m, FusedAdamW(m.parameters(), lr=1e-4, weight_decay=1e-4, max_norm=0.1)
+
+        batches = [make_batch(1, 3, 64, 96, seed=300 + 10 * i + rank, device=dev, max_boxes=5) for i in range(3)]
+        seq = [0, 1, 2, 0, 1, 2, 1]
+        # the captured step's warm-up = three eager steps on the first batch it sees (2 + 1 for the device step count):
+        # the eager data-parallel reference (FodDataParallel, side-stream reducer) runs the same sequence
+        m2, o2 = fresh(True)
+        for i in [0, 0, 0] + seq:
+            o2.zero_grad()
+            _, _, loss, _, _ = m2(data=batches[i], distributed=True)
+            loss.backward()
+            o2.step()
+        torch.cuda.synchronize()
+        from future_od.native import functional as Fn
+        Fn.set_grad_sync(None)
+        mg, og = fresh(False)
+        step = GraphedStep(mg, og, warmup=2, data_parallel=True)
+        step.broadcast_parameters()
+        graph_losses = []
+        for i in seq:
+            _, loss, _, _ = step(batches[i])
+            graph_losses.append(float(loss))
+        torch.cuda.synchronize()
+        worst = 0.0
+        for (n, a), (_, b) in zip(m2.module.named_parameters(), mg.named_parameters()):
+            worst = max(worst, float((a - b).abs().max() / (a.abs().max() + 1e-12)))
+        # the ranks must hold identical parameters after the captured steps
+        spread = 0.0
+        for p in mg.parameters():
+            lo, hi = p.detach().clone(), p.detach().clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            spread = max(spread, float((hi - lo).abs().max()))
+        q.put((rank, worst, spread, graph_losses, dict(step.comm_stats), step.replays))
+    except BaseException as e:                                  # the other rank must not wait for a collective forever
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+        os._exit(1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_captured_step_matches_eager_data_parallel():
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_graph_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    for _ in range(world):
+        r = q.get(timeout=260)
+        if r[1] == "error":
+            for p in procs:
+                p.kill()
+            raise AssertionError(f"rank {r[0]} failed:\n{r[2]}")
+        res.append(r)
+    res.sort()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, worst, spread, losses, comm, replays in res:
+        assert replays == 7
+        assert spread == 0.0, (rank, spread)                   # every rank applied the same averaged gradients
+        assert worst < 5e-4, (rank, worst)                     # fp32: atomics' summation order through Adam's normalisation
+        assert comm["tensors"] >= 1 and comm["bytes"] > 1 << 20, comm
+        assert all(l == l and abs(l) < 1e6 for l in losses), losses
+    assert res[0][4] == res[1][4]                              # same all-reduce layout on both ranks
