@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="N=1 only: launch every kernel from Python (the default replays the step as one hipGraph)")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--train-mode", action="store_true",
+                    help="model.train(): the reference's dropout 0.1 active (BASELINE.md measures model.eval() with "
+                         "autograd on, the default here); for the record, not the headline")
     ap.add_argument("--rehearse", action="store_true",
                     help="tiny shapes, gloo backend, every rank on cuda:0: exercises the N>1 code path on a 1-GPU box")
     ap.add_argument("--force-ddp", action="store_true",
@@ -194,6 +197,8 @@ def main():
         # data parallel, eager: the FodDataParallel wrapper with its side-stream reducer
         model, detr = build(a, device, distributed and not use_graph, num_images, dtype)
         model.eval()     # forward + backward in model.eval() with autograd on (dropout off, FrozenBN)
+        if a.train_mode:
+            model.train()
         opt = FusedAdamW(model.parameters(), lr=detr.lr, weight_decay=detr.weight_decay, max_norm=detr.max_norm)
         data = make_batch(BATCH_PER_GPU, T_FRAMES, HEIGHT, WIDTH, seed=1234 + rank, device=device)
 
@@ -302,6 +307,7 @@ def main():
                    "global_batch": BATCH_PER_GPU * world, "frames": T_FRAMES, "resolution": [HEIGHT, WIDTH],
                    "num_images": a.num_images, "parallelism": f"dp{world}"},
         "final_loss": final_loss,
+        "model_mode": "train (dropout 0.1 active)" if a.train_mode else "eval (BASELINE.md: eval-mode math, autograd on)",
         "launch_mode": ("eager (one Python call per kernel)" if not use_graph else
                         "hipgraph replay (one graph per step)" if not distributed else
                         "hipgraph replay (forward + backward graph, eager gradient all-reduce, optimizer graph)"),

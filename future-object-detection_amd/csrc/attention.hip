@@ -39,7 +39,17 @@ struct AttnParams {
   // drop_mix(q * S + k, seed_lo + (b * H + h) * 0x9E3779B9, seed_hi) >= drop_threshold; 0 = off
   unsigned drop_threshold, drop_seed_lo, drop_seed_hi;
   float drop_inv_keep;
+  const unsigned long long* drop_seed_dev;   // optional device-side base mixed into the seed (captured steps)
 };
+
+// the DROP kernels start by folding the device-side base into their copy of the parameters
+FOD_DEVINL void resolve_drop_seed(AttnParams& p) {
+  if (p.drop_seed_dev) {
+    const unsigned long long s = effective_seed(((unsigned long long)p.drop_seed_hi << 32) | p.drop_seed_lo, p.drop_seed_dev);
+    p.drop_seed_lo = (unsigned)(s & 0xFFFFFFFFu);
+    p.drop_seed_hi = (unsigned)(s >> 32);
+  }
+}
 
 // multiplier of probability (q, k): 0 if dropped, 1 / keep otherwise
 FOD_DEVINL float drop_gain(const AttnParams& p, unsigned bh_seed, int q, int k) {
@@ -167,7 +177,9 @@ FOD_DEVINL void zero_acc(f32x16& a) {
 //                (max, sum, O) states are merged through LDS.  Used when Tq is small (decoder queries:
 //                Tq = 128 would otherwise give 16 blocks that each walk 46 key tiles serially).
 template <typename T, int PARTS, bool SPLIT, bool DROP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p_in) {
+  AttnParams p = p_in;
+  if constexpr (DROP) resolve_drop_seed(p);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int q0 = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + wave) * 32;
@@ -611,7 +623,9 @@ __global__ __launch_bounds__(NW * 64, PARTS == 1 ? 4 : 3) void attn_fwd_lds_kern
 // ------------------------------------------------------------------------------------------------
 // dq pass: wave owns 32 queries.  Also writes delta[q] = sum_d dO[q,d] * O[q,d].
 template <typename T, int PARTS, bool SPLIT, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p_in) {
+  AttnParams p = p_in;
+  if constexpr (DROP) resolve_drop_seed(p);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int q0 = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + wave) * 32;
@@ -1106,7 +1120,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_lds_kernel(const AttnPar
 // ------------------------------------------------------------------------------------------------
 // dk/dv pass: wave owns 32 keys (key on the lane); needs lse2 and delta from the passes above.
 template <typename T, int PARTS, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p_in) {
+  AttnParams p = p_in;
+  if constexpr (DROP) resolve_drop_seed(p);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 31, fh = lane >> 5;
   const int k0 = (blockIdx.x * 4 + wave) * 32;
@@ -1206,7 +1222,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
 //     (accumulator rows 8g + 4h .. +3 are consecutive queries).
 // Rows past Tq are clamped duplicates; their P and dS are zeroed, so they add nothing.
 template <int PARTS, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_pf_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256) void attn_bwd_dkv_pf_kernel(const AttnParams p_in) {
+  AttnParams p = p_in;
+  if constexpr (DROP) resolve_drop_seed(p);
   typedef __bf16 T;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 31, fh = lane >> 5;
@@ -1445,6 +1463,7 @@ int fill(AttnParams& p, const fod_attn_shape* s) {
   p.drop_inv_keep = 1.f / (1.f - s->drop_p);
   p.drop_seed_lo = (unsigned)(s->drop_seed & 0xFFFFFFFFu);
   p.drop_seed_hi = (unsigned)(s->drop_seed >> 32);
+  p.drop_seed_dev = s->drop_seed_dev;
   FOD_REQUIRE(p.drop_threshold == 0 || (long)s->Tq * s->S < (1L << 32), "attention: Tq * S too large for dropout indexing");
   FOD_REQUIRE(p.q_ts % 8 == 0 && p.k_ts % 8 == 0 && p.v_ts % 8 == 0 && p.o_ts % 8 == 0 && p.q_bs % 8 == 0 &&
                   p.k_bs % 8 == 0 && p.v_bs % 8 == 0 && p.o_bs % 8 == 0 && p.k2_bs % 8 == 0 && p.k2_ts % 8 == 0 &&

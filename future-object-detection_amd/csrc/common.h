@@ -148,6 +148,18 @@ FOD_DEVINL unsigned drop_mix(unsigned i, unsigned seed_lo, unsigned seed_hi) {
   return h;
 }
 
+// splitmix64 finaliser (the host's mix64 in native/functional.py) and the seed a dropout kernel actually uses: with a
+// device-side base (captured steps: the call's seed is baked into the graph, the base advances once per replay) the two
+// are mixed again, so replays draw fresh masks while forward and backward of one step still agree.
+FOD_DEVINL unsigned long long mix64(unsigned long long x) {
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+FOD_DEVINL unsigned long long effective_seed(unsigned long long seed, const unsigned long long* base_dev) {
+  return base_dev ? mix64(seed + *base_dev) : seed;
+}
+
 FOD_DEVINL int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 FOD_DEVINL float wave_sum(float v) {

@@ -510,9 +510,11 @@ __global__ void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N
 // Dropout without a stored mask: element i of call `seed` is kept iff mix32(i, seed) >= threshold
 // (threshold = p * 2^32), so the backward pass regenerates the forward's mask from (seed, i) alone.
 template <typename T>
-__global__ void dropout_kernel(T* __restrict__ out, const T* __restrict__ a, unsigned nchunks, unsigned seed_lo,
-                               unsigned seed_hi, unsigned threshold, float inv_keep) {
+__global__ void dropout_kernel(T* __restrict__ out, const T* __restrict__ a, unsigned nchunks, unsigned long long seed,
+                               const unsigned long long* __restrict__ seed_dev, unsigned threshold, float inv_keep) {
   constexpr int VEC = Elem<T>::VEC;
+  seed = effective_seed(seed, seed_dev);
+  const unsigned seed_lo = (unsigned)(seed & 0xFFFFFFFFu), seed_hi = (unsigned)(seed >> 32);
   for (unsigned c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunks; c += gridDim.x * blockDim.x) {
     T t[VEC];
     __builtin_memcpy(t, __builtin_assume_aligned(a + (long)c * VEC, 16), 16);
@@ -795,8 +797,8 @@ extern "C" int fod_eltwise(int op, int dtype, void* out, const void* a, const vo
   return FOD_OK;
 }
 
-extern "C" int fod_dropout(int dtype, void* out, const void* a, long n, unsigned long long seed, float p,
-                           hipStream_t stream) {
+extern "C" int fod_dropout(int dtype, void* out, const void* a, long n, unsigned long long seed,
+                           const unsigned long long* seed_dev, float p, hipStream_t stream) {
   const int vec = dtype == FOD_BF16 ? 8 : 4;
   FOD_REQUIRE(out && a && n > 0 && n % vec == 0 && n < (1L << 32), "dropout: bad size %ld", n);
   FOD_REQUIRE(p >= 0.f && p < 1.f, "dropout: p=%f out of [0, 1)", p);
@@ -805,8 +807,7 @@ extern "C" int fod_dropout(int dtype, void* out, const void* a, long n, unsigned
   const float inv_keep = 1.f / (1.f - p);
   FOD_DISPATCH_T(dtype, "dropout",
                  hipLaunchKernelGGL((dropout_kernel<T>), dim3(grid_for(n / vec)), dim3(256), 0, stream, (T*)out,
-                                    (const T*)a, (unsigned)(n / vec), (unsigned)(seed & 0xFFFFFFFFu),
-                                    (unsigned)(seed >> 32), threshold, inv_keep))
+                                    (const T*)a, (unsigned)(n / vec), seed, seed_dev, threshold, inv_keep))
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }

@@ -21,13 +21,17 @@ all-reduced from the batch's annotations BEFORE graph A and fed in as an input (
 average is therefore not overlapped with the backward pass (215 MB over xGMI, ~1-2 ms at 8 GPUs), which costs less than
 the ~6 ms per step the eagerly launched data-parallel step loses to the launching thread (bench.py --no-graph).
 
-Restrictions (checked): one device per process, dropout inactive (eval-mode math or p = 0: a captured kernel would
-replay the same mask), static shapes -- a batch with other shapes is re-captured.
+Dropout (train mode, p > 0): the masks are stateless hashes of (seed, index); a captured kernel carries its call's
+seed as a constant, so the kernels additionally mix in a device scalar (`ops.DROP_BASE`) that the graph advances once
+per replay -- new masks every step, the same masks in the forward and the backward of one step.
+
+Restrictions (checked): one device per process, static shapes -- a batch with other shapes is re-captured.
 """
 import torch
 import torch.distributed as dist
 
 from future_od.native import functional as Fn
+from future_od.native import ops
 
 
 class GraphedStep:
@@ -37,7 +41,7 @@ class GraphedStep:
     rolled back) and captures one more; later calls copy the batch into the captured input buffers and replay.
     Returned tensors are the graph's static outputs: valid until the next call."""
 
-    def __init__(self, model, optimizer, warmup=2, process_group=None, data_parallel=False):
+    def __init__(self, model, optimizer, warmup=2, process_group=None, data_parallel=False, rollback_warmup=False):
         """`data_parallel=True` (or a `process_group`): `model` is the BARE model of this rank -- not a
         DistributedDataParallel wrapper: torch's wrapper stashes every parameter's AccumulateGrad node at construction,
         on the default stream, and a backward pass captured on another stream must not touch the default stream.  The
@@ -50,6 +54,10 @@ class GraphedStep:
         self._graphs = {}
         self.replays = 0
         self.comm_stats = {"tensors": 0, "bytes": 0}           # what one step all-reduces (data parallel)
+        # the eager warm-up steps before a capture are real optimizer steps on the batch that triggered it; with
+        # rollback_warmup the parameters, moments and step counts are put back afterwards, so that a training loop
+        # sees exactly one update per batch (the Trainer asks for this; the benchmark does not care)
+        self.rollback_warmup = bool(rollback_warmup)
 
     def broadcast_parameters(self, src=0):
         """Rank `src`'s parameters and buffers to every rank (what DistributedDataParallel's constructor does)."""
@@ -67,12 +75,6 @@ class GraphedStep:
             raise RuntimeError("GraphedStep: pass the bare model (data_parallel=True / process_group=...), not a "
                                "DistributedDataParallel wrapper: its stashed AccumulateGrad nodes live on the default "
                                "stream and its reducer's collectives are not captured")
-        if self.model.training:
-            drops = [m.p for m in self.model.modules() if isinstance(m, torch.nn.Dropout)]
-            rates = [float(getattr(m, "droprate", 0.0) or 0.0) for m in self.model.modules()]
-            if any(p > 0 for p in drops + rates):
-                raise RuntimeError("GraphedStep: dropout is active (train mode, p > 0): a captured step would replay "
-                                   "the same masks; use model.eval() (autograd stays on) or p = 0")
         for k, v in data.items():
             if isinstance(v, torch.Tensor) and not v.is_cuda:
                 raise RuntimeError(f"GraphedStep: batch entry {k!r} is not on the device")
@@ -92,7 +94,18 @@ class GraphedStep:
         return outs
 
     # ---- the pieces that are captured ------------------------------------------------------------------------------
+    def _dropout_active(self):
+        if not self.model.training:
+            return False
+        drops = [m.p for m in self.model.modules() if isinstance(m, torch.nn.Dropout)]
+        rates = [float(getattr(m, "droprate", 0.0) or 0.0) for m in self.model.modules()]
+        return any(p > 0 for p in drops + rates)
+
     def _forward_backward(self, data):
+        if ops.DROP_BASE is not None:
+            # train mode: the dropout kernels mix this device scalar into the seeds baked into the graph, so every
+            # replay draws new masks (forward and backward of one step read the same value)
+            ops.DROP_BASE.add_(1)
         self.opt.zero_grad()
         post, _state, loss, stats, od = self.core(data=data, distributed=False)
         loss.backward()
@@ -136,11 +149,47 @@ class GraphedStep:
             targets.insert(0, buf[lo:hi])
         return targets
 
+    def _snapshot(self):
+        opt = self.opt
+        params = [p for grp in opt.param_groups for p in grp["params"]]
+        return {"params": [(p, p.detach().clone()) for p in params],
+                "moments": {p: (st["exp_avg"].clone(), st["exp_avg_sq"].clone())
+                            for p, st in opt.state.items() if "exp_avg" in st},
+                "step_no": getattr(opt, "_step_no", 0)}
+
+    def _restore(self, snap):
+        opt = self.opt
+        with torch.no_grad():
+            for p, saved in snap["params"]:
+                p.copy_(saved)
+            for p, st in opt.state.items():
+                if "exp_avg" in st:
+                    old = snap["moments"].get(p)
+                    if old is None:                      # created by the warm-up: back to "never stepped"
+                        st["exp_avg"].zero_()
+                        st["exp_avg_sq"].zero_()
+                    else:
+                        st["exp_avg"].copy_(old[0])
+                        st["exp_avg_sq"].copy_(old[1])
+        opt._step_no = snap["step_no"]
+        if getattr(opt, "_dev_step", None) is not None:
+            opt._dev_step.fill_(float(snap["step_no"]))
+        Fn.PREP.mark_stale()
+
     def _capture(self, data):
+        snap = self._snapshot() if self.rollback_warmup else None
+        out = self._capture_inner(data)
+        if snap is not None:
+            self._restore(snap)
+        return out
+
+    def _capture_inner(self, data):
         self._check(data)
         dev = next(v for v in data.values() if isinstance(v, torch.Tensor)).device
         static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in data.items()
                   if k != "_host_annotations"}
+        if self._dropout_active() and (ops.DROP_BASE is None or ops.DROP_BASE.device != dev):
+            ops.DROP_BASE = torch.zeros(1, dtype=torch.int64, device=dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):

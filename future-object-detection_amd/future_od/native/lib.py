@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libfod_hip.so"))
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 F32, BF16 = 0, 1
 EW_ADD, EW_MUL, EW_RELU_MASK, EW_SCALE, EW_ADD3, EW_RELU, EW_COPY_B = range(7)
@@ -39,7 +39,7 @@ class AttnShape(C.Structure):
                 ("scale", C.c_float),
                 ("k2_batch_stride", C.c_long), ("k2_token_stride", C.c_long),
                 ("dk2_batch_stride", C.c_long), ("dk2_token_stride", C.c_long),
-                ("drop_p", C.c_float), ("drop_seed", C.c_ulonglong)]
+                ("drop_p", C.c_float), ("drop_seed", C.c_ulonglong), ("drop_seed_dev", C.c_void_p)]
 
 
 class PermuteJob(C.Structure):
@@ -68,7 +68,7 @@ SIGNATURES = {
     "fod_clip_to_stem_layout": [_i, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _l, _l, _p, _p, _p],
     "fod_conv2d_wgrad_acc": [_i, _p, _p, _p, _CG, _p, _i, _p],
     "fod_maxpool3x3s2": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _p],
-    "fod_dropout": [_i, _p, _p, _l, C.c_ulonglong, _f, _p],
+    "fod_dropout": [_i, _p, _p, _l, C.c_ulonglong, _p, _f, _p],
     "fod_multi_permute3": [_p, _p, _p, _i, _p],
     "fod_multi_permute_chunk": [],
     "fod_multi_permute_tiles": [_i, _i, _i, _l, _l, _l],

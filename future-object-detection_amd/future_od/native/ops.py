@@ -364,7 +364,7 @@ def _attn_shape(q1, k1, v, o, scale, k2=None, dk2=None, drop_p=0.0, drop_seed=0)
         assert dk2.shape == (B, S, E)
         d2b, d2t = _bt(dk2, "dk2", dtp)
     return AttnShape(B, H, Tq, S, qb, qt, kb, kt, vb, vt, ob, ot, scale, k2b, k2t, d2b, d2t, float(drop_p),
-                     int(drop_seed) & 0xFFFFFFFFFFFFFFFF), H
+                     int(drop_seed) & 0xFFFFFFFFFFFFFFFF, ptr(DROP_BASE) if drop_p > 0.0 else None), H
 
 
 def _same_bt(a, b, name):
@@ -478,11 +478,16 @@ def add(a, b, **kw):
     return eltwise(L.EW_ADD, a, b, **kw)
 
 
+# Device-side dropout seed base (int64 [1] on the device) or None.  A captured step (future_od/graph.py) bakes every
+# call's seed into its graph; the kernels mix this scalar into it, and the graph advances it once per replay.
+DROP_BASE = None
+
+
 def dropout(a, p, seed):
     """a * mask / (1 - p) with the stateless mask of call `seed` (the same call on a gradient is the backward)."""
     _chk(a, "a")
     out = torch.empty_like(a)
-    call("fod_dropout", dt(a), ptr(out), ptr(a), a.numel(), seed & 0xFFFFFFFFFFFFFFFF, float(p), stream())
+    call("fod_dropout", dt(a), ptr(out), ptr(a), a.numel(), seed & 0xFFFFFFFFFFFFFFFF, ptr(DROP_BASE), float(p), stream())
     return out
 
 

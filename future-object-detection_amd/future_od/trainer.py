@@ -104,6 +104,29 @@ class Trainer:
                     self._model_no_ddp._model.drop_mode = name
                 self._run_epoch(name, loader)
 
+    def _graphed_step(self):
+        """The training step as one captured hipGraph (future_od/graph.py) when the setup allows it: one device, the
+        fused optimizer (its step count and clipping live on the device), the device-side matcher.  The reference's loop
+        (trainer.py:171-189) costs ~1400 launches behind ~16 us of Python each -- every configuration but the largest is
+        bound by the launching thread; a replay costs one call.  Dropout stays active (train mode): the kernels draw new
+        masks per replay from a device-side counter.  FOD_GRAPH_TRAIN=0 keeps the eager loop."""
+        g = getattr(self, "_graphed", None)
+        if g is False:
+            return None
+        if g is None:
+            import os
+            from future_od.models.set_criterion import device_matching_enabled
+            dev = torch.device(self._device)
+            ok = (os.environ.get("FOD_GRAPH_TRAIN", "1") != "0" and not self._distributed and dev.type == "cuda"
+                  and hasattr(self._optimizer, "enable_device_step")
+                  and (self._optimizer_clips or not self._max_norm) and device_matching_enabled(dev))
+            if not ok:
+                self._graphed = False
+                return None
+            from future_od.graph import GraphedStep
+            g = self._graphed = GraphedStep(self._model, self._optimizer, warmup=2, rollback_warmup=True)
+        return g
+
     @staticmethod
     def _fetch_async(tensors):
         """Device tensors -> pinned host copies queued on the stream, plus the event that says when they are there.
@@ -139,14 +162,29 @@ class Trainer:
                 for j in range(4):
                     od_lists[j].extend(hod[j * n:(j + 1) * n])
 
+        graphed = self._graphed_step() if mode == "train" else None
         for i, data in enumerate(DevicePrefetcher(data_loader, self._device)):      # next batch staged on a side stream
             if EXIT.is_set():
                 return
-            if mode == "train":
-                self._optimizer.zero_grad()
-            out, _state, loss, stats, od = self._model(data=data, visualize=False, epoch=self._epoch,
-                                                       distributed=self._distributed)
-            if mode == "train":
+            if graphed is not None:
+                try:
+                    out, loss, stats, od = graphed(data)      # zero_grad + forward + backward + clip + AdamW: one launch
+                except Exception as e:                        # not capturable here: the eager step from now on
+                    print(f"[fod] captured training step unavailable ({type(e).__name__}: {e}); launching eagerly")
+                    self._graphed, graphed = False, None
+            if graphed is not None:
+                self._training_iterations += 1
+                if self._epoch == 1 and i == 0:
+                    print("\nFirst iteration. Checking whether all layers gradients.")
+                    for name, p in self._model.named_parameters():
+                        if p.requires_grad and p.grad is None:
+                            print(name, "got no gradient")
+            else:
+                if mode == "train":
+                    self._optimizer.zero_grad()
+                out, _state, loss, stats, od = self._model(data=data, visualize=False, epoch=self._epoch,
+                                                           distributed=self._distributed)
+            if mode == "train" and graphed is None:
                 loss.backward()
                 if self._epoch == 1 and i == 0:
                     print("\nFirst iteration. Checking whether all layers gradients.")

@@ -37,7 +37,7 @@ enum { FOD_OK = 0, FOD_ERR_ARG = 1, FOD_ERR_LAUNCH = 2, FOD_ERR_RUNTIME = 3 };
 size_t fod_last_error(char* buf, size_t cap);
 /* ABI version of this header; the loader refuses a library that disagrees. */
 int fod_abi_version(void);
-#define FOD_ABI_VERSION 1
+#define FOD_ABI_VERSION 2
 
 /* Fused epilogue of the NT contraction family.  In order:
  *   v = acc * scale[n] + shift[n];  v += residual[row(m), n];  v = relu ? max(v,0) : v;
@@ -187,6 +187,9 @@ typedef struct fod_attn_shape {
    * (drop_seed, b, h, q, k) >= drop_p * 2^32; forward and backward must be given the same seed. */
   float drop_p;
   unsigned long long drop_seed;
+  /* optional device scalar (NULL = none): the seed used is mix64(drop_seed + *drop_seed_dev).  A captured step bakes
+   * drop_seed into its graph and advances the device scalar once per replay (future_od/graph.py). */
+  const unsigned long long* drop_seed_dev;
 } fod_attn_shape;
 
 /* o = softmax((q1.k1 + q2.k2) * scale) v per head; head h = channels [32h, 32h+32) of every tensor.
@@ -229,7 +232,9 @@ int fod_eltwise(int op, int dtype, void* out, const void* a, const void* b, cons
 /* out[i] = keep(i) ? a[i] / (1 - p) : 0 with keep(i) a stateless hash of (seed, i): the backward pass applies the
  * same call (same seed) to the incoming gradient, no mask is stored.  nn.Dropout on the sub-layer outputs and inside
  * the feed-forward blocks in train mode (future_od/models/transformer.py:95-102,201-234,405-417). */
-int fod_dropout(int dtype, void* out, const void* a, long n, unsigned long long seed, float p, fod_stream_t stream);
+int fod_dropout(int dtype, void* out, const void* a, long n, unsigned long long seed,
+                const unsigned long long* seed_dev /* optional device-side base, see fod_attn_shape */, float p,
+                fod_stream_t stream);
 
 /* DETR sine table for an h x w map as a token-major [h*w, C] tensor: first C/2 channels encode y,
  * last C/2 encode x (future_od/models/paper.py:57-64,75-80). */

@@ -140,3 +140,36 @@ def test_prepared_operands_follow_the_optimizer():
     wt = Fn.prep_conv(blk.conv2.weight, torch.bfloat16, scale, True)                   # [Cin][taps][Cout]
     want_t = (blk.conv2.weight.detach() * scale.view(-1, 1, 1, 1)).permute(1, 2, 3, 0).reshape(wt.shape).to(torch.bfloat16)
     assert torch.equal(wt, want_t)
+
+
+def test_captured_train_mode_step_draws_new_dropout_masks_every_replay():
+    """Train mode with the reference's dropout 0.1: the captured step carries every dropout call's seed as a constant
+    and the kernels mix in a device scalar the graph advances per replay.  The same batch replayed with lr = 0 must
+    give DIFFERENT losses from replay to replay (new masks), all close to the eval-mode loss, and an eager train-mode
+    forward must see masks too; backward consistency = the loss decreases under training (masks agree between the
+    forward and the backward of a step, otherwise the gradients would be noise)."""
+    from future_od.datasets.synthetic import make_batch
+    from future_od.graph import GraphedStep
+    from future_od.native import ops
+    data = make_batch(2, 3, 96, 128, seed=21, max_boxes=9, device=DEV)
+    model, opt = _build("bf16")
+    with torch.no_grad():
+        _, _, l_eval, _, _ = model(data=data, distributed=False)
+    model.train()
+    for g in opt.param_groups:
+        g["lr"] = 0.0
+    step = GraphedStep(model, opt, warmup=2)
+    losses = [float(step(data)[1].detach()) for _ in range(5)]
+    assert ops.DROP_BASE is not None and int(ops.DROP_BASE.item()) >= 5
+    assert len({round(l, 4) for l in losses}) >= 4, losses               # new masks every replay
+    for l in losses:
+        assert abs(l - float(l_eval)) < 0.25 * abs(float(l_eval)), (l, float(l_eval))
+    # now train: the loss on this one batch must go down over a few dozen captured steps
+    for g in opt.param_groups:
+        g["lr"] = 1e-4
+    first = sum(float(step(data)[1].detach()) for _ in range(4)) / 4
+    for _ in range(40):
+        step(data)
+    last = sum(float(step(data)[1].detach()) for _ in range(4)) / 4
+    assert last < first, (first, last)
+    ops.DROP_BASE = None

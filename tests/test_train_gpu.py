@@ -66,6 +66,10 @@ def test_trainer_short_run(tmp_path):
                  checkpoint_epochs=True, is_master=True, max_norm=detr.max_norm)
     before = {k: v.clone() for k, v in model.state_dict().items()}
     tr.train(2)
+    # the training epochs ran as replays of ONE captured step (train mode, dropout 0.1 active), one update per batch:
+    # the capture's warm-up steps were rolled back
+    assert tr._graphed not in (None, False) and tr._graphed.replays == 12 and len(tr._graphed._graphs) == 1
+    assert opt._step_no == 12 and tr._training_iterations == 12
     hist = tr._stats["train labels loss"].history
     assert len(hist) == 2 and all(h == h for h in hist)            # finite
     total = [sum(tr._stats[f"train {k} loss"].history[e] for k in ("labels", "box_l1", "box_giou")) for e in range(2)]
