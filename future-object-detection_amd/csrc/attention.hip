@@ -40,6 +40,11 @@ struct AttnParams {
   unsigned drop_threshold, drop_seed_lo, drop_seed_hi;
   float drop_inv_keep;
   const unsigned long long* drop_seed_dev;   // optional device-side base mixed into the seed (captured steps)
+  // key split ACROSS blocks (few-query launches, see attn_fwd_kernel): ksplit blocks share one 32-query tile, each walks
+  // kchunk keys; partial states meet in split_ws and the block that draws the last ticket merges them
+  int ksplit, kchunk;
+  float* split_ws;
+  unsigned* split_tickets;
 };
 
 // the DROP kernels start by folding the device-side base into their copy of the parameters
@@ -182,11 +187,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p_in) {
   if constexpr (DROP) resolve_drop_seed(p);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 31, fh = lane >> 5;
-  const int q0 = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + wave) * 32;
+  const int KS = SPLIT ? p.ksplit : 1;                 // blocks per 32-query tile (key split across blocks)
+  const int qt = SPLIT ? (int)blockIdx.x / KS : 0, ks = SPLIT ? (int)blockIdx.x - qt * KS : 0;
+  const int q0 = SPLIT ? qt * 32 : (blockIdx.x * 4 + wave) * 32;
   if (q0 >= p.Tq) return;
   BLK_STAMP(0);
   const int h = blockIdx.y, b = blockIdx.z;
   const int q = min(q0 + fr, p.Tq - 1);
+  const int kbeg = SPLIT ? ks * p.kchunk : 0;          // this block's keys [kbeg, kend)
+  const int kend = SPLIT ? min(p.S, kbeg + p.kchunk) : p.S;
   const T* Qp[2] = {reinterpret_cast<const T*>(p.q1), reinterpret_cast<const T*>(p.q2)};
   const T* Kp[2] = {reinterpret_cast<const T*>(p.k1), reinterpret_cast<const T*>(p.k2)};
   const T* Vp = reinterpret_cast<const T*>(p.v) + (long)b * p.v_bs + h * 32;
@@ -341,9 +350,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p_in) {
         v_next1 = *reinterpret_cast<const uint4*>(Vp + (long)r1 * p.v_ts + (lane & 3) * 8);
       }
     };
-    const int kfirst = SPLIT ? wave * 32 : 0;
-    if (kfirst < p.S) request(kfirst);
-    for (int k0 = kfirst; k0 < p.S; k0 += KSTEP) {
+    const int kfirst = kbeg + (SPLIT ? wave * 32 : 0);
+    if (kfirst < kend) request(kfirst);
+    for (int k0 = kfirst; k0 < kend; k0 += KSTEP) {
       Frag<T> fk[PARTS][2];
 #pragma unroll
       for (int pt = 0; pt < PARTS; ++pt)
@@ -364,10 +373,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p_in) {
       // The loop is bound by the vector unit (one wave per SIMD, ~190 vector instructions per 32 keys against 6 MFMAs):
       // keys past S are masked on the wave's last tile only, the scale rides in the exponent's fma (as in the other
       // path and in the backward passes), O is rescaled only when some row's maximum moved.
-      if (k0 + 32 > p.S) {
+      if (k0 + 32 > kend) {                             // (kchunk is a multiple of 128: only the last split's last tile)
   #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (k0 + acc_row(r, lane) >= p.S) sacc[r] = -INFINITY;
+          if (k0 + acc_row(r, lane) >= kend) sacc[r] = -INFINITY;
       }
       float mxa[4];
   #pragma unroll
@@ -435,6 +444,38 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p_in) {
       oacc[r] = v;
     }
     m = mstar;
+    if (KS > 1) {
+      // ---- across blocks: wave 0 publishes this block's (m, l, O^T) and takes a ticket; the block that draws the last
+      // one merges all KS partial states (nobody waits for anybody: no co-residency assumption)
+      const int nqt = (p.Tq + 31) >> 5;
+      const long tile = ((long)b * p.H + h) * nqt + qt;
+      float* mine = p.split_ws + (tile * KS + ks) * 1088;
+      if (fh == 0) {
+        store_sc1(mine + fr, m);
+        store_sc1(mine + 32 + fr, l);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) store_sc1(mine + 64 + acc_row(r, lane) * 32 + fr, oacc[r]);
+      stores_done();                                   // (sc1 hand-off, common.h: no fences)
+      unsigned ticket = 0;
+      if (lane == 0) ticket = atomicAdd(p.split_tickets + tile, 1u);
+      ticket = __shfl(ticket, 0);
+      if (ticket != (unsigned)(KS - 1)) return;
+      const float* all = p.split_ws + tile * KS * 1088;
+      mstar = -INFINITY;
+      for (int s = 0; s < KS; ++s) mstar = fmaxf(mstar, load_sc1(all + s * 1088 + fr));
+      l = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+      for (int s = 0; s < KS; ++s) {
+        const float w = ex2(load_sc1(all + s * 1088 + fr) - mstar);
+        l += load_sc1(all + s * 1088 + 32 + fr) * w;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[r] += load_sc1(all + s * 1088 + 64 + acc_row(r, lane) * 32 + fr) * w;
+      }
+      m = mstar;
+      if (lane == 0) p.split_tickets[tile] = 0u;       // ready for the next launch (stream-ordered)
+    }
   }
   if (q0 + fr < p.Tq) {
     T* op = reinterpret_cast<T*>(p.o) + (long)b * p.o_bs + (long)q * p.o_ts + h * 32;
@@ -628,10 +669,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p_in)
   if constexpr (DROP) resolve_drop_seed(p);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 31, fh = lane >> 5;
-  const int q0 = SPLIT ? blockIdx.x * 32 : (blockIdx.x * 4 + wave) * 32;
+  const int KS = SPLIT ? p.ksplit : 1;                 // blocks per 32-query tile (key split across blocks)
+  const int qt = SPLIT ? (int)blockIdx.x / KS : 0, ks = SPLIT ? (int)blockIdx.x - qt * KS : 0;
+  const int q0 = SPLIT ? qt * 32 : (blockIdx.x * 4 + wave) * 32;
   if (q0 >= p.Tq) return;
   const int h = blockIdx.y, b = blockIdx.z;
   const int q = min(q0 + fr, p.Tq - 1);
+  const int kbeg = SPLIT ? ks * p.kchunk : 0;
+  const int kend = SPLIT ? min(p.S, kbeg + p.kchunk) : p.S;
   const T* Qp[2] = {reinterpret_cast<const T*>(p.q1), reinterpret_cast<const T*>(p.q2)};
   const T* Kp[2] = {reinterpret_cast<const T*>(p.k1), reinterpret_cast<const T*>(p.k2)};
   const T* Vp = reinterpret_cast<const T*>(p.v) + (long)b * p.v_bs + h * 32;
@@ -689,7 +734,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p_in)
 
   // next key tile one trip ahead (see attn_fwd_kernel); the transposed K operand is made from the same registers
   constexpr int KSTEP = SPLIT ? 128 : 32;
-  const int kfirst = SPLIT ? wave * 32 : 0;
+  const int kfirst = kbeg + (SPLIT ? wave * 32 : 0);
   Frag<T> fk_next[PARTS][2], fv_next[2];
   // Per-lane byte offsets of key row (k + fr) advance by a constant per trip and are clamped to the last row's
   // offset: one add and one min per operand instead of a clamped row index times a stride (quarter-rate multiplies).
@@ -720,8 +765,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p_in)
     for (int s = 0; s < 2; ++s) fv_next[s] = *reinterpret_cast<const Frag<T>*>(Vb + o + 16 * s * sizeof(T));
     vo += vstep;
   };
-  if (kfirst < p.S) request();
-  for (int k0 = kfirst; k0 < p.S; k0 += KSTEP) {
+  if (kfirst < kend) request();
+  for (int k0 = kfirst; k0 < kend; k0 += KSTEP) {
     Frag<T> fk[PARTS][2], fv[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -755,10 +800,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p_in)
         sacc[r] = pr * (dp - dl) * p.scale;            // dS^T
       }
     }
-    if (k0 + 32 > p.S) {                             // last tile only: keys past S (clamped duplicates) add nothing
+    if (k0 + 32 > kend) {                            // last tile only: keys past the end (clamped duplicates) add nothing
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        if (k0 + acc_row(r, lane) >= p.S) sacc[r] = 0.f;
+        if (k0 + acc_row(r, lane) >= kend) sacc[r] = 0.f;
     }
 #pragma unroll
     for (int pt = 0; pt < PARTS; ++pt) {
@@ -797,6 +842,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p_in)
       for (int r = 0; r < 16; ++r)
         dq[pt][r] += s_dq[0][pt][acc_row(r, lane)][fr] + s_dq[1][pt][acc_row(r, lane)][fr] +
                      s_dq[2][pt][acc_row(r, lane)][fr];
+    if (KS > 1) {      // across blocks: partial dQ^T tiles through split_ws, summed by the block with the last ticket
+      const int nqt = (p.Tq + 31) >> 5;
+      const long tile = ((long)b * p.H + h) * nqt + qt;
+      float* mine = p.split_ws + (tile * KS + ks) * (PARTS * 1024);
+#pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) store_sc1(mine + pt * 1024 + acc_row(r, lane) * 32 + fr, dq[pt][r]);
+      stores_done();                                   // (sc1 hand-off, common.h: no fences)
+      unsigned ticket = 0;
+      if (lane == 0) ticket = atomicAdd(p.split_tickets + tile, 1u);
+      ticket = __shfl(ticket, 0);
+      if (ticket != (unsigned)(KS - 1)) return;
+      const float* all = p.split_ws + tile * KS * (PARTS * 1024);
+#pragma unroll
+      for (int pt = 0; pt < PARTS; ++pt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[pt][r] = 0.f;
+      for (int s = 0; s < KS; ++s)                      // index order: the sum does not depend on who came last
+#pragma unroll
+        for (int pt = 0; pt < PARTS; ++pt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            dq[pt][r] += load_sc1(all + (s * PARTS + pt) * 1024 + acc_row(r, lane) * 32 + fr);
+      if (lane == 0) p.split_tickets[tile] = 0u;
+    }
   }
   if (q0 + fr < p.Tq) {
     const float fin = BIAS ? p.scale : 1.f;
@@ -1402,7 +1473,7 @@ int launch_all(int which, const AttnParams& p, hipStream_t stream) {
       else
         hipLaunchKernelGGL((attn_fwd_lds_kernel<PARTS, 8>), dim3(ceil_div(p.Tq, 256), p.H, p.B), dim3(512), 0, stream, p);
     } else if (split)
-      hipLaunchKernelGGL((attn_fwd_kernel<T, PARTS, true, DROP>), dim3(ceil_div(p.Tq, 32), p.H, p.B), block, 0, stream, p);
+      hipLaunchKernelGGL((attn_fwd_kernel<T, PARTS, true, DROP>), dim3(ceil_div(p.Tq, 32) * p.ksplit, p.H, p.B), block, 0, stream, p);
     else
       hipLaunchKernelGGL((attn_fwd_kernel<T, PARTS, false, DROP>), dim3(ceil_div(p.Tq, 128), p.H, p.B), block, 0, stream, p);
   } else if (which == 1) {
@@ -1410,7 +1481,7 @@ int launch_all(int which, const AttnParams& p, hipStream_t stream) {
     if (sizeof(T) == 2 && !DROP && !split && !(env_lds && env_lds[0] == '0'))
       hipLaunchKernelGGL((attn_bwd_dq_lds_kernel<PARTS, 4>), dim3(ceil_div(p.Tq, 128), p.H, p.B), dim3(256), 0, stream, p);
     else if (split)
-      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, PARTS, true, DROP>), dim3(ceil_div(p.Tq, 32), p.H, p.B), block, 0, stream, p);
+      hipLaunchKernelGGL((attn_bwd_dq_kernel<T, PARTS, true, DROP>), dim3(ceil_div(p.Tq, 32) * p.ksplit, p.H, p.B), block, 0, stream, p);
     else
       hipLaunchKernelGGL((attn_bwd_dq_kernel<T, PARTS, false, DROP>), dim3(ceil_div(p.Tq, 128), p.H, p.B), block, 0, stream, p);
   } else {
@@ -1464,6 +1535,23 @@ int fill(AttnParams& p, const fod_attn_shape* s) {
   p.drop_seed_lo = (unsigned)(s->drop_seed & 0xFFFFFFFFu);
   p.drop_seed_hi = (unsigned)(s->drop_seed >> 32);
   p.drop_seed_dev = s->drop_seed_dev;
+  // Key split across blocks for the few-query launches (the decoder's 128 queries: 64 blocks of 4 waves on 256 CUs,
+  // one wave per SIMD walking 12 tiles -- a quarter of the chip's vector units busy, 14 us).  With the caller's
+  // workspace: as many splits as fill the chip, each at least 128 keys (one tile per wave), at most 8.
+  p.ksplit = 1;
+  p.kchunk = p.S;
+  p.split_ws = reinterpret_cast<float*>(s->split_ws);
+  p.split_tickets = reinterpret_cast<unsigned*>(s->split_tickets);
+  if (s->split_ws && s->split_tickets && p.Tq <= 512 && p.S >= 256) {
+    const long tiles = (long)ceil_div(p.Tq, 32) * p.H * p.B;
+    int ks = (int)(256 / (tiles > 0 ? tiles : 1));
+    ks = ks > 8 ? 8 : ks;
+    ks = ks > p.S / 128 ? p.S / 128 : ks;
+    if (ks > 1) {
+      p.kchunk = ceil_div(ceil_div(p.S, ks), 128) * 128;
+      p.ksplit = ceil_div(p.S, p.kchunk);
+    }
+  }
   FOD_REQUIRE(p.drop_threshold == 0 || (long)s->Tq * s->S < (1L << 32), "attention: Tq * S too large for dropout indexing");
   FOD_REQUIRE(p.q_ts % 8 == 0 && p.k_ts % 8 == 0 && p.v_ts % 8 == 0 && p.o_ts % 8 == 0 && p.q_bs % 8 == 0 &&
                   p.k_bs % 8 == 0 && p.v_bs % 8 == 0 && p.o_bs % 8 == 0 && p.k2_bs % 8 == 0 && p.k2_ts % 8 == 0 &&

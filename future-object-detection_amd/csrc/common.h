@@ -160,6 +160,15 @@ FOD_DEVINL unsigned long long effective_seed(unsigned long long seed, const unsi
   return base_dev ? mix64(seed + *base_dev) : seed;
 }
 
+// Hand-off between workgroups WITHOUT fences (MI355X_MICROARCH.md, cross-workgroup hand-offs, first row of the sc1 table;
+// __threadfence() = buffer_wbl2 + buffer_inv costs 3.5-6.5 us per block): every handed-off word is stored and loaded
+// with sc1 (agent-scope relaxed atomics lower to global_store / global_load ... sc1: past the L1, coherent across XCDs),
+// the storing wave waits vmcnt(0) after its stores, one lane then takes an agent-scope ticket, and the block whose
+// ticket is the last one loads after its add has returned.
+FOD_DEVINL void store_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+FOD_DEVINL float load_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+FOD_DEVINL void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 FOD_DEVINL int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 FOD_DEVINL float wave_sum(float v) {

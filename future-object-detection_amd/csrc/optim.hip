@@ -72,15 +72,14 @@ __global__ __launch_bounds__(256) void multi_sqnorm_det_kernel(const long* __res
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) {
-    partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-    __threadfence();                                   // the partial is visible device-wide before the ticket is
+    store_sc1(partial + blockIdx.x, (red[0] + red[1]) + (red[2] + red[3]));
+    stores_done();                                     // sc1 hand-off (common.h): no fences
     last = atomicAdd(ticket, 1u) == gridDim.x - 1;
   }
-  __syncthreads();
+  __syncthreads();                                     // the other waves load after the barrier the adding wave joins
   if (!last) return;
-  __threadfence();                                     // acquire: every other block's partial
   float a = 0.f;
-  for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) a += __builtin_nontemporal_load(partial + i);
+  for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) a += load_sc1(partial + i);
   a = wave_sum(a);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
   __syncthreads();

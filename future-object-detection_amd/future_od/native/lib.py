@@ -39,7 +39,8 @@ class AttnShape(C.Structure):
                 ("scale", C.c_float),
                 ("k2_batch_stride", C.c_long), ("k2_token_stride", C.c_long),
                 ("dk2_batch_stride", C.c_long), ("dk2_token_stride", C.c_long),
-                ("drop_p", C.c_float), ("drop_seed", C.c_ulonglong), ("drop_seed_dev", C.c_void_p)]
+                ("drop_p", C.c_float), ("drop_seed", C.c_ulonglong), ("drop_seed_dev", C.c_void_p),
+                ("split_ws", C.c_void_p), ("split_tickets", C.c_void_p)]
 
 
 class PermuteJob(C.Structure):

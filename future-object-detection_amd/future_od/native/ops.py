@@ -363,8 +363,28 @@ def _attn_shape(q1, k1, v, o, scale, k2=None, dk2=None, drop_p=0.0, drop_seed=0)
     if dk2 is not None:
         assert dk2.shape == (B, S, E)
         d2b, d2t = _bt(dk2, "dk2", dtp)
+    ws = tk = None
+    if Tq <= 512 and S >= 256:
+        ws, tk = _attn_split_workspace(q1.device, B * H * ((Tq + 31) // 32))
     return AttnShape(B, H, Tq, S, qb, qt, kb, kt, vb, vt, ob, ot, scale, k2b, k2t, d2b, d2t, float(drop_p),
-                     int(drop_seed) & 0xFFFFFFFFFFFFFFFF, ptr(DROP_BASE) if drop_p > 0.0 else None), H
+                     int(drop_seed) & 0xFFFFFFFFFFFFFFFF, ptr(DROP_BASE) if drop_p > 0.0 else None, ptr(ws), ptr(tk)), H
+
+
+_ATTN_SPLIT = {}
+_ATTN_SPLIT_FLOATS_PER_TILE = 8 * 2176          # FOD_ATTN_SPLIT_WS_FLOATS_PER_TILE (include/fod.h)
+
+
+def _attn_split_workspace(device, tiles):
+    """Scratch of the launches whose keys are split across blocks (fod_attn_shape.split_ws / split_tickets): one per
+    device, reused by every call (the launches of one stream are ordered; the kernels leave the tickets zero)."""
+    key = (device.type, device.index)
+    hit = _ATTN_SPLIT.get(key)
+    if hit is None or hit[2] < tiles:
+        cap = max(tiles, 256)
+        hit = (torch.empty(cap * _ATTN_SPLIT_FLOATS_PER_TILE, dtype=torch.float32, device=device),
+               torch.zeros(cap, dtype=torch.int32, device=device), cap)
+        _ATTN_SPLIT[key] = hit
+    return hit[0], hit[1]
 
 
 def _same_bt(a, b, name):

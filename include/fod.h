@@ -190,7 +190,14 @@ typedef struct fod_attn_shape {
   /* optional device scalar (NULL = none): the seed used is mix64(drop_seed + *drop_seed_dev).  A captured step bakes
    * drop_seed into its graph and advances the device scalar once per replay (future_od/graph.py). */
   const unsigned long long* drop_seed_dev;
+  /* optional workspace for launches with few queries (Tq <= 512, S >= 256: the decoder's 128 queries): the keys are
+   * split across blocks so that the launch fills the chip, partial softmax states / dQ tiles meet here.
+   * split_ws: f32 [B*H*ceil(Tq/32) * 8 * 2176] (fod_attn_split_ws_floats), split_tickets: u32 [B*H*ceil(Tq/32)], all
+   * zero before the first launch (the kernels leave them zero).  NULL = no split across blocks. */
+  void* split_ws;
+  void* split_tickets;
 } fod_attn_shape;
+#define FOD_ATTN_SPLIT_WS_FLOATS_PER_TILE (8 * 2176)
 
 /* o = softmax((q1.k1 + q2.k2) * scale) v per head; head h = channels [32h, 32h+32) of every tensor.
  * q2/k2 NULL -> one part.  lse2 f32 [B,H,Tq] (log2 units) is saved for the backward.

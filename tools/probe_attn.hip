@@ -22,9 +22,13 @@ int main() {
   hipMemset(q, 0, big); hipMemset(k, 0, big); hipMemset(v, 0, big); hipMemset(k2, 0, big);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  struct Case { const char* name; int B, H, Tq, S, parts; long kts; };
-  const Case cases[] = {{"cross compact", 2, 8, 128, 1450, 2, 256}, {"cross hoisted (6 KB rows)", 2, 8, 128, 1450, 2, 3072},
-                        {"self 128x128", 2, 8, 128, 128, 1, 256}, {"encoder self 10x8x1450x1450", 10, 8, 1450, 1450, 1, 256}};
+  void *ws, *tk;
+  hipMalloc(&ws, 256 * FOD_ATTN_SPLIT_WS_FLOATS_PER_TILE * 4); hipMalloc(&tk, 4096);
+  hipMemset(tk, 0, 4096);
+  struct Case { const char* name; int B, H, Tq, S, parts; long kts; int split; };
+  const Case cases[] = {{"cross compact", 2, 8, 128, 1450, 2, 256, 0}, {"cross hoisted (6 KB rows)", 2, 8, 128, 1450, 2, 3072, 0},
+                        {"cross hoisted, keys over 4 blocks", 2, 8, 128, 1450, 2, 3072, 1},
+                        {"self 128x128", 2, 8, 128, 128, 1, 256, 0}, {"encoder self 10x8x1450x1450", 10, 8, 1450, 1450, 1, 256, 0}};
   for (auto& c : cases)
     for (int rep = 0; rep < 3; ++rep) {
       fod_attn_shape s = {};
@@ -35,6 +39,7 @@ int main() {
       s.o_batch_stride = (long)c.Tq * 256; s.o_token_stride = 256;
       s.k2_batch_stride = 0; s.k2_token_stride = c.parts == 2 ? 7680 : 0;     // the shared positional table's pitch
       s.scale = 0.125f;
+      if (c.split) { s.split_ws = ws; s.split_tickets = tk; }
       hipEventRecord(e0, 0);
       int rc = fod_attn_fwd(FOD_BF16, q, k, c.parts == 2 ? q : nullptr, c.parts == 2 ? k2 : nullptr, v, o, lse, &s, 0);
       hipEventRecord(e1, 0);
@@ -53,7 +58,7 @@ int main() {
       }
       static long long h[1024][4];
       hipMemcpyFromSymbol(h, HIP_SYMBOL(fod_blk_stamps), sizeof(h));
-      const int nb = (c.Tq / 32) * c.H * c.B;
+      const int nb = (c.Tq / 32) * c.H * c.B * (c.split ? 4 : 1);
       long long t0 = 1LL << 62, t3 = 0;
       double ph[3] = {0, 0, 0}, phmax[3] = {0, 0, 0};
       for (int blk = 0; blk < std::min(nb, 1024); ++blk) {
