@@ -21,6 +21,7 @@ struct TnParams {
   int g_seg_cols;                  // short-reduction kernel: G's columns in segments g_seg_stride elements apart
   long g_seg_stride;               //   (P same-shaped gradient tensors side by side); 0 = plain [M, N1]
   int Hs, Ws, Cs, Hd, Wd, kh, kw, stride, pad;
+  float* ws;                       // gemm_tn_big.hip: per-(split, tile) partial tiles, summed by a second launch; or NULL
 };
 
 // gemm_tn_big.hip: the 8-wave LDS-DMA kernel for long bf16 reductions (conv weight gradients, the encoder's Linear

@@ -577,7 +577,12 @@ int pick_splits(int tiles, int M) {
 
 template <int MODE>
 int launch_tn(int dtype, TnParams& p, hipStream_t stream) {
-  if (big_applies(MODE, dtype, p)) {        // long bf16 reductions: the 8-wave LDS-DMA kernel (gemm_tn_big.hip)
+  // long bf16 reductions: the 8-wave LDS-DMA kernel (gemm_tn_big.hip).  Not with a fused bias gradient (nn.Linear
+  // layers): the column sums would need a launch of their own there, and three launches (main, reduce, column sums) lose
+  // to this kernel's one on the encoder's shapes (gemm_tn_acc 2.36 -> 2.7 ms/step when they took it); FOD_TN_BIG=2
+  // (tests) takes it anyway.
+  const char* env_big = getenv("FOD_TN_BIG");
+  if (big_applies(MODE, dtype, p) && (!p.colsum || (env_big && env_big[0] == '2'))) {
     if (p.colsum) {
       const int rc = fod_colsum_acc(dtype, p.G, p.ldg, p.M, p.N1, 0, p.colsum, stream);
       if (rc != FOD_OK) return rc;

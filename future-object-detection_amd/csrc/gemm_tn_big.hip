@@ -273,21 +273,98 @@ __global__ __launch_bounds__(512) void tn_big_kernel(const TnParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) rs[a][r] = p.rscale[min(i0 + wi * 64 + a * 32 + acc_row(r, lane), p.N1 - 1)];
   }
+  if (p.ws) {
+    // partial tile of this (split, tile) by plain stores (128-B segments per half wave); tn_reduce_kernel sums the splits:
+    // ~21 us of f32 atomics per block (the memory-side atomic rate, whatever the launch) become ~4 us of stores plus one
+    // short launch, and the sum no longer depends on the order in which blocks finish
+    float* mine = p.ws + ((long)split * ntile + tile) * (BI * BJ);
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int j = j0 + wj * 64 + b * 32 + (lane & 31);
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = i0 + wi * 64 + a * 32 + acc_row(r, lane);
-        if (i < p.N1 && j < p.K2) atomicAdd(p.dW + (long)i * p.ldw + j, acc[a][b][r] * rs[a][r]);
-      }
+        for (int r = 0; r < 16; ++r)
+          mine[(wi * 64 + a * 32 + acc_row(r, lane)) * BJ + wj * 64 + b * 32 + (lane & 31)] = acc[a][b][r] * rs[a][r];
+  } else {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int j = j0 + wj * 64 + b * 32 + (lane & 31);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = i0 + wi * 64 + a * 32 + acc_row(r, lane);
+          if (i < p.N1 && j < p.K2) atomicAdd(p.dW + (long)i * p.ldw + j, acc[a][b][r] * rs[a][r]);
+        }
+    }
   }
 #ifdef FOD_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   BLK_STAMP(3);
 #endif
+}
+
+// dW[i, j] (+)= sum over the M-splits of the partial tiles, in a fixed order.  Block = 64 float4 columns of one row x 4
+// split lanes (lane q sums splits q, q + 4, ...; the four meet in LDS): weight gradients with few tiles have hundreds of
+// splits per output element.
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const TnParams p) {
+  __shared__ f32x4 red[3][64];
+  const int c4 = p.K2 >> 2;                                   // float4 columns per row (K2 % 8 == 0)
+  const int chunks = (c4 + 63) >> 6;
+  const int i = blockIdx.x / chunks;
+  const int j4 = (blockIdx.x - i * chunks) * 64 + (threadIdx.x & 63);
+  const int q = threadIdx.x >> 6;
+  const bool in = j4 < c4;
+  const int j = min(j4, c4 - 1) * 4;
+  const int ntile = p.ti * p.tj;
+  const int tile = (i / BI) * p.tj + j / BJ;
+  const float* src = p.ws + (long)tile * (BI * BJ) + (i % BI) * BJ + j % BJ;
+  const long stride = (long)ntile * (BI * BJ);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int s = q;
+  for (; s + 12 < p.nsplit; s += 16) {                        // four loads in flight
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (s + 0) * stride);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + (s + 4) * stride);
+    const f32x4 v2 = *reinterpret_cast<const f32x4*>(src + (s + 8) * stride);
+    const f32x4 v3 = *reinterpret_cast<const f32x4*>(src + (s + 12) * stride);
+    acc += v0;
+    acc += v1;
+    acc += v2;
+    acc += v3;
+  }
+  for (; s < p.nsplit; s += 4) acc += *reinterpret_cast<const f32x4*>(src + s * stride);
+  if (q > 0) red[q - 1][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (q > 0 || !in) return;
+  acc += red[0][threadIdx.x];
+  acc += red[1][threadIdx.x];
+  acc += red[2][threadIdx.x];
+  float* dst = p.dW + (long)i * p.ldw + j;
+  if (p.accumulate) acc += *reinterpret_cast<const f32x4*>(dst);
+  *reinterpret_cast<f32x4*>(dst) = acc;
+}
+
+// The partial tiles live in a per-device scratch of this library (64 MiB = 256 blocks x 256 KiB: one round of blocks
+// with room to spare), allocated at the first long weight-gradient launch.  One scratch per device: launches that use
+// it must be ordered on one stream (they are: the backward pass runs on the launching stream).  No allocation happens
+// inside a stream capture -- a capture that comes first keeps the atomic epilogue.
+constexpr size_t WS_BYTES = 64u << 20;
+float* workspace(hipStream_t stream) {
+  static float* ws[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!ws[dev]) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
+    void* q = nullptr;
+    if (hipMalloc(&q, WS_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    ws[dev] = reinterpret_cast<float*>(q);
+  }
+  return ws[dev];
 }
 
 template <int MODE, int BI, int BJ>
@@ -304,8 +381,18 @@ int launch_shape(const TnParams& p, hipStream_t stream) {
   }
   const int ntile = p.ti * p.tj;
   const dim3 grid(p.xcd_order ? 8 * ceil_div((long)ntile * p.nsplit, 8) : ntile * p.nsplit);
-  hipLaunchKernelGGL((tn_big_kernel<MODE, BI, BJ>), grid, dim3(512), lds, stream, p);
+  TnParams q = p;
+  q.ws = nullptr;
+  const char* env_ws = getenv("FOD_TN_WS");                      // "0": f32 atomics straight into dW (experiments)
+  const size_t need = (size_t)ntile * p.nsplit * BI * BJ * sizeof(float);
+  const bool aligned = ((uintptr_t)p.dW % 16) == 0 && p.ldw % 4 == 0;
+  if (p.nsplit > 1 && need <= WS_BYTES && aligned && !(env_ws && env_ws[0] == '0')) q.ws = workspace(stream);
+  hipLaunchKernelGGL((tn_big_kernel<MODE, BI, BJ>), grid, dim3(512), lds, stream, q);
   FOD_LAUNCH_CHECK();
+  if (q.ws) {
+    hipLaunchKernelGGL((tn_reduce_kernel<BI, BJ>), dim3(p.N1 * ceil_div(p.K2 / 4, 64)), dim3(256), 0, stream, q);
+    FOD_LAUNCH_CHECK();
+  }
   return FOD_OK;
 }
 
@@ -353,13 +440,16 @@ bool big_applies(int mode, int dtype, const TnParams& p) {
   if (mode == MODE_CONV && (long)p.Hs * p.Ws * p.Cs * 2 >= (1L << 31)) return false;   // 32-bit walks inside one image
   if (env && env[0] == '2') return p.M >= 1;
   // Measured per ResNet-50 layer at 10 x 900 x 1600 and on the encoder's shapes (tools/tn_big_probe.py,
-  // tools/probe_tn_big.hip): a block spends ~3 us in its prologue, ~1.0 us per 64-row stage (the L2 -> LDS stream of
-  // 48 KiB per stage and CU, ~12 TB/s over the chip, not the matrix pipe, sets that) and ~21 us adding its 32 K-element
-  // tile with f32 atomics (the memory-side atomic rate: the same for every launch that fills the chip).  Against the
-  // 128 x 128 kernel that wins where the reduction is long -- the 3x3, stride-2 and stage-entry convolutions (117 ->
-  // 100 us, 158 -> 139 us) -- and loses or ties below ~45 GFLOP per launch (28 stages per block: the fixed costs are
-  // two thirds of the launch).
-  return p.N1 >= 128 && p.K2 >= 128 && (double)p.M * p.N1 * p.K2 >= 2.2e10;
+  // tools/probe_tn_big.hip): a block spends ~3 us in its prologue and ~1.0 us per 64-row stage (the L2 -> LDS stream of
+  // 48 KiB per stage and CU, ~12 TB/s over the chip, not the matrix pipe, sets that); its 32 K-element partial tile
+  // costs ~21 us as f32 atomics (the memory-side atomic rate, whatever the launch) or ~4 us as plain stores plus a
+  // ~6 us reduce launch.  With the partial tiles this kernel wins from ~3 GFLOP per launch upwards (3x3 convolutions
+  // 116 -> 91 us, the encoder's feed-forward weight gradients 38 -> 29 us); below that the 128 x 128 kernel's single
+  // round of small blocks is faster (14500 x 256 x 256: 13 vs 18 us), and so it is for short reductions (the decoder's
+  // memory-side projections, M = 2900 rows: a handful of stages per block; gemm_tn_acc 2.2 -> 2.8 ms/step when they took
+  // this kernel).
+  const char* env_min = getenv("FOD_TN_BIG_MIN");               // experiment knob: M * N1 * K2 threshold
+  return p.M >= 8192 && p.N1 >= 128 && p.K2 >= 128 && (double)p.M * p.N1 * p.K2 >= (env_min ? atof(env_min) : 2.0e9);
 }
 
 int launch_big_mode(int mode, const TnParams& p, hipStream_t stream) {

@@ -28,7 +28,9 @@ def setenv(**kw):
             os.environ[k] = str(v)
 
 
-LAYERS = [("layer3.1.conv2", 10, 57, 100, 256, 256, 3, 1, 1), ("layer2.1.conv2", 10, 113, 200, 128, 128, 3, 1, 1),
+LAYERS = [("layer2.0.conv1", 10, 225, 400, 256, 128, 1, 1, 0), ("layer4.0.conv3", 10, 29, 50, 512, 2048, 1, 1, 0),
+          ("layer4.1.conv1", 10, 29, 50, 2048, 512, 1, 1, 0), ("layer2.1.conv1", 10, 113, 200, 512, 128, 1, 1, 0),
+          ("layer3.1.conv2", 10, 57, 100, 256, 256, 3, 1, 1), ("layer2.1.conv2", 10, 113, 200, 128, 128, 3, 1, 1),
           ("layer4.1.conv2", 10, 29, 50, 512, 512, 3, 1, 1), ("layer3.1.conv1", 10, 57, 100, 1024, 256, 1, 1, 0),
           ("layer2.0.conv3", 10, 113, 200, 128, 512, 1, 1, 0), ("layer3.0.conv3", 10, 57, 100, 256, 1024, 1, 1, 0)]
 for name, n, h, w, cin, cout, k, s, p in LAYERS:
@@ -41,15 +43,13 @@ for name, n, h, w, cin, cout, k, s, p in LAYERS:
     setenv(FOD_TN_BIG=0, FOD_TN_BIG_SPLITS=None, FOD_TN_XCD=None)
     t = timeit(run)
     out = [f"{name:16s} 128x128 {t * 1e6:6.1f} us {fl / t / 1e12:6.1f} TF |"]
-    setenv(FOD_TN_BIG=2)
+    setenv(FOD_TN_BIG=2, FOD_TN_WS=0)
     t = timeit(run)
-    out.append(f"big(plan) {t * 1e6:6.1f} us {fl / t / 1e12:6.1f} TF |")
-    for xcd in (1, 0):
-        for sp in sys.argv[1:] or ("8", "16"):
-            setenv(FOD_TN_BIG=2, FOD_TN_BIG_SPLITS=sp, FOD_TN_XCD=xcd)
-            t = timeit(run)
-            out.append(f"x{xcd} s{sp} {t * 1e6:6.1f}")
-    setenv(FOD_TN_BIG_SPLITS=None, FOD_TN_XCD=None)
+    out.append(f"big, atomics {t * 1e6:6.1f} us {fl / t / 1e12:6.1f} TF |")
+    setenv(FOD_TN_BIG=2, FOD_TN_WS=None)
+    t = timeit(run)
+    out.append(f"big, partial tiles + reduce {t * 1e6:6.1f} us {fl / t / 1e12:6.1f} TF")
+    setenv(FOD_TN_BIG=None)
     print(" ".join(out), flush=True)
 for M, N1, K2 in [(14500, 2048, 256), (14500, 256, 2048), (14500, 768, 256), (14500, 256, 256)]:
     gg = torch.randn(M, N1, device=DEV).to(dt)
@@ -59,6 +59,9 @@ for M, N1, K2 in [(14500, 2048, 256), (14500, 256, 2048), (14500, 768, 256), (14
     run = lambda: ops.gemm_tn_acc(gg, xx, dw)
     setenv(FOD_TN_BIG=0)
     t0 = timeit(run)
-    setenv(FOD_TN_BIG=2)
+    setenv(FOD_TN_BIG=2, FOD_TN_WS=0)
     t1 = timeit(run)
-    print(f"dense {M}x{N1}x{K2}: 128x128 {t0 * 1e6:6.1f} us {fl / t0 / 1e12:6.1f} TF | big {t1 * 1e6:6.1f} us {fl / t1 / 1e12:6.1f} TF", flush=True)
+    setenv(FOD_TN_BIG=2, FOD_TN_WS=None)
+    t2 = timeit(run)
+    setenv(FOD_TN_BIG=None)
+    print(f"dense {M}x{N1}x{K2}: 128x128 {t0 * 1e6:6.1f} us {fl / t0 / 1e12:6.1f} TF | big, atomics {t1 * 1e6:6.1f} us | big, partial tiles + reduce {t2 * 1e6:6.1f} us {fl / t2 / 1e12:6.1f} TF", flush=True)
