@@ -577,18 +577,14 @@ int pick_splits(int tiles, int M) {
 
 template <int MODE>
 int launch_tn(int dtype, TnParams& p, hipStream_t stream) {
-  // long bf16 reductions: the 8-wave LDS-DMA kernel (gemm_tn_big.hip).  Not with a fused bias gradient (nn.Linear
-  // layers): the column sums would need a launch of their own there, and three launches (main, reduce, column sums) lose
-  // to this kernel's one on the encoder's shapes (gemm_tn_acc 2.36 -> 2.7 ms/step when they took it); FOD_TN_BIG=2
-  // (tests) takes it anyway.
+  // long bf16 reductions: the 8-wave LDS-DMA kernel (gemm_tn_big.hip; the bias gradient is fused there too)
+  // nn.Linear layers (MODE_DENSE) stay here by default: in isolation the encoder's feed-forward weight gradients run
+  // 38 -> 30 us on the other kernel, inside the step (graph replay, same box, alternating runs) the difference is within
+  // the noise (22.42 / 22.75 vs 22.60 / 22.69 ms) -- FOD_TN_BIG_DENSE=1 or FOD_TN_BIG=2 (tests) send them there.
+  const char* env_dense = getenv("FOD_TN_BIG_DENSE");
   const char* env_big = getenv("FOD_TN_BIG");
-  if (big_applies(MODE, dtype, p) && (!p.colsum || (env_big && env_big[0] == '2'))) {
-    if (p.colsum) {
-      const int rc = fod_colsum_acc(dtype, p.G, p.ldg, p.M, p.N1, 0, p.colsum, stream);
-      if (rc != FOD_OK) return rc;
-    }
-    return launch_big_mode(MODE, p, stream);
-  }
+  const bool dense_ok = MODE != MODE_DENSE || (env_dense && env_dense[0] == '1') || (env_big && env_big[0] == '2');
+  if (dense_ok && big_applies(MODE, dtype, p)) return launch_big_mode(MODE, p, stream);
   const int tj = ceil_div(p.K2, 128), ti = ceil_div(p.N1, 128);
   int splits = pick_splits(ti * tj, p.M);
   static const char* env_rows = getenv("FOD_TN_ROWS");       // experiment knobs (tools/): rows per split, XCD order

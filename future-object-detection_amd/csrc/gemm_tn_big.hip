@@ -216,6 +216,19 @@ __global__ __launch_bounds__(512) void tn_big_kernel(const TnParams p) {
   // eight waves in lockstep behind the per-stage barrier, a burst of 48 pieces at the top of the stage kept the texture
   // path busy for ~770 cycles during which no wave had matrix work to issue (measured 1.0 us per stage against 0.43 us of
   // MFMA time at 2.4 GHz, tools/probe_tn_big.hip).
+  // Fused bias gradient (nn.Linear layers): colsum[i] += sum_m G[m, i] is one more product with an all-ones operand --
+  // no LDS reads, no extra launch.  Done by the blocks of the first tile column; the WJ waves that share a G fragment
+  // take turns over the k-steps (+12 % / +25 % matrix instructions for those blocks).
+  const bool do_cs = p.colsum != nullptr && bx == 0;
+  f32x16 cs[2];
+  Frag<__bf16> fones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) fones.v[j] = (__bf16)1.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cs[a][r] = 0.f;
+
   auto compute = [&](int stage, int fill) {
     const unsigned char* g_s = smem + stage * STAGE_BYTES;
     const unsigned char* x_s = g_s + G_BYTES;
@@ -233,6 +246,10 @@ __global__ __launch_bounds__(512) void tn_big_kernel(const TnParams p) {
       __builtin_amdgcn_sched_barrier(0);
       mma16(fa[ks & 1][1], fb[ks & 1][0], acc[1][0]);
       mma16(fa[ks & 1][1], fb[ks & 1][1], acc[1][1]);
+      if (do_cs && (ks % WJ) == wj) {
+        mma16(fa[ks & 1][0], fones, cs[0]);
+        mma16(fa[ks & 1][1], fones, cs[1]);
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (ks == 0) issue_piece(fill, std::integral_constant<int, 1>{});
       if (ks == 1) issue_piece(fill, std::integral_constant<int, 3>{});
@@ -272,6 +289,15 @@ __global__ __launch_bounds__(512) void tn_big_kernel(const TnParams p) {
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) rs[a][r] = p.rscale[min(i0 + wi * 64 + a * 32 + acc_row(r, lane), p.N1 - 1)];
+  }
+  if (do_cs && (lane & 31) == 0) {                      // every column of a row-sum tile holds the same sum
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = i0 + wi * 64 + a * 32 + acc_row(r, lane);
+        if (i < p.N1) atomicAdd(p.colsum + i, cs[a][r]);
+      }
   }
   if (p.ws) {
     // partial tile of this (split, tile) by plain stores (128-B segments per half wave); tn_reduce_kernel sums the splits:
@@ -446,8 +472,7 @@ bool big_applies(int mode, int dtype, const TnParams& p) {
   // ~6 us reduce launch.  With the partial tiles this kernel wins from ~3 GFLOP per launch upwards (3x3 convolutions
   // 116 -> 91 us, the encoder's feed-forward weight gradients 38 -> 29 us); below that the 128 x 128 kernel's single
   // round of small blocks is faster (14500 x 256 x 256: 13 vs 18 us), and so it is for short reductions (the decoder's
-  // memory-side projections, M = 2900 rows: a handful of stages per block; gemm_tn_acc 2.2 -> 2.8 ms/step when they took
-  // this kernel).
+  // memory-side projections, M = 2900 rows: a handful of stages per block).
   const char* env_min = getenv("FOD_TN_BIG_MIN");               // experiment knob: M * N1 * K2 threshold
   return p.M >= 8192 && p.N1 >= 128 && p.K2 >= 128 && (double)p.M * p.N1 * p.K2 >= (env_min ? atof(env_min) : 2.0e9);
 }
