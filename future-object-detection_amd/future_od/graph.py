@@ -14,12 +14,14 @@ costs the host one call.  What made the step capturable:
 
 Data parallel (`GraphedStep(bare_model, opt, data_parallel=True)`): the step is TWO graphs with the collectives between them, launched eagerly --
     [graph A: zero_grad, forward, backward]  ->  all_reduce(AVG) of the flat gradient arena (one large message, plus the
-    few gradients autograd allocated itself)  ->  [graph B: clip + AdamW].
+    few gradients autograd allocated itself)  ->  [graph B: clip + AdamW]
+(FOD_GRAPH_OVERLAP=1 splits graph A at the backbone's output and sends the transformer's gradients while the backbone's
+backward runs; off by default, see __init__).
 No collective is captured (RCCL inside a hipGraph could not be verified on the one-GPU boxes this was built on; a hang
 there would void a whole scaling run): the loss normaliser `num_boxes`, the only collective of the forward pass, is
 all-reduced from the batch's annotations BEFORE graph A and fed in as an input (`data["_num_boxes"]`).  The gradient
-average is therefore not overlapped with the backward pass (215 MB over xGMI, ~1-2 ms at 8 GPUs), which costs less than
-the ~6 ms per step the eagerly launched data-parallel step loses to the launching thread (bench.py --no-graph).
+average is not overlapped with the backward pass (215 MB over xGMI, ~1-2 ms at 8 GPUs), which costs less than the ~6 ms
+per step the eagerly launched data-parallel step loses to the launching thread (bench.py --no-graph).
 
 Dropout (train mode, p > 0): the masks are stateless hashes of (seed, index); a captured kernel carries its call's
 seed as a constant, so the kernels additionally mix in a device scalar (`ops.DROP_BASE`) that the graph advances once
@@ -58,6 +60,14 @@ class GraphedStep:
         # rollback_warmup the parameters, moments and step counts are put back afterwards, so that a training loop
         # sees exactly one update per batch (the Trainer asks for this; the benchmark does not care)
         self.rollback_warmup = bool(rollback_warmup)
+        # data parallel, opt-in (FOD_GRAPH_OVERLAP=1): split the captured backward at the backbone's output and average the
+        # transformer gradients while the backbone's backward runs.  Off by default: measured with a one-rank RCCL group
+        # on one GPU the third graph launch and the concurrent collective cost 0.95 ms per step (24.43 vs 23.48 ms),
+        # about what the overlap could hide at 8 GPUs, and a two-rank gloo rehearsal with full-size gradients stalled in
+        # the asynchronous collective (6.7 s per step) -- not something to leave on for a scaling run that cannot be
+        # rehearsed on RCCL here.
+        import os
+        self.overlap = os.environ.get("FOD_GRAPH_OVERLAP", "0") == "1"
 
     def broadcast_parameters(self, src=0):
         """Rank `src`'s parameters and buffers to every rank (what DistributedDataParallel's constructor does)."""
@@ -118,19 +128,25 @@ class GraphedStep:
         self._all_reduce(n, average=True)
         out.copy_(n.clamp_(min=1.0))
 
-    def _all_reduce(self, t, average=True):
-        group = self.group
-        if average and dist.get_backend(group) == "nccl":
-            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
-        else:                                                   # gloo (rehearsal on one GPU): sum, then scale
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-            if average:
-                t.div_(self.world)
+    def _native_avg(self):
+        return dist.get_backend(self.group) == "nccl"
 
-    def _reduce_targets(self):
-        """What graph A leaves to be averaged: the arena region that holds gradients as ONE flat tensor (everything in
-        it that is not a gradient is a dead temporary: averaging it is harmless) plus the gradients that live elsewhere
-        (sums autograd allocated itself).  Static addresses: every replay rewrites the same memory."""
+    def _all_reduce(self, t, average=True, async_op=False):
+        group = self.group
+        if average and self._native_avg():
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
+        # gloo (rehearsal on one GPU): sum, then scale (an asynchronous call leaves the scaling to its caller)
+        work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if average and not async_op:
+            t.div_(self.world)
+        return work
+
+    def _reduce_targets(self, arena_from=0, skip=()):
+        """What a captured backward piece leaves to be averaged: the arena region that holds gradients as ONE flat tensor
+        (everything in it that is not a gradient is a dead temporary: averaging it is harmless) plus the gradients that
+        live elsewhere (sums autograd allocated itself).  Static addresses: every replay rewrites the same memory.
+        `arena_from` / `skip`: only arena gradients from that element offset on, none of the tensors whose data_ptr is
+        in `skip` -- the second piece of a split backward."""
         grads = [p.grad for p in self.core.parameters() if p.requires_grad and p.grad is not None]
         buf = Fn.ARENA.buf if Fn.ARENA.active else None
         targets, lo, hi = [], None, None
@@ -140,10 +156,12 @@ class GraphedStep:
             if inside:
                 # the extent of the gradient's storage footprint inside the arena (channels_last views included)
                 first = (g.data_ptr() - buf.data_ptr()) // 4
+                if first < arena_from:
+                    continue
                 last = first + sum((n - 1) * s for n, s in zip(g.shape, g.stride())) + 1
                 lo = first if lo is None else min(lo, first)
                 hi = last if hi is None else max(hi, last)
-            else:
+            elif g.data_ptr() not in skip:
                 targets.append(g)
         if lo is not None:
             targets.insert(0, buf[lo:hi])
@@ -213,17 +231,35 @@ class GraphedStep:
         # data parallel: the collectives stay outside the two graphs
         self._global_num_boxes(static, static["_num_boxes"])
         torch.cuda.synchronize(dev)
+        # The backward pass in two pieces (native/functional.py: BackboneCut): A1 = forward + everything down to the
+        # backbone's output (all transformer gradients), A2 = the backbone's backward.  The transformer gradients are
+        # all-reduced while A2 runs -- the overlap the eager reducer has (parallel.py), without a collective in a graph.
         graph_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph_a):
-            outs = self._forward_backward(static)
-        targets = self._reduce_targets()
+        cut = Fn.BackboneCut() if self.overlap else None
+        Fn.BACKBONE_CUT = cut
+        try:
+            with torch.cuda.graph(graph_a):
+                outs = self._forward_backward(static)
+        finally:
+            Fn.BACKBONE_CUT = None
+        first = self._reduce_targets()
+        graph_a2, second = None, []
+        if cut is not None and cut.pairs:
+            off1 = Fn.ARENA.off if Fn.ARENA.active else 0
+            graph_a2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_a2, pool=graph_a.pool()):
+                cut.finish()
+            second = self._reduce_targets(arena_from=off1, skip={t.data_ptr() for t in first})
         graph_b = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph_b, pool=graph_a.pool()):
             self.opt.step()
         torch.cuda.synchronize(dev)
         self.opt._step_no -= 1
-        self.comm_stats = {"tensors": len(targets), "bytes": sum(t.numel() * t.element_size() for t in targets)}
-        return {"graph": graph_a, "graph_opt": graph_b, "targets": targets, "static": static, "outs": outs}
+        both = first + second
+        self.comm_stats = {"tensors": len(both), "bytes": sum(t.numel() * t.element_size() for t in both),
+                           "overlapped_bytes": sum(t.numel() * t.element_size() for t in first) if graph_a2 else 0}
+        return {"graph": graph_a, "graph_bb": graph_a2, "graph_opt": graph_b, "targets": first, "targets_bb": second,
+                "static": static, "outs": outs}
 
     # ------------------------------------------------------------------------------------------
     def __call__(self, data, sync=True):
@@ -243,9 +279,24 @@ class GraphedStep:
             self._global_num_boxes(g["static"], g["static"]["_num_boxes"])
         g["graph"].replay()
         if self.ddp:
+            pending = []
             if sync:
-                for t in g["targets"]:
-                    self._all_reduce(t)
+                if g["graph_bb"] is not None:
+                    # issued behind graph A1 on the collective's own stream: runs while graph A2 does
+                    pending = [self._all_reduce(t, async_op=True) for t in g["targets"]]
+                else:
+                    for t in g["targets"]:
+                        self._all_reduce(t)
+            if g["graph_bb"] is not None:
+                g["graph_bb"].replay()
+                if sync:
+                    for t in g["targets_bb"]:
+                        self._all_reduce(t)
+                    for w in pending:
+                        w.wait()                     # stream-ordered for RCCL: the launching stream waits, not the host
+                    if pending and not self._native_avg():
+                        for t in g["targets"]:
+                            t.div_(self.world)
             g["graph_opt"].replay()
         self.opt._step_no += 1
         self.replays += 1

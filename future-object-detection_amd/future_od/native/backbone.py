@@ -290,4 +290,7 @@ def backbone_trainable(body, proj):
 
 
 def run_backbone(video, body, proj, dtype):
-    return BackboneFn.apply(video, body, proj, dtype, *backbone_trainable(body, proj))
+    feat = BackboneFn.apply(video, body, proj, dtype, *backbone_trainable(body, proj))
+    if Fn.BACKBONE_CUT is not None and feat.requires_grad:
+        feat = Fn.BACKBONE_CUT.cut(feat)
+    return feat

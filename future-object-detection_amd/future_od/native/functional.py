@@ -187,6 +187,29 @@ def set_grad_sync(reducer):
     GRAD_SYNC = reducer
 
 
+class BackboneCut:
+    """Cuts the autograd graph at the backbone's output so that a backward pass can run in TWO pieces: `loss.backward()`
+    stops at the returned leaf (every transformer gradient + d loss / d features), `finish()` then runs the backbone's
+    backward from it.  A data-parallel captured step (future_od/graph.py) puts the two pieces into separate graphs and
+    averages the transformer gradients across ranks WHILE the backbone piece runs."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def cut(self, feat):
+        leaf = feat.detach().requires_grad_(True)
+        self.pairs.append((feat, leaf))
+        return leaf
+
+    def finish(self):
+        pairs, self.pairs = self.pairs, []
+        if pairs:
+            torch.autograd.backward([f for f, _ in pairs], [l.grad for _, l in pairs])
+
+
+BACKBONE_CUT = None
+
+
 def zeros_f32(shape, device):
     return ARENA.zeros(tuple(shape), device)
 

@@ -191,7 +191,11 @@ def _graph_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_captured_step_matches_eager_data_parallel():
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_two_ranks_captured_step_matches_eager_data_parallel(overlap, monkeypatch):
+    """overlap = "1": the captured backward split at the backbone's output, the transformer's gradients all-reduced
+    asynchronously while the backbone's backward graph runs (FOD_GRAPH_OVERLAP, off by default)."""
+    monkeypatch.setenv("FOD_GRAPH_OVERLAP", overlap)
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
