@@ -9,6 +9,7 @@ hits are included in both.  Kernels are keyed by the C-ABI entry point they impl
 import collections, csv, glob, json, re, sys
 
 ENTRY = [  # (substring of the kernel name, entry point)
+    ("tn_big_kernel<1", "fod_conv2d_wgrad_acc"), ("tn_big_kernel<0", "fod_gemm_tn_acc"), ("tn_reduce_kernel", "fod_conv2d_wgrad_acc"),
     ("nt_big_kernel<0>", "fod_gemm_nt"), ("nt_big_kernel<1>", "fod_conv2d_fwd"), ("nt_big_kernel<2>", "fod_conv2d_dgrad"),
     ("nt_big_kernel<3>", "fod_conv2d_dgrad"), ("conv_stem_fwd_kernel", "fod_conv2d_fwd"),
     ("stem_layout_kernel", "fod_clip_to_stem_layout"), ("lap_dev_kernel", "fod_lap_solve_batch_dev"),
