@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="N=1 only: launch every kernel from Python (the default replays the step as one hipGraph)")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="the evaluation pass (no_grad forward incl. set loss, post-processing, AP bookkeeping) instead of "
+                         "the training step; N = 1; for the record, not the headline")
     ap.add_argument("--train-mode", action="store_true",
                     help="model.train(): the reference's dropout 0.1 active (BASELINE.md measures model.eval() with "
                          "autograd on, the default here); for the record, not the headline")
@@ -209,8 +212,19 @@ def main():
             opt.step()
             return loss
 
+        if a.forward_only:
+            def step():                                  # noqa: F811  (the evaluation pass of the reference's Trainer)
+                with torch.no_grad():
+                    out, _state, loss, stats, od = model(data=data, distributed=distributed)
+                return loss
+
         eager_step = step
-        if use_graph:
+        if use_graph and a.forward_only:
+            from future_od.graph import GraphedForward
+            fwd = GraphedForward(model)
+            fwd(data)
+            step = lambda: fwd(data)[1]
+        elif use_graph:
             # the same step -- same kernels, same order -- captured once and replayed (future_od/graph.py); the
             # capture and its eager warm-up steps happen before the timed region
             from future_od.graph import GraphedStep
@@ -308,6 +322,7 @@ def main():
                    "num_images": a.num_images, "parallelism": f"dp{world}"},
         "final_loss": final_loss,
         "model_mode": "train (dropout 0.1 active)" if a.train_mode else "eval (BASELINE.md: eval-mode math, autograd on)",
+        "step": "evaluation pass (no_grad forward + set loss + post-processing)" if a.forward_only else "training step",
         "launch_mode": ("eager (one Python call per kernel)" if not use_graph else
                         "hipgraph replay (one graph per step)" if not distributed else
                         "hipgraph replay (forward + backward graph, eager gradient all-reduce, optimizer graph)"),

@@ -188,12 +188,16 @@ class SlotToImageAttention(Attention):
         self.droprate = dropout            # on the attention probabilities (reference :126)
         self.store_attention = False
 
-    def forward(self, x, qpos, query_sine, side, layer, image, is_first, qs=None, qpos_proj=None):
+    def forward(self, x, qpos, query_sine, side, layer, image, is_first, qs=None, qpos_proj=None, keep=False):
         """`side` (functional.MemorySide) holds this image's value / key_content projections for ALL layers
         and the projected positional table; this call uses the (layer, image) slots.  `qs` = query_sine(query_sine)
-        and `qpos_proj` = query_pos(qpos) when the caller has projected them for all images at once."""
+        and `qpos_proj` = query_pos(qpos) when the caller has projected them for all images at once.
+        `keep`: also return x for the residual step (one autograd consumer of x instead of two, Fn.LinearKeepFn)."""
         B, M, D = x.shape
-        qc = _lin(x, self.query_content)
+        if keep:
+            x_keep, qc = Fn.linear_keep(x, self.query_content.weight, self.query_content.bias)
+        else:
+            qc = _lin(x, self.query_content)
         if is_first:
             qc = Fn.add(qc, qpos_proj if qpos_proj is not None else _lin(qpos, self.query_pos), b_row_mod=M)
         if qs is None:
@@ -210,7 +214,7 @@ class SlotToImageAttention(Attention):
         if self.store_attention:
             kc, ks, _v = side.slots(layer, image)
             self.stored_attention = _head_mean_weights(qc, kc, qs, ks.unsqueeze(0).expand(B, -1, -1), self.Nhead)
-        return _Proj(a, self.fun.out_proj)
+        return (_Proj(a, self.fun.out_proj), x_keep) if keep else _Proj(a, self.fun.out_proj)
 
 
 @torch.no_grad()
@@ -259,8 +263,8 @@ class TransformerDecoderLayer(nn.Module):
         # the sine embedding is the same for every image of the layer: all their query_sine projections at once
         qs_all = Fn.group_linear(query_sine, [self.image_attend[i].query_sine for i in range(side.K)])
         for i in range(side.K):
-            o = self.image_attend[i](x, qpos, query_sine, side, layer, i, is_first, qs=qs_all[i],
-                                     qpos_proj=pos_proj["ca"][i] if (pos_proj and is_first) else None)
+            o, x = self.image_attend[i](x, qpos, query_sine, side, layer, i, is_first, qs=qs_all[i],
+                                        qpos_proj=pos_proj["ca"][i] if (pos_proj and is_first) else None, keep=True)
             x = _add_norm(x, o, self.norm_ia[i], p, t)
         if self.slotstates_attend is not None and slotstates is not None:
             o = self.slotstates_attend.forward_cross(x, qpos, slotstates)
@@ -274,7 +278,8 @@ class TransformerDecoderLayer(nn.Module):
             x = Fn.layer_norm(x, self.norm_eda.weight, self.norm_eda.bias, residual=e, res_row_div=x.shape[1])
             if torch.is_grad_enabled():
                 x = Fn.ZeroGradAnchor.apply(x, *self.egodeep_attend.dead_parameters())
-        h = Fn.dropout(_lin(x, self.feedforward[0], relu=True), p, t)
+        x, h = Fn.linear_keep(x, self.feedforward[0].weight, self.feedforward[0].bias, relu=True)
+        h = Fn.dropout(h, p, t)
         return _add_norm(x, _Proj(h, self.feedforward[3]), self.norm_out, p, t)
 
 
@@ -373,7 +378,8 @@ class EncoderAttention(nn.Module):
         a = Fn.attention(q, k, v, 1.0 / math.sqrt(D // self.H), drop_p=self.droprate, training=self.training)
         t, p = self.training, self.droprate
         src = _add_norm(src, _Proj(a, self.attn.out_proj), self.norm1, p, t)
-        h = Fn.dropout(_lin(src, self.mlp[0], relu=True), p, t)
+        src, h = Fn.linear_keep(src, self.mlp[0].weight, self.mlp[0].bias, relu=True)
+        h = Fn.dropout(h, p, t)
         return _add_norm(src, _Proj(h, self.mlp[3]), self.norm2, p, t)
 
 

@@ -355,6 +355,57 @@ def linear(x, weight, bias=None, relu=False, out_f32=False):
     return LinearFn.apply(x.contiguous(), weight, bias, relu, out_f32)
 
 
+class LinearKeepFn(Function):
+    """(x, act(x W^T + b)): the projection of a tensor that is ALSO the residual of the sub-layer it opens.  As two
+    consumers of x, autograd would sum their gradients with a kernel of its own (a 5 us graph node per sub-layer, ~45 per
+    step); here the residual path's gradient enters the projection's input-gradient GEMM as its epilogue operand."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        dtype = x.dtype
+        w = prep_linear(weight, dtype, False)
+        N = weight.shape[0]
+        y = ops.gemm_nt(x, w[:N] if w.shape[0] != N else w, shift=bias, relu=relu).view(*x.shape[:-1], N)
+        ctx.relu, ctx.weight, ctx.has_bias = relu, weight, bias is not None
+        ctx.save_for_backward(x, y if relu else None)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, dkeep, dy):
+        x, y = ctx.saved_tensors
+        weight = ctx.weight
+        dtype = x.dtype
+        N, K = weight.shape
+        assert N % _VEC[dtype] == 0
+        g = dy.contiguous().view(-1, N)
+        if g.dtype != dtype:
+            g = cast(g, dtype)
+        if ctx.relu:
+            g = ops.eltwise(L.EW_RELU_MASK, g, y.view(-1, N))
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            res = None if dkeep is None else dkeep.contiguous().view(-1, K)
+            if res is not None and res.dtype != dtype:
+                res = cast(res, dtype)
+            dx = ops.gemm_nt(g, prep_linear(weight, dtype, True), residual=res).view(x.shape)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        dbp = zeros_f32((N,), x.device) if want_db else None
+        if ctx.needs_input_grad[1]:
+            dw = zeros_f32((N, K), x.device)
+            ops.gemm_tn_acc(g, x.view(-1, K), dw, colsum=dbp, zeroed=True)
+        elif want_db:
+            ops.colsum_acc(g, dbp)
+        return dx, dw, dbp, None
+
+
+def linear_keep(x, weight, bias=None, relu=False):
+    """-> (x for the residual path, act(x W^T + b)); see LinearKeepFn.  Falls back to two consumers when the output
+    width does not fit the vector epilogue."""
+    if weight.shape[0] % _VEC[x.dtype] != 0:
+        return x, linear(x, weight, bias, relu=relu)
+    return LinearKeepFn.apply(x.contiguous(), weight, bias, relu)
+
+
 class AddFn(Function):
     """a + b[row(m)], b broadcast over row groups (div) or periodically (mod)."""
 

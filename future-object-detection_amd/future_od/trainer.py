@@ -127,6 +127,25 @@ class Trainer:
             g = self._graphed = GraphedStep(self._model, self._optimizer, warmup=2, rollback_warmup=True)
         return g
 
+    def _graphed_forward(self):
+        """The evaluation pass as one captured hipGraph (future_od/graph.py: GraphedForward), same conditions as the
+        captured training step; FOD_GRAPH_EVAL=0 keeps the eager loop."""
+        g = getattr(self, "_graphed_eval", None)
+        if g is False:
+            return None
+        if g is None:
+            import os
+            from future_od.models.set_criterion import device_matching_enabled
+            dev = torch.device(self._device)
+            ok = (os.environ.get("FOD_GRAPH_EVAL", "1") != "0" and not self._distributed and dev.type == "cuda"
+                  and device_matching_enabled(dev) and not torch.is_grad_enabled())
+            if not ok:
+                self._graphed_eval = False
+                return None
+            from future_od.graph import GraphedForward
+            g = self._graphed_eval = GraphedForward(self._model)
+        return g
+
     @staticmethod
     def _fetch_async(tensors):
         """Device tensors -> pinned host copies queued on the stream, plus the event that says when they are there.
@@ -163,6 +182,7 @@ class Trainer:
                     od_lists[j].extend(hod[j * n:(j + 1) * n])
 
         graphed = self._graphed_step() if mode == "train" else None
+        graphed_eval = self._graphed_forward() if mode != "train" else None
         for i, data in enumerate(DevicePrefetcher(data_loader, self._device)):      # next batch staged on a side stream
             if EXIT.is_set():
                 return
@@ -182,8 +202,17 @@ class Trainer:
             else:
                 if mode == "train":
                     self._optimizer.zero_grad()
-                out, _state, loss, stats, od = self._model(data=data, visualize=False, epoch=self._epoch,
-                                                           distributed=self._distributed)
+                done = False
+                if graphed_eval is not None:
+                    try:
+                        out, loss, stats, od = graphed_eval(data)     # the evaluation pass: one launch
+                        done = True
+                    except Exception as e:
+                        print(f"[fod] captured evaluation pass unavailable ({type(e).__name__}: {e}); launching eagerly")
+                        self._graphed_eval, graphed_eval = False, None
+                if not done:
+                    out, _state, loss, stats, od = self._model(data=data, visualize=False, epoch=self._epoch,
+                                                               distributed=self._distributed)
             if mode == "train" and graphed is None:
                 loss.backward()
                 if self._epoch == 1 and i == 0:

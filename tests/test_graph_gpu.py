@@ -173,3 +173,29 @@ def test_captured_train_mode_step_draws_new_dropout_masks_every_replay():
     last = sum(float(step(data)[1].detach()) for _ in range(4)) / 4
     assert last < first, (first, last)
     ops.DROP_BASE = None
+
+
+def test_captured_evaluation_pass_tracks_parameter_updates():
+    """GraphedForward: the captured no-grad forward gives the eager forward's loss / detections bit for bit, and keeps
+    doing so after the parameters were updated in place (its first node refreshes the prepared weight copies)."""
+    from future_od.datasets.synthetic import make_batch
+    from future_od.graph import GraphedForward
+    data = make_batch(2, 3, 96, 128, seed=31, max_boxes=9, device=DEV)
+    model, opt = _build("bf16")
+    fwd = GraphedForward(model)
+
+    def eager():
+        with torch.no_grad():
+            post, _, loss, stats, od = model(data=data, distributed=False)
+        return float(loss), post["boxes"].clone(), [t.clone() for t in od]
+
+    for round_ in range(2):
+        post, loss, stats, od = fwd(data)
+        l_e, boxes_e, od_e = eager()
+        assert float(loss) == l_e, (round_, float(loss), l_e)
+        assert torch.equal(post["boxes"], boxes_e)
+        for a, b in zip(od, od_e):
+            assert torch.equal(a, b)
+        _eager_step(model, opt, data)          # parameters move (fused AdamW writes them through raw pointers)
+        _eager_step(model, opt, data)
+    assert fwd.replays == 2 and len(fwd._graphs) == 1

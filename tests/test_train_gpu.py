@@ -70,6 +70,8 @@ def test_trainer_short_run(tmp_path):
     # the capture's warm-up steps were rolled back
     assert tr._graphed not in (None, False) and tr._graphed.replays == 12 and len(tr._graphed._graphs) == 1
     assert opt._step_no == 12 and tr._training_iterations == 12
+    # ... and the two evaluation passes as replays of one captured forward
+    assert tr._graphed_eval not in (None, False) and tr._graphed_eval.replays == 2 and len(tr._graphed_eval._graphs) == 1
     hist = tr._stats["train labels loss"].history
     assert len(hist) == 2 and all(h == h for h in hist)            # finite
     total = [sum(tr._stats[f"train {k} loss"].history[e] for k in ("labels", "box_l1", "box_giou")) for e in range(2)]
