@@ -398,10 +398,13 @@ class LinearKeepFn(Function):
         return dx, dw, dbp, None
 
 
+_LINEAR_KEEP = __import__("os").environ.get("FOD_LINEAR_KEEP", "1") != "0"       # "0": two autograd consumers (experiments)
+
+
 def linear_keep(x, weight, bias=None, relu=False):
     """-> (x for the residual path, act(x W^T + b)); see LinearKeepFn.  Falls back to two consumers when the output
     width does not fit the vector epilogue."""
-    if weight.shape[0] % _VEC[x.dtype] != 0:
+    if weight.shape[0] % _VEC[x.dtype] != 0 or not _LINEAR_KEEP:
         return x, linear(x, weight, bias, relu=relu)
     return LinearKeepFn.apply(x.contiguous(), weight, bias, relu)
 
