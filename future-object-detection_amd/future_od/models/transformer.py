@@ -370,11 +370,14 @@ class EncoderAttention(nn.Module):
         D = self.D
         N = pos.shape[-2]
         add_pos = (lambda t: Fn.add(t, pos, b_row_mod=N)) if pos.dim() == 2 else (lambda t: Fn.add(t, pos))
-        xp = add_pos(src)
-        if other is None:
-            q, k, v = Fn.in_proj(xp, src, self.attn.in_proj_weight, self.attn.in_proj_bias)
+        fused = Fn.in_proj_self(src, pos, self.attn.in_proj_weight, self.attn.in_proj_bias) if other is None else None
+        if fused is not None:
+            src, q, k, v = fused               # one autograd consumer of src (positional add, projections, residual)
+        elif other is None:
+            q, k, v = Fn.in_proj(add_pos(src), src, self.attn.in_proj_weight, self.attn.in_proj_bias)
         else:
-            q, k, v = Fn.in_proj_cross(xp, add_pos(other), other, self.attn.in_proj_weight, self.attn.in_proj_bias)
+            q, k, v = Fn.in_proj_cross(add_pos(src), add_pos(other), other, self.attn.in_proj_weight,
+                                       self.attn.in_proj_bias)
         a = Fn.attention(q, k, v, 1.0 / math.sqrt(D // self.H), drop_p=self.droprate, training=self.training)
         t, p = self.training, self.droprate
         src = _add_norm(src, _Proj(a, self.attn.out_proj), self.norm1, p, t)

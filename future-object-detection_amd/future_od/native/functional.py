@@ -804,6 +804,60 @@ def in_proj(xp, src, weight, bias):
     return InProjFn.apply(xp.contiguous(), src.contiguous(), weight, bias)
 
 
+class InProjSelfFn(Function):
+    """The encoder's self-attention input side as ONE autograd consumer of src: xp = src + pos, q | k = xp W_qk^T, v =
+    src W_v^T, and src handed back for the residual step.  Separately, src has three consumers (the positional add,
+    the v projection, the residual) and autograd sums their gradients with two kernels of its own per layer (14500 x 256
+    elements each); here the residual gradient rides in the q | k input-gradient GEMM's epilogue and that result in the
+    v one's.  `pos` (a table or per-frame tensor without gradient) is broadcast by the add kernel."""
+
+    @staticmethod
+    def forward(ctx, src, pos, w, b, row_mod):
+        D = w.shape[1]
+        dtype = src.dtype
+        xp = ops.eltwise(L.EW_ADD, src, pos, b_row_mod=row_mod)
+        wqk, wv = prep_linear(w[:2 * D], dtype, False), prep_linear(w[2 * D:], dtype, False)
+        qk = ops.gemm_nt(xp, wqk, shift=b[:2 * D]).view(*xp.shape[:-1], 2 * D)
+        v = ops.gemm_nt(src, wv, shift=b[2 * D:]).view(src.shape)
+        ctx.save_for_backward(xp, src)
+        ctx.w, ctx.b = w, b
+        return src.view_as(src), qk[..., :D], qk[..., D:], v
+
+    @staticmethod
+    def backward(ctx, dkeep, dq, dk, dv):
+        xp, src = ctx.saved_tensors
+        w, b = ctx.w, ctx.b
+        D = w.shape[1]
+        dtype = xp.dtype
+        rows = xp.numel() // D
+        dqk = _column_siblings(dq, dk)
+        if dqk is None:
+            dqk = torch.cat([dq, dk], dim=-1)
+        dqk = dqk.reshape(rows, 2 * D)
+        dv = dv.contiguous().view(rows, D)
+        dsrc = None
+        if ctx.needs_input_grad[0]:
+            res = None if dkeep is None else dkeep.contiguous().view(rows, D)
+            if res is not None and res.dtype != dtype:
+                res = cast(res, dtype)
+            dxp = ops.gemm_nt(dqk, prep_linear(w[:2 * D], dtype, True), residual=res)
+            dsrc = ops.gemm_nt(dv, prep_linear(w[2 * D:], dtype, True), residual=dxp).view(src.shape)
+        dw = zeros_f32((3 * D, D), xp.device)
+        db = zeros_f32((3 * D,), xp.device)
+        ops.gemm_tn_acc(dqk, xp.view(rows, D), dw[:2 * D], colsum=db[:2 * D], zeroed=True)
+        ops.gemm_tn_acc(dv, src.view(rows, D), dw[2 * D:], colsum=db[2 * D:], zeroed=True)
+        return dsrc, None, dw, db, None
+
+
+def in_proj_self(src, pos, weight, bias):
+    """-> (src for the residual step, q, k, v) with q = k-input = src + pos (see InProjSelfFn); None if `pos` carries a
+    gradient or the fused form is switched off (the caller then takes the separate add + in_proj)."""
+    if pos.requires_grad or not _LINEAR_KEEP:
+        return None
+    row_mod = pos.shape[-2] if pos.dim() == 2 else 0
+    return InProjSelfFn.apply(src.contiguous(), pos.contiguous(), weight, bias, row_mod)
+
+
 class InProjCrossFn(Function):
     """The packed input projection with three different inputs (encoder cross-attention onto the previous output /
     a previous frame, reference transformer.py:464-478: q-input = x + pos, k-input = other + pos, v-input = other).
