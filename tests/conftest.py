@@ -24,3 +24,13 @@ def golden():
         return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
     return load
+
+
+@pytest.fixture(autouse=True)
+def _no_leaked_dropout_base():
+    """A captured train-mode step installs a device-side dropout seed base (ops.DROP_BASE) for the process; tests that
+    restate the dropout hash from a host seed must not inherit it from an earlier test."""
+    yield
+    mod = sys.modules.get("future_od.native.ops")
+    if mod is not None:
+        mod.DROP_BASE = None
