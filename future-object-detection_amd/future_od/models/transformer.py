@@ -38,10 +38,10 @@ def _lin(x, m: nn.Linear, relu=False, out_f32=False):
 class _Proj:
     """An output projection that has not been applied yet: `_add_norm` applies it together with the residual add and
     the post-norm as one autograd node (Fn.linear_add_norm), or on its own when dropout sits in between."""
-    __slots__ = ("a", "lin")
+    __slots__ = ("a", "lin", "a_relu")
 
-    def __init__(self, a, lin):
-        self.a, self.lin = a, lin
+    def __init__(self, a, lin, a_relu=False):
+        self.a, self.lin, self.a_relu = a, lin, a_relu      # a_relu: see Fn.LinearAddNormFn / _fused_tail
 
 
 def _add_norm(x, new, norm: nn.LayerNorm, p, training):
@@ -50,9 +50,16 @@ def _add_norm(x, new, norm: nn.LayerNorm, p, training):
     if isinstance(new, _Proj):
         vec_ok = new.lin.weight.shape[0] % 8 == 0
         if vec_ok and not (training and p > 0.0):
-            return Fn.linear_add_norm(new.a, x, new.lin.weight, new.lin.bias, norm.weight, norm.bias)
+            return Fn.linear_add_norm(new.a, x, new.lin.weight, new.lin.bias, norm.weight, norm.bias, new.a_relu)
+        assert not new.a_relu, "a ReLU that left its gradient mask to a fused tail needs that tail (see _fused_tail)"
         new = _lin(new.a, new.lin)
     return Fn.layer_norm(x, norm.weight, norm.bias, residual=Fn.dropout(new, p, training))
+
+
+def _fused_tail(lin: nn.Linear, p, training):
+    """Whether `_add_norm` will apply `lin` inside the fused projection + add + norm node (its own condition): only then
+    may the feed-forward's ReLU leave the masking of its gradient to that node."""
+    return lin.weight.shape[0] % 8 == 0 and not (training and p > 0.0)
 
 
 class MLP(nn.Module):
@@ -278,9 +285,10 @@ class TransformerDecoderLayer(nn.Module):
             x = Fn.layer_norm(x, self.norm_eda.weight, self.norm_eda.bias, residual=e, res_row_div=x.shape[1])
             if torch.is_grad_enabled():
                 x = Fn.ZeroGradAnchor.apply(x, *self.egodeep_attend.dead_parameters())
-        x, h = Fn.linear_keep(x, self.feedforward[0].weight, self.feedforward[0].bias, relu=True)
+        fuse = _fused_tail(self.feedforward[3], p, t)
+        x, h = Fn.linear_keep(x, self.feedforward[0].weight, self.feedforward[0].bias, relu=True, grad_masked=fuse)
         h = Fn.dropout(h, p, t)
-        return _add_norm(x, _Proj(h, self.feedforward[3]), self.norm_out, p, t)
+        return _add_norm(x, _Proj(h, self.feedforward[3], a_relu=fuse), self.norm_out, p, t)
 
 
 class TransformerDecoder(nn.Module):
@@ -381,9 +389,10 @@ class EncoderAttention(nn.Module):
         a = Fn.attention(q, k, v, 1.0 / math.sqrt(D // self.H), drop_p=self.droprate, training=self.training)
         t, p = self.training, self.droprate
         src = _add_norm(src, _Proj(a, self.attn.out_proj), self.norm1, p, t)
-        src, h = Fn.linear_keep(src, self.mlp[0].weight, self.mlp[0].bias, relu=True)
+        fuse = _fused_tail(self.mlp[3], p, t)
+        src, h = Fn.linear_keep(src, self.mlp[0].weight, self.mlp[0].bias, relu=True, grad_masked=fuse)
         h = Fn.dropout(h, p, t)
-        return _add_norm(src, _Proj(h, self.mlp[3]), self.norm2, p, t)
+        return _add_norm(src, _Proj(h, self.mlp[3], a_relu=fuse), self.norm2, p, t)
 
 
 class TransformerEncoderLayer(nn.Module):
