@@ -33,6 +33,11 @@ struct NtParams {
   int par_h, par_w, out_H, out_W;   // parity of the class, full input dims (rows of C / residual / mask)
   int r_first, s_first, n_s;        // first valid tap per axis, taps per row of the compact list
   int off_h, off_w;                 // source row = hi' + off_h - ri
+  // short-launch kernel: K split ACROSS blocks (gridDim.z = ksplit); partial 64 x 64 f32 tiles meet in split_ws, the
+  // block that draws the last ticket sums them in index order and runs the epilogue
+  int ksplit;
+  float* split_ws;
+  unsigned* split_tickets;
   // gather geometry
   int Hs, Ws, Cs;   // source image dims / channels
   int Hd, Wd;       // m-domain dims

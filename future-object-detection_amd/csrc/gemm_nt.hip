@@ -562,10 +562,14 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const NtParams p) {
     __builtin_memcpy(&rmsk[ps], &b, 8);
   }
 
-  // ---- this wave's share of K, in units of 32 elements (2 k-steps, 64 B per row)
+  // ---- this block's share of K (split across blocks: few tiles, deep K), then this wave's share of that, in units of
+  // 32 elements (2 k-steps, 64 B per row)
   const int units = (p.K + 31) >> 5;
-  const int per = (units + 3) >> 2;
-  const int ub = wave * per, ue = min(units, ub + per);
+  const int KS = p.ksplit > 1 ? p.ksplit : 1, kz = blockIdx.z;
+  const int ublk = (units + KS - 1) / KS;
+  const int u_lo = kz * ublk, u_hi = min(units, u_lo + ublk);
+  const int per = (max(u_hi - u_lo, 0) + 3) >> 2;
+  const int ub = u_lo + wave * per, ue = min(u_hi, ub + per);
   unsigned a_off[2], b_off[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -646,13 +650,44 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const NtParams p) {
     c_base = (long)cseg * p.c_seg_stride;
     n_c = n - cseg * p.c_seg_cols;
   }
+  f32x4 vsum[4];
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int row = rq + 16 * ps;
+    vsum[ps] = *reinterpret_cast<const f32x4*>(&sC[0][row][cq * 4]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) vsum[ps] += *reinterpret_cast<const f32x4*>(&sC[w][row][cq * 4]);
+  }
+  if (KS > 1) {
+    // ---- across blocks (sc1 hand-off, common.h): every thread publishes its 16 partial sums, every wave waits for its
+    // stores, one lane takes the ticket behind a workgroup barrier; the last block adds all KS partials in index order
+    __shared__ unsigned s_ticket;
+    const long tile = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    float* mine = p.split_ws + (tile * KS + kz) * 4096;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) store_sc1(mine + (rq + 16 * ps) * 64 + cq * 4 + e, vsum[ps][e]);
+    stores_done();
+    __syncthreads();
+    if (tid == 0) s_ticket = atomicAdd(p.split_tickets + tile, 1u);
+    __syncthreads();
+    if (s_ticket != (unsigned)(KS - 1)) return;
+    const float* all = p.split_ws + tile * KS * 4096;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) vsum[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < KS; ++z)
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vsum[ps][e] += load_sc1(all + z * 4096 + (rq + 16 * ps) * 64 + cq * 4 + e);
+    if (tid == 0) p.split_tickets[tile] = 0u;            // ready for the next launch (stream-ordered)
+  }
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
     const int row = rq + 16 * ps;
     const int m = m0 + row;
-    f32x4 v = *reinterpret_cast<const f32x4*>(&sC[0][row][cq * 4]);
-#pragma unroll
-    for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(&sC[w][row][cq * 4]);
+    f32x4 v = vsum[ps];
     if (has_scale) v = v * sc;
     v += sh;
 #pragma unroll
@@ -675,6 +710,31 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const NtParams p) {
     }
   }
   FOD_STAMP(4);
+}
+
+// Scratch of the split-K launches: 64 tiles x 8 splits x 64 x 64 floats (8 MiB) + 64 tickets per device, allocated and
+// zeroed at the first use outside a stream capture (a capture that comes first keeps the unsplit launch); one per
+// device: launches that use it must be ordered on one stream.
+bool small_split_scratch(hipStream_t stream, float** ws, unsigned** tickets) {
+  static float* g_ws[64] = {};
+  static unsigned* g_tk[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (!g_ws[dev]) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
+    void *a = nullptr, *b = nullptr;
+    if (hipMalloc(&a, (size_t)64 * 8 * 4096 * sizeof(float)) != hipSuccess || hipMalloc(&b, 64 * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(b, 0, 64 * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    g_ws[dev] = reinterpret_cast<float*>(a);
+    g_tk[dev] = reinterpret_cast<unsigned*>(b);
+  }
+  *ws = g_ws[dev];
+  *tickets = g_tk[dev];
+  return true;
 }
 
 // The short-launch kernel is used when its 64 x 64 tiles fit the chip in one wave of blocks.
@@ -796,7 +856,19 @@ extern "C" int fod_gemm_nt(int dtype, const void* A, long lda, int a_row_mod, co
   p.a_bytes = (unsigned)ab;
   p.b_bytes = (unsigned)bb;
   if (use_small_nt(dtype, p)) {
-    hipLaunchKernelGGL(gemm_nt_small_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, stream, p);
+    // deep K on few tiles (the decoder's feed-forward: 256 x 256 x 2048 = 16 blocks walking 64 units each, 18-24 us):
+    // split K across blocks so the launch covers more of the chip
+    const long tiles = (long)ceil_div(N, 64) * ceil_div(M, 64);
+    int ks = 1;
+    static const char* env_ks = getenv("FOD_NT_SPLITK");             // "0": never (experiments)
+    if (K >= 1024 && tiles <= 64 && !(env_ks && env_ks[0] == '0')) {
+      ks = (int)(256 / tiles);
+      if (ks > 8) ks = 8;
+      if (ks > K / 256) ks = K / 256;
+      if (ks > 1 && small_split_scratch(stream, &p.split_ws, &p.split_tickets)) p.ksplit = ks;
+      else ks = 1;
+    }
+    hipLaunchKernelGGL(gemm_nt_small_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64), ks), dim3(256), 0, stream, p);
     FOD_LAUNCH_CHECK();
     return FOD_OK;
   }

@@ -486,7 +486,7 @@ def test_gemm_tn_short_reduction(dtype, mnk, zeroed):
 
 
 @pytest.mark.parametrize("mnk", [(256, 256, 256), (256, 256, 2048), (100, 72, 40), (2900, 256, 256), (64, 2048, 256),
-                                 (65, 68, 72)])
+                                 (65, 68, 72), (130, 200, 4096), (256, 64, 1024), (37, 40, 2056)])
 def test_gemm_nt_short_launch(mnk):
     """bf16 problems of <= 256 64x64 tiles take the short-launch kernel (4-way in-block split of K)."""
     M, N, K = mnk

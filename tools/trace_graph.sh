@@ -1,7 +1,7 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-out=$R/gpurun_out/r02m_trace
+out=$R/gpurun_out/${1:-r02x_trace}
 rm -rf $out && mkdir -p $out
 rocprofv3 --kernel-trace --output-format csv -d $out/kt -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > $out/log.txt 2>&1
 cp $(ls $out/kt/*/*kernel_trace.csv | head -1) $out/kernel_trace.csv
