@@ -36,6 +36,23 @@ from future_od.native import functional as Fn
 from future_od.native import ops
 
 
+def _stage_inputs(g, data):
+    """Copy the batch into the graph's input buffers -- except entries that are the very tensors staged last time and
+    have not been written since (same object, same version counter): a resident, unchanged batch costs nothing."""
+    seen = g.setdefault("staged", {})
+    for k, v in g["static"].items():
+        if isinstance(v, torch.Tensor) and k in data:
+            src = data[k]
+            if src.data_ptr() == v.data_ptr():
+                continue
+            tag = (id(src), src._version)
+            if seen.get(k) == tag:
+                continue
+            v.copy_(src, non_blocking=True)
+            seen[k] = tag
+            g.setdefault("keep", {})[k] = src        # the id stays unique while the tensor is alive
+
+
 class GraphedStep:
     """step = GraphedStep(model, optimizer);  post, loss, stats, od = step(data)
 
@@ -269,11 +286,7 @@ class GraphedStep:
         g = self._graphs.get(sig)
         if g is None:
             g = self._graphs[sig] = self._capture(data)
-        for k, v in g["static"].items():
-            if isinstance(v, torch.Tensor) and k in data:
-                src = data[k]
-                if src.data_ptr() != v.data_ptr():
-                    v.copy_(src, non_blocking=True)
+        _stage_inputs(g, data)
         self.opt.sync_hyperparams()
         if self.ddp:
             self._global_num_boxes(g["static"], g["static"]["_num_boxes"])
@@ -350,11 +363,7 @@ class GraphedForward:
                 outs = self._run(static)
             torch.cuda.synchronize(dev)
             g = self._graphs[sig] = {"graph": graph, "static": static, "outs": outs}
-        for k, v in g["static"].items():
-            if isinstance(v, torch.Tensor) and k in data:
-                src = data[k]
-                if src.data_ptr() != v.data_ptr():
-                    v.copy_(src, non_blocking=True)
+        _stage_inputs(g, data)
         Fn.PREP.refresh()                             # one launch if an optimizer step happened since, nothing otherwise
         g["graph"].replay()
         self.replays += 1

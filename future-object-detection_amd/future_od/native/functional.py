@@ -1086,13 +1086,20 @@ class GroupLinearFn(Function):
         _, _, wcat_t = CAT.get(weights, biases, x.dtype)
         rows = x.numel() // K
         g = _as_segments(gs, rows, D)
-        if g is None:                                # gather the P gradients into the segment layout
+        if g is None:                                # gather the P gradients into the segment layout: ONE launch
             g = torch.empty((P, rows, D), dtype=x.dtype, device=x.device)
+            dsts, srcs = [], []
             for p_, gp in enumerate(gs):
                 if gp is None:
                     g[p_].zero_()
                 else:
-                    g[p_].copy_(gp.reshape(rows, D))
+                    dsts.append(g[p_])
+                    srcs.append(gp.reshape(rows, D))
+            if all(t.dtype == x.dtype and t.is_contiguous() for t in srcs):
+                torch._foreach_copy_(dsts, srcs)     # (17 separate copies of 64 KB were 17 graph nodes of ~5 us each)
+            else:
+                for d_, s_ in zip(dsts, srcs):
+                    d_.copy_(s_)
         dx = ops.group_linear_dgrad(g, wcat_t, P).view(x.shape) if ctx.needs_input_grad[0] else None
         dw = zeros_f32((P * D, K), x.device)
         db = zeros_f32((P * D,), x.device)
