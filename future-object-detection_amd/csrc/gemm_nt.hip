@@ -971,7 +971,11 @@ static int conv_common(int dtype, bool dgrad, const void* src, const void* w, vo
     q.off_h = (q.par_h + g->pad - q.r_first) / 2;
     q.off_w = (q.par_w + g->pad - q.s_first) / 2;
     q.M = g->Nimg * q.Hd * q.Wd;
-    q.K = n_r * q.n_s * g->Cout;          // may be 0 (1x1 stride 2, odd classes): the epilogue still runs
+    q.K = n_r * q.n_s * g->Cout;          // may be 0 (1x1 stride 2, odd classes): the epilogue still runs ...
+    // ... unless the call accumulates in place (residual == dx, "dx += dgrad(dy)", no affine part): a class without
+    // taps then leaves its pixels as they are -- three of the four launches of a 1x1 stride-2 convolution
+    if (q.K == 0 && p.res == p.C && p.res != nullptr && !p.scale && !p.shift && !p.relu && p.ldr == p.ldc)
+      continue;
     if (q.n_s == 0) q.n_s = 1;
     const int rc = dispatch_nt<MODE_DGRAD_S2>(dtype, q, stream);
     if (rc) return rc;

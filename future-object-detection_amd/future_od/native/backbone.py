@@ -260,15 +260,24 @@ class BackboneFn(Function):
             if ds is not None:
                 wgrad(g_out, acts[0], ds[0], ds_geom, ds[1].scale_shift()[0])
             if need_dx:
-                if ds is not None:
-                    sc = ds[1].scale_shift()[0]
-                    d_idt = ops.conv2d_dgrad(g_out, Fn.prep_conv(ds[0].weight, dtype, sc, True), ds_geom)
-                else:
-                    d_idt = g_out
                 cw, bn = main[0]
                 sc = bn.scale_shift()[0]
-                g = ops.conv2d_dgrad(gcur, Fn.prep_conv(cw.weight, dtype, sc, True), geoms[0],
-                                     residual=d_idt, relu_mask=acts[0])
+                w1t = Fn.prep_conv(cw.weight, dtype, sc, True)
+                if ds is not None and ds[0].k == 1 and ds[0].stride == 2 and cw.stride == 1 and cw.k == 1:
+                    # the shortcut is a 1x1 stride-2 convolution: its input gradient lives on the even pixels only.
+                    # Main path first (no residual), then the shortcut's ONE parity class accumulated in place -- the
+                    # full-resolution, three-quarters-zero gradient tensor is neither written nor read
+                    g = ops.conv2d_dgrad(gcur, w1t, geoms[0], relu_mask=acts[0])
+                    scd = ds[1].scale_shift()[0]
+                    ops.conv2d_dgrad(g_out, Fn.prep_conv(ds[0].weight, dtype, scd, True), ds_geom, residual=g,
+                                     relu_mask=acts[0], out=g)
+                else:
+                    if ds is not None:
+                        scd = ds[1].scale_shift()[0]
+                        d_idt = ops.conv2d_dgrad(g_out, Fn.prep_conv(ds[0].weight, dtype, scd, True), ds_geom)
+                    else:
+                        d_idt = g_out
+                    g = ops.conv2d_dgrad(gcur, w1t, geoms[0], residual=d_idt, relu_mask=acts[0])
             if sync is not None:
                 sync.maybe_flush(Fn.ARENA)        # this block's weight gradients are final (weights are used once)
         ctx.tape = None

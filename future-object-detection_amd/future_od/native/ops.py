@@ -248,12 +248,17 @@ def conv_stem_fwd(xp, w, h, wd, *, shift=None, relu=True):
     return y
 
 
-def conv2d_dgrad(dy, w_t, geom, *, residual=None, relu_mask=None):
-    """dy NHWC [N,Ho,Wo,Cout], w_t [Cin, kh, kw, Cout] -> dx NHWC [N,H,W,Cin] (+residual, *mask>0)."""
+def conv2d_dgrad(dy, w_t, geom, *, residual=None, relu_mask=None, out=None):
+    """dy NHWC [N,Ho,Wo,Cout], w_t [Cin, kh, kw, Cout] -> dx NHWC [N,H,W,Cin] (+residual, *mask>0).
+    `out is residual`: accumulate in place (dx = mask(dx + dgrad(dy))); pixels that no tap reaches (three of the four
+    parity classes of a 1x1 stride-2 convolution) are then not touched at all -- the caller's mask must already hold on
+    them (it does where dx came out of a masked input-gradient pass)."""
     _chk(dy, "dy"); _chk(w_t, "w_t", dy.dtype)
     assert tuple(dy.shape) == (geom.Nimg, geom.Ho, geom.Wo, geom.Cout), (dy.shape,)
     assert w_t.numel() == geom.Cout * geom.kh * geom.kw * geom.Cin
-    dx = torch.empty((geom.Nimg, geom.H, geom.W, geom.Cin), dtype=dy.dtype, device=dy.device)
+    if out is not None:
+        _chk(out, "out", dy.dtype); assert tuple(out.shape) == (geom.Nimg, geom.H, geom.W, geom.Cin)
+    dx = out if out is not None else torch.empty((geom.Nimg, geom.H, geom.W, geom.Cin), dtype=dy.dtype, device=dy.device)
     for v in (residual, relu_mask):
         if v is not None:
             _chk(v, "residual/mask", dy.dtype); assert v.shape == dx.shape

@@ -139,6 +139,17 @@ def test_conv2d_fwd_dgrad_wgrad(dtype, case):
         dx = ops.conv2d_dgrad(dy.to(DEV), w_t.to(DEV), geom, residual=dres.to(DEV), relu_mask=mask.to(DEV))
         dx_ref = torch.where(mask.float() > 0, x32.grad + dres.float(), torch.zeros(()))
         check(dx, dx_ref, dtype, 4, f"conv dgrad {case}")
+        if stride == 2 and k == 1:
+            # in place ("dx = mask(dx + dgrad(dy))", what the backbone's shortcut does): the odd pixels, which no tap
+            # reaches, must come back untouched; the caller's buffer already satisfies the mask there
+            pre = torch.where(mask.float() > 0, dres.float(), torch.zeros(())).to(dtype)
+            buf = pre.clone().to(DEV)
+            got = ops.conv2d_dgrad(dy.to(DEV), w_t.to(DEV), geom, residual=buf, relu_mask=mask.to(DEV), out=buf)
+            assert got.data_ptr() == buf.data_ptr()
+            ref_ip = torch.where(mask.float() > 0, x32.grad + pre.float(), torch.zeros(()))
+            check(buf, ref_ip, dtype, 4, f"conv dgrad in place {case}")
+            odd = buf.cpu()[:, 1::2]
+            assert torch.equal(odd, pre[:, 1::2]), "pixels without taps were rewritten"
     dw = torch.zeros((cout, k, k, cin), device=DEV)
     rs = torch.rand(cout) + 0.5
     ops.conv2d_wgrad_acc(dy.to(DEV), x.to(DEV), dw, geom, row_scale=rs.to(DEV))
