@@ -339,11 +339,14 @@ class TransformerDecoder(nn.Module):
             x = layer(x, qpos, q_sine, side, lid, is_first=special, pos_proj=pos_proj, slotstates=slotstates,
                       egodeep=egodeep)
             if self.return_intermediate:
-                inter.append(Fn.layer_norm(x, self.norm.weight, self.norm.bias))
+                inter.append(x)
         if not self.return_intermediate:
             y = Fn.layer_norm(x, self.norm.weight, self.norm.bias) if self.norm is not None else x
             return y.unsqueeze(0), ref
-        return torch.stack(inter), ref
+        # the shared output norm over all levels at once (rows are independent: the same numbers as level by level):
+        # one launch forward and one backward instead of six each, and one gradient for its weight / bias instead of six
+        # that autograd would sum with ten kernels of its own
+        return Fn.layer_norm(torch.stack(inter), self.norm.weight, self.norm.bias), ref
 
 
 class PackedMHA(nn.Module):
