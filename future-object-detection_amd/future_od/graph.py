@@ -152,7 +152,11 @@ class GraphedStep:
         group = self.group
         if average and self._native_avg():
             return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
-        # gloo (rehearsal on one GPU): sum, then scale (an asynchronous call leaves the scaling to its caller)
+        # gloo (rehearsal on one GPU): sum, then scale (an asynchronous call leaves the scaling to its caller).  The
+        # stream is drained first: a gloo collective issued behind a queued graph replay took seconds instead of 60 ms
+        # (per-phase timings with FOD_GRAPH_TIMING=1); RCCL orders itself on the stream and needs no such wait
+        if t.is_cuda and not async_op:
+            torch.cuda.current_stream(t.device).synchronize()
         work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         if average and not async_op:
             t.div_(self.world)
@@ -255,7 +259,8 @@ class GraphedStep:
         cut = Fn.BackboneCut() if self.overlap else None
         Fn.BACKBONE_CUT = cut
         try:
-            with torch.cuda.graph(graph_a):
+            # thread-local capture mode: the process group's watchdog thread polls its events while this thread captures
+            with torch.cuda.graph(graph_a, capture_error_mode="thread_local"):
                 outs = self._forward_backward(static)
         finally:
             Fn.BACKBONE_CUT = None
@@ -264,11 +269,11 @@ class GraphedStep:
         if cut is not None and cut.pairs:
             off1 = Fn.ARENA.off if Fn.ARENA.active else 0
             graph_a2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph_a2, pool=graph_a.pool()):
+            with torch.cuda.graph(graph_a2, pool=graph_a.pool(), capture_error_mode="thread_local"):
                 cut.finish()
             second = self._reduce_targets(arena_from=off1, skip={t.data_ptr() for t in first})
         graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph_b, pool=graph_a.pool()):
+        with torch.cuda.graph(graph_b, pool=graph_a.pool(), capture_error_mode="thread_local"):
             self.opt.step()
         torch.cuda.synchronize(dev)
         self.opt._step_no -= 1
@@ -288,9 +293,20 @@ class GraphedStep:
             g = self._graphs[sig] = self._capture(data)
         _stage_inputs(g, data)
         self.opt.sync_hyperparams()
+        import os, time
+        dbg = os.environ.get("FOD_GRAPH_TIMING") == "1"
+        def tick(label, _t=[time.perf_counter()]):
+            if dbg:
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                print(f"[graph timing] {label}: {(now - _t[0]) * 1e3:.1f} ms", flush=True)
+                _t[0] = now
+        tick("staged")
         if self.ddp:
             self._global_num_boxes(g["static"], g["static"]["_num_boxes"])
+        tick("num_boxes")
         g["graph"].replay()
+        tick("graph A")
         if self.ddp:
             pending = []
             if sync:
@@ -300,6 +316,7 @@ class GraphedStep:
                 else:
                     for t in g["targets"]:
                         self._all_reduce(t)
+                        tick(f"all_reduce {t.numel()} elements")
             if g["graph_bb"] is not None:
                 g["graph_bb"].replay()
                 if sync:
