@@ -69,7 +69,11 @@ class GraphedStep:
         self.core = model
         self.group = process_group
         self.ddp = bool(data_parallel or process_group is not None)
-        self.world = dist.get_world_size(process_group) if self.ddp else 1
+        if getattr(model, "light", False) and hasattr(model, "module"):
+            # FodDataParallel built without torch's reducer (parallel.py): nothing of it lives on the default stream, so
+            # the wrapped model can be captured; its own reducer is simply not armed (the model is called directly)
+            self.core, self.group, self.ddp = model.module, model.process_group, True
+        self.world = dist.get_world_size(self.group) if self.ddp else 1
         self._graphs = {}
         self.replays = 0
         self.comm_stats = {"tensors": 0, "bytes": 0}           # what one step all-reduces (data parallel)
@@ -98,7 +102,8 @@ class GraphedStep:
         return tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in data.items() if isinstance(v, torch.Tensor)))
 
     def _check(self, data):
-        if isinstance(self.model, torch.nn.parallel.DistributedDataParallel) or Fn.GRAD_SYNC is not None:
+        if (isinstance(self.core, torch.nn.parallel.DistributedDataParallel)
+                or (isinstance(self.model, torch.nn.parallel.DistributedDataParallel) and self.core is self.model)):
             raise RuntimeError("GraphedStep: pass the bare model (data_parallel=True / process_group=...), not a "
                                "DistributedDataParallel wrapper: its stashed AccumulateGrad nodes live on the default "
                                "stream and its reducer's collectives are not captured")
@@ -122,10 +127,10 @@ class GraphedStep:
 
     # ---- the pieces that are captured ------------------------------------------------------------------------------
     def _dropout_active(self):
-        if not self.model.training:
+        if not self.core.training:
             return False
-        drops = [m.p for m in self.model.modules() if isinstance(m, torch.nn.Dropout)]
-        rates = [float(getattr(m, "droprate", 0.0) or 0.0) for m in self.model.modules()]
+        drops = [m.p for m in self.core.modules() if isinstance(m, torch.nn.Dropout)]
+        rates = [float(getattr(m, "droprate", 0.0) or 0.0) for m in self.core.modules()]
         return any(p > 0 for p in drops + rates)
 
     def _forward_backward(self, data):
@@ -134,6 +139,7 @@ class GraphedStep:
             # replay draws new masks (forward and backward of one step read the same value)
             ops.DROP_BASE.add_(1)
         self.opt.zero_grad()
+        Fn.set_grad_sync(None)          # an eager pass through a FodDataParallel wrapper may have left its reducer installed
         post, _state, loss, stats, od = self.core(data=data, distributed=False)
         loss.backward()
         return post, loss, stats, od

@@ -235,11 +235,50 @@ class _NoSync:
 
 
 class FodDataParallel(DistributedDataParallel):
-    def __init__(self, module, device=None, bucket_cap_mb=48, find_unused_parameters=False):
-        super().__init__(module, broadcast_buffers=False, bucket_cap_mb=bucket_cap_mb, find_unused_parameters=False)
+    def __init__(self, module, device=None, bucket_cap_mb=48, find_unused_parameters=False, process_group=None):
+        """A DistributedDataParallel by type (the reference's `isinstance` checks and `.module` accesses), WITHOUT torch's
+        reducer: DistributedDataParallel.__init__ builds it, and with it stashes every parameter's AccumulateGrad node
+        on the default stream -- unused weight here (this class averages the gradients itself), and the one thing that
+        keeps a backward pass from being captured into a hipGraph on another stream (future_od/graph.py).  What the
+        constructor is needed for is done directly: rank 0's parameters and buffers are broadcast, shapes verified.
+        FOD_DDP_TORCH_INIT=1 runs torch's constructor instead (then captured steps need the bare model)."""
+        import os
+        self.light = os.environ.get("FOD_DDP_TORCH_INIT", "0") != "1"
+        if self.light:
+            torch.nn.Module.__init__(self)
+            self.module = module
+            self.process_group = process_group if process_group is not None else dist.group.WORLD
+            self.device_ids = None
+            self.output_device = None
+            self.broadcast_buffers = False
+            self.find_unused_parameters = False
+            self.static_graph = False
+            self._verify_and_broadcast()
+        else:
+            super().__init__(module, broadcast_buffers=False, bucket_cap_mb=bucket_cap_mb, find_unused_parameters=False,
+                             process_group=process_group)
         self.require_backward_grad_sync = False          # torch's reducer stays idle (as under no_sync())
         self.grad_reducer = GradientReducer(self.module.parameters(), self.process_group, bucket_cap_mb)
         self._sync_enabled = True
+
+    def _verify_and_broadcast(self):
+        """Every rank must hold the same parameter shapes (a mismatch would deadlock or corrupt the first collective);
+        then rank 0's parameters and buffers go to everyone, as DistributedDataParallel's constructor does."""
+        tensors = [p.data for p in self.module.parameters()] + [b.data for b in self.module.buffers()]
+        sig = torch.tensor([len(tensors), sum(t.numel() for t in tensors)], dtype=torch.int64)
+        dev = tensors[0].device if tensors else torch.device("cpu")
+        backend = dist.get_backend(self.process_group)
+        sig = sig.to(dev) if (backend == "nccl" or dev.type == "cuda") else sig
+        lo, hi = sig.clone(), sig.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.process_group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.process_group)
+        if not torch.equal(lo, hi):
+            raise RuntimeError(f"FodDataParallel: ranks hold different models (tensors / elements: this rank "
+                               f"{sig.tolist()}, min {lo.tolist()}, max {hi.tolist()})")
+        src = dist.get_global_rank(self.process_group, 0) if self.process_group is not dist.group.WORLD else 0
+        with torch.no_grad():
+            for t in tensors:
+                dist.broadcast(t, src=src, group=self.process_group)
 
     def no_sync(self):
         """Gradient accumulation without communication, as DistributedDataParallel.no_sync()."""

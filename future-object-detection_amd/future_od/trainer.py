@@ -117,7 +117,10 @@ class Trainer:
             import os
             from future_od.models.set_criterion import device_matching_enabled
             dev = torch.device(self._device)
-            ok = (os.environ.get("FOD_GRAPH_TRAIN", "1") != "0" and not self._distributed and dev.type == "cuda"
+            # data parallel: with the FodDataParallel wrapper built without torch's reducer (its default) the step is two
+            # graphs around an eagerly launched gradient all-reduce (graph.py); any other wrapper keeps the eager loop
+            dp_ok = not self._distributed or getattr(self._model, "light", False)
+            ok = (os.environ.get("FOD_GRAPH_TRAIN", "1") != "0" and dp_ok and dev.type == "cuda"
                   and hasattr(self._optimizer, "enable_device_step")
                   and (self._optimizer_clips or not self._max_norm) and device_matching_enabled(dev))
             if not ok:

@@ -222,3 +222,90 @@ def test_two_ranks_captured_step_matches_eager_data_parallel(overlap, monkeypatc
         assert comm["tensors"] >= 1 and comm["bytes"] > 1 << 20, comm
         assert all(l == l and abs(l) < 1e6 for l in losses), losses
     assert res[0][4] == res[1][4]                              # same all-reduce layout on both ranks
+
+
+class _ListLoader:
+    def __init__(self, batches):
+        self.batches, self.batch_size = batches, 1
+
+    def __iter__(self):
+        return iter(self.batches)
+
+    def __len__(self):
+        return len(self.batches)
+
+
+def _trainer_worker(rank, world, port, q, tmp):
+    """The reference's Trainer in distributed mode on two ranks: model wrapped by build_model (FodDataParallel), train
+    mode with dropout, the training epochs replayed as the data-parallel captured step."""
+    import faulthandler
+    faulthandler.dump_traceback_later(200, exit=True)
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "future-object-detection_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from types import SimpleNamespace
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from future_od.datasets.synthetic import make_batch
+        from future_od.models.st_detr import SpatioTemporalDETRArgs
+        from future_od.parallel import FodDataParallel
+        from future_od.trainer import Trainer
+        from runs._helper import get_lr_func, setup_optimizer
+        from runs._model import build_model
+        dev = torch.device("cuda", 0)
+        torch.manual_seed(5 + rank)                  # different initial weights per rank: the wrapper must broadcast rank 0's
+        args = SimpleNamespace(device=dev, distributed=True, compute_dtype="bf16", backbone="resnet18")
+        detr = SpatioTemporalDETRArgs(num_classes=8, num_queries=32, lr_backbone=1e-4, enc_layers=1, dec_layers=2,
+                                      pretrained_backbone=False)
+        model = build_model(args, detr)
+        assert isinstance(model, FodDataParallel) and isinstance(model, torch.nn.parallel.DistributedDataParallel)
+        assert model.light and not hasattr(model, "reducer")
+        sched, opt = setup_optimizer(detr, model, get_lr_func(4))
+        batches = [make_batch(2, 3, 96, 128, seed=40 + 7 * i + rank, max_boxes=5) for i in range(3)]
+        tr = Trainer(model, opt, sched, _ListLoader(batches), {"val": _ListLoader(batches[:1])}, tmp, tmp, f"t{rank}", dev,
+                     print_interval=2, visualization_epochs=[], visualization_iterations=[], category_dict={},
+                     checkpoint_epochs=False, distributed=True, is_master=rank == 0, max_norm=detr.max_norm)
+        tr.train(2)
+        torch.cuda.synchronize()
+        g = tr._graphed
+        spread = 0.0
+        for p in model.module.parameters():
+            lo, hi = p.detach().clone(), p.detach().clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            spread = max(spread, float((hi - lo).abs().max()))
+        hist = tr._stats["train labels loss"].history
+        q.put((rank, g not in (None, False), getattr(g, "replays", -1), getattr(g, "ddp", None), spread,
+               [float(h) for h in hist], opt._step_no))
+    except BaseException:
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+        os._exit(1)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_trainer_replays_the_data_parallel_captured_step(tmp_path):
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    for _ in range(world):
+        r = q.get(timeout=280)
+        if r[1] == "error":
+            for p in procs:
+                p.kill()
+            raise AssertionError(f"rank {r[0]} failed:\n{r[2]}")
+        res.append(r)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, graphed, replays, ddp, spread, hist, steps in sorted(res):
+        assert graphed and ddp is True and replays == 6 and steps == 6, (rank, graphed, replays, ddp, steps)
+        assert spread == 0.0, (rank, spread)          # rank 0's weights were broadcast and every update was the same
+        assert len(hist) == 2 and all(h == h for h in hist), hist
