@@ -386,10 +386,15 @@ def _attn_split_workspace(device, tiles):
     hit = _ATTN_SPLIT.get(key)
     if hit is None or hit[2] < tiles:
         cap = max(tiles, 256)
+        if hit is not None:
+            _ATTN_SPLIT_RETIRED.append(hit)      # a captured graph may still hold its addresses: never freed
         hit = (torch.empty(cap * _ATTN_SPLIT_FLOATS_PER_TILE, dtype=torch.float32, device=device),
                torch.zeros(cap, dtype=torch.int32, device=device), cap)
         _ATTN_SPLIT[key] = hit
     return hit[0], hit[1]
+
+
+_ATTN_SPLIT_RETIRED = []
 
 
 def _same_bt(a, b, name):

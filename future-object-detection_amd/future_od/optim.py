@@ -196,6 +196,8 @@ class FusedAdamW(torch.optim.Optimizer):
             # fixed summation order: data-parallel replicas with equal gradients get bit-equal clip factors
             scr = getattr(self, "_sq_scratch", None)
             if scr is None or scr.device != dev or scr.numel() < nblocks + 1:
+                if scr is not None:
+                    self._retired = getattr(self, "_retired", []) + [scr]     # a captured step may still hold its address
                 scr = self._sq_scratch = torch.zeros(nblocks + 1, dtype=torch.float32, device=dev)
             L.call("fod_multi_sqnorm_det", ptr(ptrs), ptr(numel), ptr(bt), ptr(bc), nblocks, ptr(self._sq), ptr(scr), stream())
             sq = self._sq
