@@ -136,11 +136,14 @@ class _ZeroArena:
         self.active = False
         self.extra = []
         self.cap = 0
+        self.retired = []
 
     def recycle(self, device):
         device = torch.device(device)
         need = max(self.high, 1 << 20)
         if self.buf is None or self.buf.device != device or self.buf.numel() < need:
+            if self.buf is not None:
+                self.retired.append(self.buf)      # a captured step may have baked slices of it in: never freed
             self.buf = torch.zeros(int(need * 1.25), dtype=torch.float32, device=device)
         elif self.off:
             self.buf[:self.off].zero_()

@@ -143,7 +143,10 @@ class FusedAdamW(torch.optim.Optimizer):
                     plan["ring"][turn] = spares.pop()
                     plan.setdefault("captured_slots", []).append(host)
                 else:
-                    self._plan = None      # out of spare slots: the next eager step rebuilds the plan (and its ring)
+                    # out of spare slots: the next eager step rebuilds the plan (and its ring); this one's tables are
+                    # baked into the capture in progress and stay alive
+                    self._retired_plans = (getattr(self, "_retired_plans", []) + [plan])[-8:]
+                    self._plan = None
             else:
                 ev = torch.cuda.Event()
                 ev.record()
@@ -228,6 +231,10 @@ class FusedAdamW(torch.optim.Optimizer):
             if ok:
                 self._launch(plan["tab"], plan["dev"], betas, eps)
                 return None
+        old_plan = getattr(self, "_plan", None)
+        if old_plan is not None:
+            # its device tables may be baked into a captured step (future_od/graph.py): kept alive, never freed
+            self._retired_plans = (getattr(self, "_retired_plans", []) + [old_plan])[-8:]
         plan = self._build_plan()
         self._plan = plan
         if plan is not None:
@@ -268,4 +275,6 @@ class FusedAdamW(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         steps = [float(st["step"]) for st in self.state.values() if "step" in st]
         self._step_no = int(max(steps)) if steps else 0
+        if getattr(self, "_plan", None) is not None:
+            self._retired_plans = (getattr(self, "_retired_plans", []) + [self._plan])[-8:]
         self._plan = None
