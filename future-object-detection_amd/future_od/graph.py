@@ -293,6 +293,11 @@ class GraphedStep:
     def __call__(self, data, sync=True):
         """One optimizer step on `data`.  `sync=False` (data parallel only) skips the gradient average -- the ranks'
         parameters then DIVERGE; it exists to time the step without communication."""
+        token = getattr(self.opt, "_state_token", 0)
+        if token != getattr(self, "_opt_token", token):
+            self._retired_graphs = getattr(self, "_retired_graphs", []) + [self._graphs]
+            self._graphs = {}                      # optimizer.load_state_dict() replaced the moment tensors: capture anew
+        self._opt_token = token
         sig = self._signature(data)
         g = self._graphs.get(sig)
         if g is None:

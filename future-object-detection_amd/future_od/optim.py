@@ -275,6 +275,9 @@ class FusedAdamW(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         steps = [float(st["step"]) for st in self.state.values() if "step" in st]
         self._step_no = int(max(steps)) if steps else 0
+        self._state_token = getattr(self, "_state_token", 0) + 1      # the moment tensors are new objects: captured steps
+        if getattr(self, "_dev_step", None) is not None:              # that baked the old ones in must be re-captured
+            self._dev_step.fill_(float(self._step_no))
         if getattr(self, "_plan", None) is not None:
             self._retired_plans = (getattr(self, "_retired_plans", []) + [self._plan])[-8:]
         self._plan = None

@@ -199,3 +199,24 @@ def test_captured_evaluation_pass_tracks_parameter_updates():
         _eager_step(model, opt, data)          # parameters move (fused AdamW writes them through raw pointers)
         _eager_step(model, opt, data)
     assert fwd.replays == 2 and len(fwd._graphs) == 1
+
+
+def test_optimizer_state_reload_forces_a_new_capture():
+    """optimizer.load_state_dict() replaces the moment tensors with new objects; a captured step that baked the old
+    addresses in must not be replayed: the next call captures anew (device step count re-synchronised) and keeps
+    tracking the eagerly stepped twin."""
+    from future_od.datasets.synthetic import make_batch
+    from future_od.graph import GraphedStep
+    data = make_batch(2, 3, 96, 128, seed=41, max_boxes=9, device=DEV)
+    m_e, o_e = _build("fp32")
+    m_g, o_g = _build("fp32")
+    step = GraphedStep(m_g, o_g, warmup=2)
+    le = [float(_eager_step(m_e, o_e, data)) for _ in range(9)]
+    l4 = float(step(data)[1].detach())                       # 3 eager warm-up steps + 1 replay = optimizer steps 1..4
+    assert o_g._step_no == 4 and step.replays == 1
+    o_g.load_state_dict(o_g.state_dict())                    # same numbers, NEW tensors
+    l7 = float(step(data)[1].detach())                       # captured anew: 2 eager warm-up steps + 1 replay = steps 5..7
+    l8 = float(step(data)[1].detach())
+    assert o_g._step_no == 8 and step.replays == 3 and len(step._graphs) == 1
+    for got, want in ((l4, le[3]), (l7, le[6]), (l8, le[7])):
+        assert abs(got - want) <= 2e-5 * max(abs(want), 1.0), (got, want)
