@@ -864,7 +864,7 @@ extern "C" int fod_gemm_nt(int dtype, const void* A, long lda, int a_row_mod, co
     if (K >= 1024 && tiles <= 64 && !(env_ks && env_ks[0] == '0')) {
       // at most 4 splits (FOD_NT_SPLITK=n: n): the merge reads every partial tile with scalar sc1 loads, ~1.2 us each;
       // measured whole step 21.95 / 22.09 ms at 4, 22.09 / 22.18 at 8, 22.12 / 22.02 at 2 (same box, alternating)
-      const int cap = (env_ks && atoi(env_ks) > 1) ? atoi(env_ks) : 4;
+      const int cap = (env_ks && atoi(env_ks) > 1) ? (atoi(env_ks) < 8 ? atoi(env_ks) : 8) : 4;   // scratch holds 8
       ks = (int)(256 / tiles);
       if (ks > cap) ks = cap;
       if (ks > K / 256) ks = K / 256;
