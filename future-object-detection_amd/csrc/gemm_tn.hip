@@ -404,14 +404,13 @@ __global__ void colsum_kernel(const T* __restrict__ G, long ldg, int M, int N, i
 // staged rows four ways and read their fragments with the transposing LDS read, and the four partial tiles
 // meet in LDS once.  LDS rows are 128 B unpadded; 64-B half `hc` of row r is stored at half hc ^ ((r>>1)&1),
 // which puts the 4 rows x 64 B of a transposed read on 64 distinct banks.
-__global__ __launch_bounds__(256) void gemm_tn_small_kernel(const TnParams p) {
+FOD_DEVINL void tn_small_body(const TnParams& p, const int bx, const int by, unsigned char* smem) {
   typedef __bf16 T;
   constexpr int ROWS = 256;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[65536];
   unsigned char* sG = smem;                  // ROWS x 128 B
   unsigned char* sX = smem + ROWS * 128;     // ROWS x 128 B
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+  const int j0 = bx * 64, i0 = by * 64;
   FOD_STAMP(0);
   constexpr unsigned OOB = 0xFFFFFFF0u;
   const auto rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.G), 0, p.g_bytes, 0x00020000);
@@ -437,7 +436,7 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const TnParams p) {
     const int seg = i0 / p.g_seg_cols;
     g_col = (long)seg * p.g_seg_stride + (gi - seg * p.g_seg_cols);
   }
-  const bool do_colsum = p.colsum != nullptr && blockIdx.x == 0;
+  const bool do_colsum = p.colsum != nullptr && bx == 0;
   float csum[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) csum[e] = 0.f;
@@ -548,6 +547,36 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const TnParams p) {
   FOD_STAMP(5);
 }
 
+__global__ __launch_bounds__(256) void gemm_tn_small_kernel(const TnParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[65536];
+  tn_small_body(p, blockIdx.x, blockIdx.y, smem);
+}
+
+// MANY short weight gradients in ONE launch (fod_gemm_tn_multi): block b works on tile blk_tile[b] of job blk_job[b].
+// The decoder's query side produces ~130 of these per step, each a 5 us graph node of its own although none of them is
+// on the backward pass's critical path -- queued during the backward pass and launched together at its end
+// (native/functional.py: WGRAD_QUEUE), they cost one node.
+__global__ __launch_bounds__(256) void gemm_tn_multi_kernel(const fod_tn_job* __restrict__ jobs,
+                                                            const int* __restrict__ blk_job,
+                                                            const int* __restrict__ blk_tile) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[65536];
+  const fod_tn_job& j = jobs[blk_job[blockIdx.x]];
+  TnParams p{};
+  p.G = j.G; p.X = j.X; p.dW = j.dW;
+  p.ldg = j.ldg; p.ldx = j.ldx; p.ldw = j.ldw;
+  p.M = j.M; p.N1 = j.N1; p.K2 = j.K2;
+  p.colsum = j.colsum;
+  p.accumulate = j.accumulate;
+  p.g_seg_cols = j.g_seg_cols; p.g_seg_stride = j.g_seg_stride;
+  const long nseg = j.g_seg_cols > 0 ? (j.N1 + j.g_seg_cols - 1) / j.g_seg_cols : 1;
+  const long seg_c = j.g_seg_cols > 0 ? j.g_seg_cols : j.N1;
+  p.g_bytes = (unsigned)(((nseg - 1) * j.g_seg_stride + (long)(j.M - 1) * j.ldg + seg_c) * 2);
+  p.x_bytes = (unsigned)(((long)(j.M - 1) * j.ldx + j.K2) * 2);
+  const int tj = (j.K2 + 63) >> 6;
+  const int tile = blk_tile[blockIdx.x];
+  tn_small_body(p, tile % tj, tile / tj, smem);
+}
+
 bool use_small_tn(int dtype, const TnParams& p) {
   static const char* env = getenv("FOD_TN_SMALL");
   if (env && env[0] == '0') return false;
@@ -646,6 +675,14 @@ extern "C" int fod_gemm_tn_grouped(int dtype, const void* G, long ldg, int g_seg
   p.g_bytes = (unsigned)gb;
   p.x_bytes = (unsigned)xb;
   hipLaunchKernelGGL(gemm_tn_small_kernel, dim3(ceil_div(K2, 64), ceil_div(N1, 64)), dim3(256), 0, stream, p);
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
+}
+
+extern "C" int fod_gemm_tn_multi(const fod_tn_job* jobs, const int* blk_job, const int* blk_tile, int nblocks,
+                                 hipStream_t stream) {
+  FOD_REQUIRE(jobs && blk_job && blk_tile && nblocks > 0, "gemm_tn_multi: bad args");
+  hipLaunchKernelGGL(gemm_tn_multi_kernel, dim3(nblocks), dim3(256), 0, stream, jobs, blk_job, blk_tile);
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }

@@ -245,6 +245,7 @@ class GraphedStep:
                 self._eager(static)               # one eager step through the device-side bias corrections
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        Fn.WGRADS.prepare(dev)                    # pinned job tables for the captures below (none can be made inside)
         if not self.ddp:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):

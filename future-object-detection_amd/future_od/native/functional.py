@@ -217,6 +217,184 @@ def zeros_f32(shape, device):
     return ARENA.zeros(tuple(shape), device)
 
 
+class _WgradQueue:
+    """The SHORT weight gradients of a backward pass (dW = G^T X over at most 512 rows: every Linear on the decoder's
+    query side, ~130 per step) launched together instead of one by one.  None of them is on the critical path of the
+    backward pass -- their results are first read by the gradient norm -- but each is a launch (a ~5 us graph node for
+    ~1 us of work).  A site hands its operands to `tn` / `grouped`; the autograd node returns the still all-zero
+    destination as the gradient, and ONE fod_gemm_tn_multi launch fills every destination when the pass ends (engine
+    callback), before the data-parallel reducer averages a region (parallel.GradientReducer.flush), or before a
+    parameter that already has a pending gradient in this pass is used again (autograd sums the gradients of a shared
+    parameter when the second one arrives: the first must be real by then).
+
+    Not deferred (the site launches at once, as without the queue): parameters that already hold a .grad (autograd adds
+    the returned tensor to it on arrival), parameters with tensor hooks, operands outside the short kernel's domain,
+    FOD_WGRAD_QUEUE=0, torch's own DistributedDataParallel reducer (it copies gradients into buckets on arrival;
+    parallel.FodDataParallel switches the queue off for it).
+
+    Inside a stream capture the job table is written into a pinned host buffer set aside BEFORE the capture (allocating
+    pinned memory inside one hangs) and copied by a captured memcpy node; host and device side of such a table are
+    never reused.  Without a spare the jobs are launched one by one."""
+
+    SPARE_BYTES = 1 << 18
+
+    def __init__(self):
+        import os
+        self.enabled = os.environ.get("FOD_WGRAD_QUEUE", "1") != "0" and os.environ.get("FOD_TN_SMALL", "1") != "0"
+        self.jobs = []
+        self.keep = []
+        self.task = -1               # autograd graph task whose end-of-pass callback is installed
+        self.epoch = 1
+        self._tables = {}
+        self._spares = []
+        self._baked = []
+        self.hold = False            # tests: collect jobs outside a backward pass until flush() is called
+        self.launches = 0            # multi launches / jobs they carried (tests, bench diagnostics)
+        self.carried = 0
+
+    # -- sites
+    def site(self, params):
+        """A backward node about to produce the gradients of `params`: True if its short weight gradients may wait."""
+        if not self.enabled:
+            return False
+        ok = True
+        for p in params:
+            if p is None:
+                continue
+            if not p.is_leaf:          # its gradient is read by further backward nodes as soon as it is returned
+                ok = False
+            elif p.__dict__.get("_fod_wq") == self.epoch:
+                self.flush()           # used again in this pass: the gradient handed out earlier must be real now
+                ok = False
+            elif (p.grad is not None or p._backward_hooks
+                  or getattr(p, "_post_accumulate_grad_hooks", None)):
+                ok = False
+        if ok:
+            for p in params:
+                if p is not None:
+                    p._fod_wq = self.epoch
+        return ok
+
+    @staticmethod
+    def _fits(g, x, dw, db, M, N1, K2, ldg, ldx):
+        if g.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or not g.is_cuda or M > 512 or M < 1:
+            return False
+        if N1 % 8 or K2 % 8 or ldg % 8 or ldx % 8 or (g.data_ptr() | x.data_ptr() | dw.data_ptr()) % 16:
+            return False
+        if ((N1 + 63) // 64) * ((K2 + 63) // 64) > 256 or not dw.is_contiguous():
+            return False
+        return db is None or db.is_contiguous()
+
+    def tn(self, ok, g, x, dw, db):
+        """dw [N1, K2] = g [M, N1]^T x [M, K2], db [N1] = column sums of g (dw, db all-zero f32)."""
+        N1, K2 = g.shape[-1], x.shape[-1]
+        M = g.numel() // N1
+        if not (ok and g.is_contiguous() and x.is_contiguous() and self._fits(g, x, dw, db, M, N1, K2, N1, K2)):
+            return ops.gemm_tn_acc(g, x, dw, colsum=db, zeroed=True)
+        self._push((g.data_ptr(), x.data_ptr(), dw.data_ptr(), 0 if db is None else db.data_ptr(), N1, K2, K2,
+                    M, N1, K2, 0, 0, 0), g, x, dw, db)
+
+    def grouped(self, ok, g, x, dw, db):
+        """g [P, rows, D] (P output gradients, each block contiguous), x [rows, K] -> dw [P*D, K], db [P*D]."""
+        P, rows, D = g.shape
+        K = x.shape[-1]
+        if not (ok and D % 64 == 0 and g.is_contiguous() and x.is_contiguous()
+                and self._fits(g, x, dw, db, rows, P * D, K, D, K)):
+            return ops.group_linear_wgrad(g, x, dw, db, zeroed=True)
+        self._push((g.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), D, K, K, rows, P * D, K, 0, D, rows * D),
+                   g, x, dw, db)
+
+    def _push(self, job, g, x, dw, db):
+        task = torch._C._current_graph_task_id()
+        if task != self.task and self.jobs:          # left behind by a backward pass that raised: not this pass's work
+            self.jobs, self.keep = [], []
+        self.jobs.append(job)
+        # detach(): a second handle on the same memory -- the gradient tensor itself must stay singly referenced, or
+        # autograd copies it instead of adopting it as .grad
+        self.keep.append((g, x, dw.detach(), None if db is None else db.detach()))
+        if task < 0:                     # not inside a backward pass (a backward function called directly)
+            self.task = -1
+            if not self.hold:
+                self.flush()
+        elif task != self.task:
+            self.task = task
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_pass)
+
+    def _end_of_pass(self):
+        self.task = -1
+        self.epoch += 1
+        self.flush()
+
+    # -- launch
+    def _pack(self, jobs):
+        import numpy as np
+        arr = (L.TnJob * len(jobs))()
+        bj, bt = [], []
+        order = sorted(range(len(jobs)), key=lambda i: -jobs[i][7])          # long reductions first
+        for slot, i in enumerate(order):
+            j = jobs[i]
+            arr[slot] = L.TnJob(*j)
+            tiles = ((j[8] + 63) // 64) * ((j[9] + 63) // 64)
+            bj.extend([slot] * tiles)
+            bt.extend(range(tiles))
+        head = np.frombuffer(bytes(arr), dtype=np.uint8)
+        pad = (-head.size) % 16
+        maps = np.asarray(bj + bt, dtype=np.int32).view(np.uint8)
+        raw = np.concatenate([head, np.zeros(pad, np.uint8), maps])
+        return raw, head.size + pad, len(bj)
+
+    def _top_up(self, device):
+        while len(self._spares) < 8:
+            self._spares.append((torch.empty(self.SPARE_BYTES, dtype=torch.uint8).pin_memory(),
+                                 torch.empty(self.SPARE_BYTES, dtype=torch.uint8, device=device)))
+
+    def prepare(self, device):
+        """Set aside the capture-time tables (call outside a capture; future_od/graph.py does before it captures)."""
+        if self.enabled and torch.device(device).type == "cuda":
+            self._top_up(device)
+
+    def flush(self):
+        jobs = self.jobs
+        if not jobs:
+            return
+        keep = self.keep
+        self.jobs, self.keep = [], []
+        dev = keep[0][0].device
+        sig = tuple(jobs)
+        tab = self._tables.get(sig)
+        if tab is None:
+            raw, off, nblocks = self._pack(jobs)
+            if torch.cuda.is_current_stream_capturing():
+                if not self._spares or raw.size > self.SPARE_BYTES or self._spares[-1][1].device != dev:
+                    return self._one_by_one(jobs)
+                pin, table = self._spares.pop()
+                self._baked.append((pin, table, keep))
+                pin[:raw.size].copy_(torch.from_numpy(raw))
+                table[:raw.size].copy_(pin[:raw.size], non_blocking=True)
+                tab = (table, off, nblocks)
+            else:
+                table = torch.from_numpy(raw).pin_memory().to(dev, non_blocking=True)
+                tab = (table, off, nblocks)
+                if len(self._tables) >= 8:
+                    self._tables.clear()
+                self._tables[sig] = tab
+                self._top_up(dev)
+        table, off, nblocks = tab
+        base = table.data_ptr()
+        L.call("fod_gemm_tn_multi", base, base + off, base + off + 4 * nblocks, nblocks, ops.stream(),
+               work=sum(2.0 * j[7] * j[8] * j[9] for j in jobs), tag="fod_gemm_tn_acc")
+        self.launches += 1
+        self.carried += len(jobs)
+
+    def _one_by_one(self, jobs):
+        for G, X, dW, cs, ldg, ldx, ldw, M, N1, K2, acc, seg_cols, seg_stride in jobs:
+            L.call("fod_gemm_tn_grouped", L.BF16, G, ldg, seg_cols, seg_stride, X, ldx, dW, ldw, M, N1, K2, cs,
+                   acc, ops.stream(), work=2.0 * M * N1 * K2, tag="fod_gemm_tn_acc")
+
+
+WGRADS = _WgradQueue()
+
+
 def _pad_to(n, v):
     return (n + v - 1) // v * v
 
@@ -317,7 +495,7 @@ class LinearFn(Function):
         y = ops.gemm_nt(x, w[:N] if w.shape[0] != N else w, shift=bias, relu=relu, out_f32=out_f32)
         y = y.view(*x.shape[:-1], N)
         ctx.relu, ctx.out_f32 = relu, out_f32
-        ctx.weight = weight
+        ctx.weight, ctx.bias = weight, bias
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, y if relu else None)
         return y
@@ -345,7 +523,7 @@ class LinearFn(Function):
         dbp = zeros_f32((Np,), x.device) if want_db else None
         if ctx.needs_input_grad[1]:
             dwp = zeros_f32((Np, K), x.device)
-            ops.gemm_tn_acc(g, x.view(-1, K), dwp, colsum=dbp, zeroed=True)   # bias gradient from the same pass
+            WGRADS.tn(WGRADS.site((weight, ctx.bias)), g, x.view(-1, K), dwp, dbp)    # bias gradient from the same pass
             dw = dwp[:N] if Np != N else dwp
         elif want_db:
             ops.colsum_acc(g, dbp)
@@ -371,7 +549,7 @@ class LinearKeepFn(Function):
         w = prep_linear(weight, dtype, False)
         N = weight.shape[0]
         y = ops.gemm_nt(x, w[:N] if w.shape[0] != N else w, shift=bias, relu=relu).view(*x.shape[:-1], N)
-        ctx.relu, ctx.weight, ctx.has_bias = relu, weight, bias is not None
+        ctx.relu, ctx.weight, ctx.bias, ctx.has_bias = relu, weight, bias, bias is not None
         ctx.mask_here = relu and not grad_masked
         ctx.save_for_backward(x, y if ctx.mask_here else None)
         return x.view_as(x), y
@@ -398,7 +576,7 @@ class LinearKeepFn(Function):
         dbp = zeros_f32((N,), x.device) if want_db else None
         if ctx.needs_input_grad[1]:
             dw = zeros_f32((N, K), x.device)
-            ops.gemm_tn_acc(g, x.view(-1, K), dw, colsum=dbp, zeroed=True)
+            WGRADS.tn(WGRADS.site((weight, ctx.bias)), g, x.view(-1, K), dw, dbp)
         elif want_db:
             ops.colsum_acc(g, dbp)
         return dx, dw, dbp, None, None
@@ -552,7 +730,7 @@ class LinearAddNormFn(Function):
         o = ops.gemm_nt(a, w, shift=bias).view(x.shape)
         y, s, mean, rstd = ops.layernorm_fwd(x, gamma, beta, residual=o)
         ctx.save_for_backward(a, s, mean, rstd, gamma)
-        ctx.weight, ctx.has_bias, ctx.a_relu = weight, bias is not None, bool(a_relu)
+        ctx.weight, ctx.bias, ctx.has_bias, ctx.a_relu = weight, bias, bias is not None, bool(a_relu)
         return y
 
     @staticmethod
@@ -574,7 +752,7 @@ class LinearAddNormFn(Function):
             db = zeros_f32((N,), dev)
         if ctx.needs_input_grad[2]:
             dw = zeros_f32((N, K), dev)
-            ops.gemm_tn_acc(g, a.view(-1, K), dw, colsum=db, zeroed=True)
+            WGRADS.tn(WGRADS.site((weight, ctx.bias)), g, a.view(-1, K), dw, db)
         elif want_db:
             ops.colsum_acc(g, db)
         return da, (dsum if ctx.needs_input_grad[1] else None), dw, db, dg, dbeta, None
@@ -807,8 +985,9 @@ class InProjFn(Function):
         dsrc = ops.gemm_nt(dv, prep_linear(w[2 * D:], dtype, True)).view(src.shape) if ctx.needs_input_grad[1] else None
         dw = zeros_f32((3 * D, D), xp.device)
         db = zeros_f32((3 * D,), xp.device)
-        ops.gemm_tn_acc(dqk, xp.view(rows, D), dw[:2 * D], colsum=db[:2 * D], zeroed=True)
-        ops.gemm_tn_acc(dv, src.view(rows, D), dw[2 * D:], colsum=db[2 * D:], zeroed=True)
+        wq = WGRADS.site((w, b))
+        WGRADS.tn(wq, dqk, xp.view(rows, D), dw[:2 * D], db[:2 * D])
+        WGRADS.tn(wq, dv, src.view(rows, D), dw[2 * D:], db[2 * D:])
         return dxp, dsrc, dw, db
 
 
@@ -856,8 +1035,9 @@ class InProjSelfFn(Function):
             dsrc = ops.gemm_nt(dv, prep_linear(w[2 * D:], dtype, True), residual=dxp).view(src.shape)
         dw = zeros_f32((3 * D, D), xp.device)
         db = zeros_f32((3 * D,), xp.device)
-        ops.gemm_tn_acc(dqk, xp.view(rows, D), dw[:2 * D], colsum=db[:2 * D], zeroed=True)
-        ops.gemm_tn_acc(dv, src.view(rows, D), dw[2 * D:], colsum=db[2 * D:], zeroed=True)
+        wq = WGRADS.site((w, b))
+        WGRADS.tn(wq, dqk, xp.view(rows, D), dw[:2 * D], db[:2 * D])
+        WGRADS.tn(wq, dv, src.view(rows, D), dw[2 * D:], db[2 * D:])
         return dsrc, None, dw, db, None
 
 
@@ -895,12 +1075,13 @@ class InProjCrossFn(Function):
         dw = zeros_f32((3 * D, D), xs[0].device)
         db = zeros_f32((3 * D,), xs[0].device)
         dxs = []
+        wq = WGRADS.site((w, b))
         for i, (x, g) in enumerate(zip(xs, (dq, dk, dv))):
             rows = x.numel() // D
             g = g.contiguous().view(rows, D)
             sl = slice(i * D, (i + 1) * D)
             dxs.append(ops.gemm_nt(g, prep_linear(w[sl], dtype, True)).view(x.shape) if ctx.needs_input_grad[i] else None)
-            ops.gemm_tn_acc(g, x.view(rows, D), dw[sl], colsum=db[sl], zeroed=True)
+            WGRADS.tn(wq, g, x.view(rows, D), dw[sl], db[sl])
         return dxs[0], dxs[1], dxs[2], dw, db
 
 
@@ -1056,7 +1237,7 @@ class WideLinearFn(Function):
             dx = ops.gemm_nt(g, wcat_t).view(x.shape)
         dw = zeros_f32((P * D_out, D_in), x.device)
         db = zeros_f32((P * D_out,), x.device)
-        ops.gemm_tn_acc(g, x.view(-1, D_in), dw, colsum=db, zeroed=True)
+        WGRADS.tn(WGRADS.site(ctx.params), g, x.view(-1, D_in), dw, db)
         gw = [dw[i * D_out:(i + 1) * D_out] for i in range(P)]
         gb = [db[i * D_out:(i + 1) * D_out] for i in range(P)]
         return (dx, None) + tuple(gw) + tuple(gb)
@@ -1106,7 +1287,7 @@ class GroupLinearFn(Function):
         dx = ops.group_linear_dgrad(g, wcat_t, P).view(x.shape) if ctx.needs_input_grad[0] else None
         dw = zeros_f32((P * D, K), x.device)
         db = zeros_f32((P * D,), x.device)
-        ops.group_linear_wgrad(g, x.view(rows, K), dw, db, zeroed=True)
+        WGRADS.grouped(WGRADS.site(ctx.params), g, x.view(rows, K), dw, db)
         return (dx,) + tuple(dw[i * D:(i + 1) * D] for i in range(P)) + tuple(db[i * D:(i + 1) * D] for i in range(P))
 
 

@@ -138,6 +138,8 @@ class GradientReducer:
 
     def flush(self, arena, min_elems=1):
         """Average the arena region filled since the last flush, if it holds at least `min_elems` elements."""
+        from future_od.native import functional as Fn
+        Fn.WGRADS.flush()                # weight gradients still waiting for their launch are part of the region
         if not self.enabled or not arena.active or arena.buf is None:
             return
         self.arm()

@@ -89,6 +89,24 @@ int fod_gemm_tn_grouped(int dtype, const void* G, long ldg, int g_seg_cols, long
 
 /* out[g, n] += sum over rows m of group g of G[m, n];  group g = m / group_rows (group_rows <= 0:
  * one group).  Bias gradients and sums over a broadcast dimension. */
+/* Many SHORT weight gradients (bf16, M <= 512 rows, no row scale; the conditions under which fod_gemm_tn_acc /
+ * fod_gemm_tn_grouped take their short-reduction kernel: N1, K2 multiples of 8, ldw % 4 == 0, 16-byte aligned operands,
+ * at most 256 64 x 64 tiles, operands < 4 GiB) in ONE launch: block b computes the 64 x 64 tile blk_tile[b]
+ * (row-major over ceil(N1/64) x ceil(K2/64)) of jobs[blk_job[b]].  jobs / blk_job / blk_tile live in device memory.
+ * accumulate = 0: dW / colsum are all-zero on entry (plain stores), 1: added to.  g_seg_*: as fod_gemm_tn_grouped. */
+typedef struct fod_tn_job {
+  const void* G;
+  const void* X;
+  float* dW;
+  float* colsum;
+  long ldg, ldx, ldw;
+  int M, N1, K2;
+  int accumulate;
+  int g_seg_cols;
+  long g_seg_stride;
+} fod_tn_job;
+int fod_gemm_tn_multi(const fod_tn_job* jobs, const int* blk_job, const int* blk_tile, int nblocks, fod_stream_t stream);
+
 int fod_colsum_acc(int dtype, const void* G, long ldg, int M, int N, int group_rows, float* out,
                    fod_stream_t stream);
 

@@ -700,3 +700,91 @@ def test_dropout_masks_of_consecutive_calls_are_not_index_permutations():
         for d in (0, 1, 2, 3, 4, 7, 8, 255):
             agree = float((b == a[idx ^ d]).float().mean())
             assert abs(agree - chance) < 0.02, (d, agree, chance)
+
+
+def test_gemm_tn_multi_matches_single_launches():
+    """fod_gemm_tn_multi (many short weight gradients in one launch) against the same jobs launched one by one: the
+    block of a tile runs the same code either way, so the results are bit-identical -- plain, ragged and segmented
+    (grouped) jobs, with and without a bias gradient, stores and accumulation."""
+    from future_od.native import functional as Fn
+    dtype = torch.bfloat16
+    cases = [(300, 256, 256, 0), (512, 264, 72, 0), (7, 8, 2048, 0), (96, 2048, 256, 0), (300, 3 * 64, 256, 64),
+             (33, 5 * 128, 32, 128)]
+    q = Fn._WgradQueue()
+    q.enabled = q.hold = True
+    refs, outs = [], []
+    for i, (M, N1, K2, seg) in enumerate(cases):
+        x = rnd((M, K2), dtype, 40 + i).to(DEV)
+        if seg:
+            P = N1 // seg
+            g = rnd((P, M, seg), dtype, 60 + i).to(DEV)
+        else:
+            g = rnd((M, N1), dtype, 60 + i).to(DEV)
+        want_db = i % 2 == 0 or bool(seg)
+        dw_ref = torch.zeros(N1, K2, device=DEV)
+        db_ref = torch.zeros(N1, device=DEV) if want_db else None
+        dw = torch.zeros(N1, K2, device=DEV)
+        db = torch.zeros(N1, device=DEV) if want_db else None
+        if seg:
+            ops.group_linear_wgrad(g, x, dw_ref, db_ref, zeroed=True)
+            q.grouped(True, g, x, dw, db)
+        else:
+            ops.gemm_tn_acc(g, x, dw_ref, colsum=db_ref, zeroed=True)
+            q.tn(True, g, x, dw, db)
+        refs.append((dw_ref, db_ref))
+        outs.append((dw, db))
+        gf = g.float().permute(1, 0, 2).reshape(M, N1) if seg else g.float()
+        check(dw_ref, gf.t() @ x.float(), dtype, math.sqrt(M), f"tn single {cases[i]}")
+    assert q.launches == 0 and len(q.jobs) == len(cases)
+    for dw, _ in outs:
+        assert not bool(dw.any())                      # nothing has run yet
+    q.flush()
+    assert q.launches == 1 and q.carried == len(cases) and not q.jobs
+    for (dw_ref, db_ref), (dw, db), c in zip(refs, outs, cases):
+        assert torch.equal(dw, dw_ref), c
+        assert db is None or torch.equal(db, db_ref), c
+
+
+def test_wgrad_queue_in_autograd():
+    """Deferred weight gradients through autograd: a layer used ONCE per pass is queued (its .grad is the buffer the
+    multi launch fills), a layer used TWICE forces the first gradient out before autograd sums the two, a parameter that
+    already holds a .grad is not deferred.  All bit-equal to the same passes with the queue switched off."""
+    from future_od.native import functional as Fn
+    torch.manual_seed(5)
+    lin_a = torch.nn.Linear(256, 256).to(DEV)
+    lin_b = torch.nn.Linear(256, 64).to(DEV)
+    shared = torch.nn.Linear(256, 256).to(DEV)
+    x = torch.randn(4, 75, 256, device=DEV).to(torch.bfloat16)
+    params = list(lin_a.parameters()) + list(lin_b.parameters()) + list(shared.parameters())
+
+    def run(passes):
+        for p in params:
+            p.grad = None
+        for _ in range(passes):
+            h = Fn.linear(x, lin_a.weight, lin_a.bias, relu=True)
+            h = Fn.linear(h, shared.weight, shared.bias)
+            h = Fn.linear(h, shared.weight, shared.bias, relu=True)
+            y = Fn.linear(h, lin_b.weight, lin_b.bias, out_f32=True)
+            (y.float() ** 2).mean().backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in params]
+
+    q = Fn.WGRADS
+    was = q.enabled
+    try:
+        q.enabled = False
+        ref1, ref2 = run(1), run(2)
+        q.enabled = True
+        l0, c0 = q.launches, q.carried
+        got1 = run(1)
+        # lin_b, the second use of `shared` (first to run in backward) queued; the first use flushes them and runs at
+        # once; lin_a queued and flushed at the end of the pass
+        assert (q.launches - l0, q.carried - c0) == (2, 3)
+        got2 = run(2)                                  # second pass: every .grad exists -> nothing deferred
+        assert (q.launches - l0, q.carried - c0) == (4, 6)
+    finally:
+        q.enabled = was
+    for a, b in zip(got1, ref1):
+        assert torch.equal(a, b)
+    for a, b in zip(got2, ref2):
+        assert torch.equal(a, b)
