@@ -1,0 +1,70 @@
+"""Where autograd sums gradients with kernels of its own: every (backward node, input slot) of one headline forward pass
+that receives a gradient from MORE than one consumer -- each extra consumer is one add launch (a ~5 us graph node) per
+step.  Also tallies the element-wise entry point's calls per calling function over one eager step.
+    python tools/grad_fanout.py            (on the GPU box)"""
+import collections
+import os
+import sys
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "future-object-detection_amd")]
+import torch
+
+import bench
+from future_od.datasets.synthetic import make_batch
+from future_od.native import lib as L
+from future_od.native import ops
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    from types import SimpleNamespace
+    model, detr = bench.build(SimpleNamespace(), dev, False, 5, "bf16")
+    model.eval()
+    data = make_batch(bench.BATCH_PER_GPU, bench.T_FRAMES, bench.HEIGHT, bench.WIDTH, seed=1234, device=dev)
+    calls = collections.Counter()
+    real = ops.call
+
+    def counting(name, *a, **k):
+        if name in ("fod_eltwise", "fod_layernorm_fwd", "fod_permute3_cast", "fod_colsum_acc"):
+            fr = [f for f in traceback.extract_stack(limit=7)[:-1] if "native/ops.py" not in f.filename]
+            calls[(name, a[0] if name == "fod_eltwise" else "", " < ".join(f"{f.name}:{f.lineno}" for f in fr[-3:][::-1]))] += 1
+        return real(name, *a, **k)
+
+    ops.call = counting
+    out, _s, loss, _st, _od = model(data=data, distributed=False)
+    # consumers of each (node, slot): walk the graph from the loss
+    seen, stack = set(), [loss.grad_fn]
+    fan = collections.defaultdict(list)
+    while stack:
+        fn = stack.pop()
+        if fn is None or fn in seen:
+            continue
+        seen.add(fn)
+        for nxt, slot in fn.next_functions:
+            if nxt is not None:
+                fan[(nxt, slot)].append(fn)
+                stack.append(nxt)
+    multi = collections.Counter()
+    for (fn, slot), cons in fan.items():
+        if len(cons) > 1 and "AccumulateGrad" not in fn.name():
+            multi[(fn.name(), slot, tuple(sorted(c.name() for c in cons)))] += 1
+    print(f"{len(seen)} backward nodes; (node, slot) pairs with more than one consumer (autograd adds {sum((len(k[2]) - 1) * v for k, v in multi.items())} times):")
+    for (name, slot, cons), n in sorted(multi.items(), key=lambda kv: -kv[1]):
+        print(f"  {n:3d} x  {name}[{slot}]  <-  {', '.join(cons)}")
+    shared = collections.Counter()
+    for (fn, slot), cons in fan.items():
+        if len(cons) > 1 and "AccumulateGrad" in fn.name():
+            shared[tuple(sorted(c.name() for c in cons))] += 1
+    print("parameters used more than once:")
+    for cons, n in shared.most_common():
+        print(f"  {n:3d} x  {', '.join(cons)}")
+    loss.backward()
+    torch.cuda.synchronize()
+    print("element-wise / norm / cast entry calls of one eager step, by caller:")
+    for (name, op, where), n in sorted(calls.items(), key=lambda kv: -kv[1]):
+        print(f"  {n:3d}  {name} {op}  {where}")
+
+
+main()

@@ -16,7 +16,7 @@ ENTRY = [  # (substring of the kernel name, entry point)
     ("pack_targets_kernel", "fod_pack_targets"), ("attn_fwd_lds_kernel", "fod_attn_fwd"),
     ("conv2d_fwd_kernel", "fod_conv2d_fwd"), ("conv2d_dgrad", "fod_conv2d_dgrad"),
     ("conv2d_wgrad_kernel", "fod_conv2d_wgrad_acc"), ("gemm_nt_small_kernel", "fod_gemm_nt"),
-    ("gemm_nt_kernel", "fod_gemm_nt"), ("gemm_tn_small_kernel", "fod_gemm_tn_acc"), ("gemm_tn_kernel", "fod_gemm_tn_acc"),
+    ("gemm_nt_kernel", "fod_gemm_nt"), ("gemm_tn_small_kernel", "fod_gemm_tn_acc"), ("gemm_tn_multi_kernel", "fod_gemm_tn_acc"), ("gemm_tn_kernel", "fod_gemm_tn_acc"),
     ("attn_fwd_kernel", "fod_attn_fwd"), ("attn_bwd", "fod_attn_bwd"), ("ln_fwd_kernel", "fod_layernorm_fwd"),
     ("ln_bwd_kernel", "fod_layernorm_bwd"), ("eltwise_kernel", "fod_eltwise"), ("maxpool", "fod_maxpool3x3s2"),
     ("multi_adamw", "fod_multi_adamw"), ("multi_sqnorm", "fod_multi_sqnorm_acc"), ("permute3", "fod_permute3_cast"),
