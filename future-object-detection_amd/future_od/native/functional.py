@@ -375,7 +375,7 @@ class _WgradQueue:
             else:
                 table = torch.from_numpy(raw).pin_memory().to(dev, non_blocking=True)
                 tab = (table, off, nblocks)
-                if len(self._tables) >= 8:
+                if len(self._tables) >= 32:
                     self._tables.clear()
                 self._tables[sig] = tab
                 self._top_up(dev)

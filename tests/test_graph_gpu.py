@@ -75,6 +75,31 @@ def test_graphed_steps_track_eager_steps(dtype):
     assert abs(float(l1) - float(l2)) <= tol * max(abs(float(l2)), 1.0)
 
 
+def test_capture_without_spare_job_tables_launches_the_queued_gradients_one_by_one(monkeypatch):
+    """The queued short weight gradients (native/functional.py: WGRADS) need a pinned job table set aside BEFORE a
+    capture; a capture that finds none (more flushes than spares, a foreign capture) must launch them one by one --
+    never allocate inside the capture, never drop a gradient."""
+    from future_od.datasets.synthetic import make_batch
+    from future_od.graph import GraphedStep
+    from future_od.native import functional as Fn
+    q = Fn.WGRADS
+    assert q.enabled
+    monkeypatch.setattr(q, "_spares", [])
+    monkeypatch.setattr(q, "_top_up", lambda dev: None)
+    baked = len(q._baked)
+    data = make_batch(2, 3, 96, 128, seed=11, max_boxes=9, device=DEV)
+    data2 = make_batch(2, 3, 96, 128, seed=12, max_boxes=20, device=DEV)
+    m_e, o_e = _build("bf16")
+    m_g, o_g = _build("bf16")
+    step = GraphedStep(m_g, o_g, warmup=2)
+    seq = [data, data, data, data, data2, data]
+    le = [float(_eager_step(m_e, o_e, d)) for d in seq]
+    lg = [None, None, None] + [float(step(d)[1].detach()) for d in seq[3:]]
+    assert step.replays == 3 and len(q._baked) == baked          # no table was baked into the graph
+    for i in range(3, len(seq)):
+        assert abs(lg[i] - le[i]) <= 2e-3 * max(abs(le[i]), 1.0), (i, lg[i], le[i])
+
+
 def test_graph_outputs_are_the_eager_outputs_at_equal_parameters():
     """One replay against one eager forward/backward from the SAME parameters: the forward has no atomics, so the
     loss, the detections and the AP bookkeeping must be bit-identical; gradients agree to accumulation-order noise."""

@@ -1,15 +1,12 @@
 set -e
-mkdir -p gpurun_out/r02w
-timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -x -q -k "tn_multi or wgrad_queue" > gpurun_out/r02w/t0.log 2>&1 || { tail -30 gpurun_out/r02w/t0.log; exit 1; }
-tail -2 gpurun_out/r02w/t0.log
-timeout -k 10 200 python bench.py --no-cpu-baseline --no-extras > gpurun_out/r02w/bench_q1.json 2> gpurun_out/r02w/bench_q1.err || { tail -20 gpurun_out/r02w/bench_q1.err; exit 1; }
-FOD_WGRAD_QUEUE=0 timeout -k 10 200 python bench.py --no-cpu-baseline --no-extras > gpurun_out/r02w/bench_q0.json 2> gpurun_out/r02w/bench_q0.err
-timeout -k 10 200 python bench.py --no-cpu-baseline --no-extras > gpurun_out/r02w/bench_q1b.json 2> gpurun_out/r02w/bench_q1b.err
-FOD_WGRAD_QUEUE=0 timeout -k 10 200 python bench.py --no-cpu-baseline --no-extras > gpurun_out/r02w/bench_q0b.json 2> gpurun_out/r02w/bench_q0b.err
+mkdir -p gpurun_out/r02w2
+timeout -k 10 300 python -m pytest tests/test_graph_gpu.py -x -q -k "spare_job_tables or track_eager" > gpurun_out/r02w2/t0.log 2>&1 || { tail -30 gpurun_out/r02w2/t0.log; exit 1; }
+tail -2 gpurun_out/r02w2/t0.log
+timeout -k 10 300 python bench.py --gpus 1 --force-ddp --no-cpu-baseline --no-extras > gpurun_out/r02w2/ddp1_graph.json 2> gpurun_out/r02w2/ddp1_graph.err || { tail -20 gpurun_out/r02w2/ddp1_graph.err; exit 1; }
+timeout -k 10 300 python bench.py --gpus 1 --force-ddp --no-graph --no-cpu-baseline --no-extras > gpurun_out/r02w2/ddp1_eager.json 2> gpurun_out/r02w2/ddp1_eager.err || { tail -20 gpurun_out/r02w2/ddp1_eager.err; exit 1; }
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --rehearse --steps 4 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/r02w2/rehearse2.json 2> gpurun_out/r02w2/rehearse2.err || { tail -20 gpurun_out/r02w2/rehearse2.err; exit 1; }
 python - <<'P'
 import json
-for n in ("q1","q0","q1b","q0b"):
-    d=json.load(open(f"gpurun_out/r02w/bench_{n}.json")); print(n, d["value"], d["ms_per_step"])
+for n in ("ddp1_graph","ddp1_eager","rehearse2"):
+    d=json.loads(open(f"gpurun_out/r02w2/{n}.json").read().strip().splitlines()[-1]); print(n, d["value"], d["ms_per_step"], json.dumps(d.get("ddp"))[:300])
 P
-timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r02w/tests.log 2>&1 || { tail -40 gpurun_out/r02w/tests.log; exit 1; }
-tail -3 gpurun_out/r02w/tests.log
