@@ -404,8 +404,18 @@ __global__ void colsum_kernel(const T* __restrict__ G, long ldg, int M, int N, i
 // staged rows four ways and read their fragments with the transposing LDS read, and the four partial tiles
 // meet in LDS once.  LDS rows are 128 B unpadded; 64-B half `hc` of row r is stored at half hc ^ ((r>>1)&1),
 // which puts the 4 rows x 64 B of a transposed read on 64 distinct banks.
-FOD_DEVINL void tn_small_body(const TnParams& p, const int bx, const int by, unsigned char* smem) {
+// `more` / `nmore`: further (G, X, M) segments whose products are added into the same tile before the one epilogue
+// (fod_gemm_tn_multi: the gradients of a parameter used several times in one backward pass, summed in queue order).
+FOD_DEVINL unsigned tn_job_g_bytes(const fod_tn_job& j) {
+  const long nseg = j.g_seg_cols > 0 ? (j.N1 + j.g_seg_cols - 1) / j.g_seg_cols : 1;
+  const long seg_c = j.g_seg_cols > 0 ? j.g_seg_cols : j.N1;
+  return (unsigned)(((nseg - 1) * j.g_seg_stride + (long)(j.M - 1) * j.ldg + seg_c) * 2);
+}
+
+FOD_DEVINL void tn_small_body(const TnParams& p0, const int bx, const int by, unsigned char* smem,
+                              const fod_tn_job* __restrict__ more = nullptr, const int nmore = 0) {
   typedef __bf16 T;
+  TnParams p = p0;                           // the segment being reduced (G, X, M, strides); outputs are p0's
   constexpr int ROWS = 256;
   unsigned char* sG = smem;                  // ROWS x 128 B
   unsigned char* sX = smem + ROWS * 128;     // ROWS x 128 B
@@ -413,8 +423,6 @@ FOD_DEVINL void tn_small_body(const TnParams& p, const int bx, const int by, uns
   const int j0 = bx * 64, i0 = by * 64;
   FOD_STAMP(0);
   constexpr unsigned OOB = 0xFFFFFFF0u;
-  const auto rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.G), 0, p.g_bytes, 0x00020000);
-  const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.X), 0, p.x_bytes, 0x00020000);
   // old values of this thread's outputs (accumulate) through a descriptor that is empty otherwise
   const int cq = tid & 15, rq = tid >> 4;
   const int jn = j0 + cq * 4;
@@ -431,11 +439,6 @@ FOD_DEVINL void tn_small_body(const TnParams& p, const int bx, const int by, uns
   const int cc = tid & 7, r0 = tid >> 3;     // 16-byte chunk column / first row (then +32 ...) of the staging pass
   const int gi = i0 + cc * 8, xj = j0 + cc * 8;
   const bool g_ok = gi < p.N1, x_ok = xj < p.K2;
-  long g_col = gi;                 // element offset of column gi inside a row of G (segmented: the tile's 64 columns
-  if (p.g_seg_cols > 0) {          // lie in one segment, g_seg_cols % 64 == 0)
-    const int seg = i0 / p.g_seg_cols;
-    g_col = (long)seg * p.g_seg_stride + (gi - seg * p.g_seg_cols);
-  }
   const bool do_colsum = p.colsum != nullptr && bx == 0;
   float csum[8];
 #pragma unroll
@@ -448,6 +451,15 @@ FOD_DEVINL void tn_small_body(const TnParams& p, const int bx, const int by, uns
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  bool staged = false;                           // the staging buffers hold fragments some wave may still be reading
+  for (int s = 0;; ++s) {
+  const auto rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.G), 0, p.g_bytes, 0x00020000);
+  const auto rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.X), 0, p.x_bytes, 0x00020000);
+  long g_col = gi;                 // element offset of column gi inside a row of G (segmented: the tile's 64 columns
+  if (p.g_seg_cols > 0) {          // lie in one segment, g_seg_cols % 64 == 0)
+    const int seg = i0 / p.g_seg_cols;
+    g_col = (long)seg * p.g_seg_stride + (gi - seg * p.g_seg_cols);
+  }
   for (int mb = 0; mb < p.M; mb += ROWS) {
     uint4 vg[8], vx[8];
 #pragma unroll
@@ -461,7 +473,8 @@ FOD_DEVINL void tn_small_body(const TnParams& p, const int bx, const int by, uns
       __builtin_memcpy(&vg[i], &a, 16);
       __builtin_memcpy(&vx[i], &b, 16);
     }
-    if (mb > 0) __syncthreads();               // the previous chunk's fragments have been read
+    if (staged) __syncthreads();               // the previous chunk's fragments have been read
+    staged = true;
     if (mb == 0) FOD_STAMP(1);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -510,6 +523,17 @@ FOD_DEVINL void tn_small_body(const TnParams& p, const int bx, const int by, uns
       }
     }
   }
+  if (s >= nmore) break;
+  {                                              // next segment of the chain: same outputs, other operands
+    const fod_tn_job& j = more[s];
+    p.G = j.G; p.X = j.X;
+    p.ldg = j.ldg; p.ldx = j.ldx;
+    p.M = j.M;
+    p.g_seg_cols = j.g_seg_cols; p.g_seg_stride = j.g_seg_stride;
+    p.g_bytes = tn_job_g_bytes(j);
+    p.x_bytes = (unsigned)(((long)(j.M - 1) * j.ldx + j.K2) * 2);
+  }
+  }
   FOD_STAMP(3);
   __syncthreads();                               // staging buffers are free
   if (do_colsum) {
@@ -555,12 +579,14 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const TnParams p) {
 // MANY short weight gradients in ONE launch (fod_gemm_tn_multi): block b works on tile blk_tile[b] of job blk_job[b].
 // The decoder's query side produces ~130 of these per step, each a 5 us graph node of its own although none of them is
 // on the backward pass's critical path -- queued during the backward pass and launched together at its end
-// (native/functional.py: WGRAD_QUEUE), they cost one node.
+// (native/functional.py: WGRADS), they cost one node.  A job with chain = n is followed in the table by n entries that
+// only contribute operands (G, X, M, strides): their products are added into the job's tile in table order.
 __global__ __launch_bounds__(256) void gemm_tn_multi_kernel(const fod_tn_job* __restrict__ jobs,
                                                             const int* __restrict__ blk_job,
                                                             const int* __restrict__ blk_tile) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[65536];
-  const fod_tn_job& j = jobs[blk_job[blockIdx.x]];
+  const int head = blk_job[blockIdx.x];
+  const fod_tn_job& j = jobs[head];
   TnParams p{};
   p.G = j.G; p.X = j.X; p.dW = j.dW;
   p.ldg = j.ldg; p.ldx = j.ldx; p.ldw = j.ldw;
@@ -568,13 +594,11 @@ __global__ __launch_bounds__(256) void gemm_tn_multi_kernel(const fod_tn_job* __
   p.colsum = j.colsum;
   p.accumulate = j.accumulate;
   p.g_seg_cols = j.g_seg_cols; p.g_seg_stride = j.g_seg_stride;
-  const long nseg = j.g_seg_cols > 0 ? (j.N1 + j.g_seg_cols - 1) / j.g_seg_cols : 1;
-  const long seg_c = j.g_seg_cols > 0 ? j.g_seg_cols : j.N1;
-  p.g_bytes = (unsigned)(((nseg - 1) * j.g_seg_stride + (long)(j.M - 1) * j.ldg + seg_c) * 2);
+  p.g_bytes = tn_job_g_bytes(j);
   p.x_bytes = (unsigned)(((long)(j.M - 1) * j.ldx + j.K2) * 2);
   const int tj = (j.K2 + 63) >> 6;
   const int tile = blk_tile[blockIdx.x];
-  tn_small_body(p, tile % tj, tile / tj, smem);
+  tn_small_body(p, tile % tj, tile / tj, smem, jobs + head + 1, j.chain);
 }
 
 bool use_small_tn(int dtype, const TnParams& p) {

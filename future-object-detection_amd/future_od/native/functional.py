@@ -225,7 +225,11 @@ class _WgradQueue:
     destination as the gradient, and ONE fod_gemm_tn_multi launch fills every destination when the pass ends (engine
     callback), before the data-parallel reducer averages a region (parallel.GradientReducer.flush), or before a
     parameter that already has a pending gradient in this pass is used again (autograd sums the gradients of a shared
-    parameter when the second one arrives: the first must be real by then).
+    parameter when the second one arrives: the first must be real by then).  A plain Linear used several times in a pass
+    (the decoder's query_scale, once per layer) does better: its later uses join the FIRST use's job as further
+    (g, x) segments (`chain`) -- the block that owns a tile sums them in queue order and stores once, the autograd
+    node returns no gradient of its own, so there is neither a flush nor a gradient-sum kernel, and the parameter's
+    gradient stays inside the arena (one flat all-reduce in data-parallel runs).
 
     Not deferred (the site launches at once, as without the queue): parameters that already hold a .grad (autograd adds
     the returned tensor to it on arrival), parameters with tensor hooks, operands outside the short kernel's domain,
@@ -242,7 +246,9 @@ class _WgradQueue:
         import os
         self.enabled = os.environ.get("FOD_WGRAD_QUEUE", "1") != "0" and os.environ.get("FOD_TN_SMALL", "1") != "0"
         self.jobs = []
+        self.members = {}            # index into jobs -> further (G, X, M) contributions to that job's outputs
         self.keep = []
+        self.serial = 0              # flushes so far: a job index is only meaningful within one
         self.task = -1               # autograd graph task whose end-of-pass callback is installed
         self.epoch = 1
         self._tables = {}
@@ -285,14 +291,37 @@ class _WgradQueue:
             return False
         return db is None or db.is_contiguous()
 
-    def tn(self, ok, g, x, dw, db):
-        """dw [N1, K2] = g [M, N1]^T x [M, K2], db [N1] = column sums of g (dw, db all-zero f32)."""
+    def tn(self, ok, g, x, dw, db, owner=None):
+        """dw [N1, K2] = g [M, N1]^T x [M, K2], db [N1] = column sums of g (dw, db all-zero f32).  `owner`: the weight
+        parameter, if further uses of it in this pass may add to this job (`chain`)."""
         N1, K2 = g.shape[-1], x.shape[-1]
         M = g.numel() // N1
         if not (ok and g.is_contiguous() and x.is_contiguous() and self._fits(g, x, dw, db, M, N1, K2, N1, K2)):
             return ops.gemm_tn_acc(g, x, dw, colsum=db, zeroed=True)
         self._push((g.data_ptr(), x.data_ptr(), dw.data_ptr(), 0 if db is None else db.data_ptr(), N1, K2, K2,
                     M, N1, K2, 0, 0, 0), g, x, dw, db)
+        if owner is not None and self.jobs:
+            owner._fod_wq_job = (self.epoch, self.serial, len(self.jobs) - 1)
+
+    def chain(self, owner, want_db, g, x):
+        """A FURTHER use of `owner` (a weight whose gradient job of this pass is still waiting): its g^T x -- and g's
+        column sums -- are added inside that job (summed in queue order by the block that owns the tile, one store).
+        True: done, the caller returns no gradient for the parameter (autograd would add a second tensor with a kernel
+        of its own, and could not, the first one being unfinished).  False: not possible, proceed as usual."""
+        rec = owner.__dict__.get("_fod_wq_job") if self.enabled else None
+        if rec is None or rec[0] != self.epoch or rec[1] != self.serial or rec[2] >= len(self.jobs):
+            return False
+        head = self.jobs[rec[2]]
+        N1, K2 = g.shape[-1], x.shape[-1]
+        M = g.numel() // N1
+        if (head[8], head[9]) != (N1, K2) or head[11] != 0 or (head[3] != 0) != bool(want_db):
+            return False
+        if not (g.is_contiguous() and x.is_contiguous() and g.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+                and 1 <= M <= 512 and (g.data_ptr() | x.data_ptr()) % 16 == 0):
+            return False
+        self.members.setdefault(rec[2], []).append((g.data_ptr(), x.data_ptr(), 0, 0, N1, K2, K2, M, N1, K2, 1, 0, 0))
+        self.keep.append((g, x, None, None))
+        return True
 
     def grouped(self, ok, g, x, dw, db):
         """g [P, rows, D] (P output gradients, each block contiguous), x [rows, K] -> dw [P*D, K], db [P*D]."""
@@ -307,7 +336,8 @@ class _WgradQueue:
     def _push(self, job, g, x, dw, db):
         task = torch._C._current_graph_task_id()
         if task != self.task and self.jobs:          # left behind by a backward pass that raised: not this pass's work
-            self.jobs, self.keep = [], []
+            self.jobs, self.keep, self.members = [], [], {}
+            self.serial += 1
         self.jobs.append(job)
         # detach(): a second handle on the same memory -- the gradient tensor itself must stay singly referenced, or
         # autograd copies it instead of adopting it as .grad
@@ -326,17 +356,21 @@ class _WgradQueue:
         self.flush()
 
     # -- launch
-    def _pack(self, jobs):
+    def _pack(self, jobs, members):
         import numpy as np
-        arr = (L.TnJob * len(jobs))()
+        arr = (L.TnJob * (len(jobs) + sum(len(m) for m in members.values())))()
         bj, bt = [], []
-        order = sorted(range(len(jobs)), key=lambda i: -jobs[i][7])          # long reductions first
-        for slot, i in enumerate(order):
+        rows = lambda i: jobs[i][7] + sum(m[7] for m in members.get(i, ()))
+        slot = 0
+        for i in sorted(range(len(jobs)), key=lambda i: -rows(i)):           # long reductions first
             j = jobs[i]
-            arr[slot] = L.TnJob(*j)
+            more = members.get(i, ())
             tiles = ((j[8] + 63) // 64) * ((j[9] + 63) // 64)
             bj.extend([slot] * tiles)
             bt.extend(range(tiles))
+            for e, n in [(j, len(more))] + [(m, 0) for m in more]:
+                arr[slot] = L.TnJob(*e[:12], n, e[12])
+                slot += 1
         head = np.frombuffer(bytes(arr), dtype=np.uint8)
         pad = (-head.size) % 16
         maps = np.asarray(bj + bt, dtype=np.int32).view(np.uint8)
@@ -357,16 +391,17 @@ class _WgradQueue:
         jobs = self.jobs
         if not jobs:
             return
-        keep = self.keep
-        self.jobs, self.keep = [], []
+        keep, members = self.keep, self.members
+        self.jobs, self.keep, self.members = [], [], {}
+        self.serial += 1
         dev = keep[0][0].device
-        sig = tuple(jobs)
+        sig = (tuple(jobs), tuple((i, tuple(m)) for i, m in sorted(members.items()))) if members else tuple(jobs)
         tab = self._tables.get(sig)
         if tab is None:
-            raw, off, nblocks = self._pack(jobs)
+            raw, off, nblocks = self._pack(jobs, members)
             if torch.cuda.is_current_stream_capturing():
                 if not self._spares or raw.size > self.SPARE_BYTES or self._spares[-1][1].device != dev:
-                    return self._one_by_one(jobs)
+                    return self._one_by_one(jobs, members)
                 pin, table = self._spares.pop()
                 self._baked.append((pin, table, keep))
                 pin[:raw.size].copy_(torch.from_numpy(raw))
@@ -382,14 +417,18 @@ class _WgradQueue:
         table, off, nblocks = tab
         base = table.data_ptr()
         L.call("fod_gemm_tn_multi", base, base + off, base + off + 4 * nblocks, nblocks, ops.stream(),
-               work=sum(2.0 * j[7] * j[8] * j[9] for j in jobs), tag="fod_gemm_tn_acc")
+               work=sum(2.0 * j[7] * j[8] * j[9] for j in jobs)
+               + sum(2.0 * m[7] * m[8] * m[9] for ms in members.values() for m in ms), tag="fod_gemm_tn_acc")
         self.launches += 1
-        self.carried += len(jobs)
+        self.carried += len(jobs) + sum(len(m) for m in members.values())
 
-    def _one_by_one(self, jobs):
-        for G, X, dW, cs, ldg, ldx, ldw, M, N1, K2, acc, seg_cols, seg_stride in jobs:
+    def _one_by_one(self, jobs, members):
+        for i, (G, X, dW, cs, ldg, ldx, ldw, M, N1, K2, acc, seg_cols, seg_stride) in enumerate(jobs):
             L.call("fod_gemm_tn_grouped", L.BF16, G, ldg, seg_cols, seg_stride, X, ldx, dW, ldw, M, N1, K2, cs,
                    acc, ops.stream(), work=2.0 * M * N1 * K2, tag="fod_gemm_tn_acc")
+            for m in members.get(i, ()):             # stream-ordered after the head: plain read-modify-write is safe
+                L.call("fod_gemm_tn_grouped", L.BF16, m[0], m[4], 0, 0, m[1], m[5], dW, ldw, m[7], N1, K2, cs, 1,
+                       ops.stream(), work=2.0 * m[7] * N1 * K2, tag="fod_gemm_tn_acc")
 
 
 WGRADS = _WgradQueue()
@@ -520,10 +559,13 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0]:
             dx = ops.gemm_nt(g, prep_linear(weight, dtype, True)).view(x.shape)
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] and WGRADS.chain(weight, want_db, g, x.view(-1, K)):
+            return dx, None, None, None, None        # a further use of a shared layer: summed inside the first use's job
         dbp = zeros_f32((Np,), x.device) if want_db else None
         if ctx.needs_input_grad[1]:
             dwp = zeros_f32((Np, K), x.device)
-            WGRADS.tn(WGRADS.site((weight, ctx.bias)), g, x.view(-1, K), dwp, dbp)    # bias gradient from the same pass
+            # bias gradient from the same pass
+            WGRADS.tn(WGRADS.site((weight, ctx.bias)), g, x.view(-1, K), dwp, dbp, owner=weight)
             dw = dwp[:N] if Np != N else dwp
         elif want_db:
             ops.colsum_acc(g, dbp)

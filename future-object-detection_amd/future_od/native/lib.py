@@ -56,7 +56,7 @@ class TnJob(C.Structure):          # fod_tn_job (include/fod.h)
     _fields_ = [("G", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("colsum", C.c_void_p),
                 ("ldg", C.c_long), ("ldx", C.c_long), ("ldw", C.c_long),
                 ("M", C.c_int), ("N1", C.c_int), ("K2", C.c_int), ("accumulate", C.c_int),
-                ("g_seg_cols", C.c_int), ("g_seg_stride", C.c_long)]
+                ("g_seg_cols", C.c_int), ("chain", C.c_int), ("g_seg_stride", C.c_long)]
 
 
 _i, _l, _f, _p = C.c_int, C.c_long, C.c_float, C.c_void_p

@@ -259,6 +259,8 @@ class FodDataParallel(DistributedDataParallel):
         else:
             super().__init__(module, broadcast_buffers=False, bucket_cap_mb=bucket_cap_mb, find_unused_parameters=False,
                              process_group=process_group)
+            from future_od.native import functional as Fn
+            Fn.WGRADS.enabled = False    # torch's reducer hooks see gradients on arrival: none may be filled in later
         self.require_backward_grad_sync = False          # torch's reducer stays idle (as under no_sync())
         self.grad_reducer = GradientReducer(self.module.parameters(), self.process_group, bucket_cap_mb)
         self._sync_enabled = True

@@ -93,7 +93,8 @@ int fod_gemm_tn_grouped(int dtype, const void* G, long ldg, int g_seg_cols, long
  * fod_gemm_tn_grouped take their short-reduction kernel: N1, K2 multiples of 8, ldw % 4 == 0, 16-byte aligned operands,
  * at most 256 64 x 64 tiles, operands < 4 GiB) in ONE launch: block b computes the 64 x 64 tile blk_tile[b]
  * (row-major over ceil(N1/64) x ceil(K2/64)) of jobs[blk_job[b]].  jobs / blk_job / blk_tile live in device memory.
- * accumulate = 0: dW / colsum are all-zero on entry (plain stores), 1: added to.  g_seg_*: as fod_gemm_tn_grouped. */
+ * accumulate = 0: dW / colsum are all-zero on entry (plain stores), 1: added to (no two jobs of one launch may share
+ * outputs: the update is not atomic -- chain them instead).  g_seg_*: as fod_gemm_tn_grouped. */
 typedef struct fod_tn_job {
   const void* G;
   const void* X;
@@ -103,6 +104,9 @@ typedef struct fod_tn_job {
   int M, N1, K2;
   int accumulate;
   int g_seg_cols;
+  int chain;            /* this many FOLLOWING table entries add their G^T X (same N1, K2) into this job's outputs, in
+                           table order, before the one store: a parameter used several times in a backward pass.  Only
+                           G, X, ldg, ldx, M, K2, g_seg_* of such an entry are read; blk_job never points at one */
   long g_seg_stride;
 } fod_tn_job;
 int fod_gemm_tn_multi(const fod_tn_job* jobs, const int* blk_job, const int* blk_tile, int nblocks, fod_stream_t stream);

@@ -1,12 +1,13 @@
 set -e
-mkdir -p gpurun_out/r02w2
-timeout -k 10 300 python -m pytest tests/test_graph_gpu.py -x -q -k "spare_job_tables or track_eager" > gpurun_out/r02w2/t0.log 2>&1 || { tail -30 gpurun_out/r02w2/t0.log; exit 1; }
-tail -2 gpurun_out/r02w2/t0.log
-timeout -k 10 300 python bench.py --gpus 1 --force-ddp --no-cpu-baseline --no-extras > gpurun_out/r02w2/ddp1_graph.json 2> gpurun_out/r02w2/ddp1_graph.err || { tail -20 gpurun_out/r02w2/ddp1_graph.err; exit 1; }
-timeout -k 10 300 python bench.py --gpus 1 --force-ddp --no-graph --no-cpu-baseline --no-extras > gpurun_out/r02w2/ddp1_eager.json 2> gpurun_out/r02w2/ddp1_eager.err || { tail -20 gpurun_out/r02w2/ddp1_eager.err; exit 1; }
-timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --rehearse --steps 4 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/r02w2/rehearse2.json 2> gpurun_out/r02w2/rehearse2.err || { tail -20 gpurun_out/r02w2/rehearse2.err; exit 1; }
+mkdir -p gpurun_out/r02v
+timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -x -q -k "tn_multi or wgrad_queue or short_reduction or group_linear" > gpurun_out/r02v/t0.log 2>&1 || { tail -30 gpurun_out/r02v/t0.log; exit 1; }
+tail -2 gpurun_out/r02v/t0.log
+timeout -k 10 200 python bench.py --no-cpu-baseline --no-extras > gpurun_out/r02v/bench_a.json 2> gpurun_out/r02v/bench_a.err || { tail -20 gpurun_out/r02v/bench_a.err; exit 1; }
+timeout -k 10 200 python bench.py --no-cpu-baseline --no-extras > gpurun_out/r02v/bench_b.json 2> gpurun_out/r02v/bench_b.err
 python - <<'P'
 import json
-for n in ("ddp1_graph","ddp1_eager","rehearse2"):
-    d=json.loads(open(f"gpurun_out/r02w2/{n}.json").read().strip().splitlines()[-1]); print(n, d["value"], d["ms_per_step"], json.dumps(d.get("ddp"))[:300])
+for n in ("a","b"):
+    d=json.load(open(f"gpurun_out/r02v/bench_{n}.json")); print(n, d["value"], d["ms_per_step"], d.get("fod_launches_per_step"))
 P
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r02v/tests.log 2>&1 || { tail -40 gpurun_out/r02v/tests.log; exit 1; }
+tail -3 gpurun_out/r02v/tests.log
