@@ -63,7 +63,7 @@ FOD_DEVINL void tn_frag(Frag<float>& f, const unsigned char* tile, int ks, int c
 
 // RING = depth of the register staging ring: RING-1 steps of global loads are in flight while one is computed.
 template <typename T, int MODE, int RING>
-FOD_DEVINL void gemm_tn_body(const TnParams& p) {
+FOD_DEVINL void gemm_tn_body(const TnParams& p, const int bid_x, const int bid_y, const int bid_z) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int PITCH = TnCfg<T>::PITCH;
   constexpr int CHR = 128 / VEC;          // 16-byte chunks per tile row
@@ -79,7 +79,7 @@ FOD_DEVINL void gemm_tn_body(const TnParams& p) {
   if (p.xcd_order) {
     // all (i, j) tiles of one M-split re-read the same G / X rows: give a split's tiles to ONE XCD (block ids
     // congruent mod 8 share an L2) so its rows cross the fabric once instead of once per XCD
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int xcd = bid_x & 7, slot = bid_x >> 3;
     const int ntile = p.ti * p.tj;
     const int tile = slot % ntile;
     split = (slot / ntile) * 8 + xcd;
@@ -87,7 +87,7 @@ FOD_DEVINL void gemm_tn_body(const TnParams& p) {
     bx = tile % p.tj;
     by = tile / p.tj;
   } else {
-    bx = blockIdx.x; by = blockIdx.y; split = blockIdx.z;
+    bx = bid_x; by = bid_y; split = bid_z;
   }
   const int j0 = bx * 128, i0 = by * 128;
   const int mb = split * p.m_per_split;
@@ -368,11 +368,38 @@ FOD_DEVINL void gemm_tn_body(const TnParams& p) {
 // RING = 3: deeper rings (4, 6) measured within 1 % on every shape of the workload and cost an occupancy step.
 template <typename T>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
-  gemm_tn_body<T, MODE_DENSE, 3>(p);
+  gemm_tn_body<T, MODE_DENSE, 3>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// MANY long bf16 weight gradients of nn.Linear layers in ONE launch (fod_gemm_tn_multi_long): block b works on block
+// blk_local[b] = (split * ti + tile_i) * tj + tile_j of job blk_job[b] (< 0: nothing).  One encoder layer's weight
+// gradients are 4 .. 32 tiles of 128 x 128 each: launched one by one they leave most of the chip idle however M is
+// split (256 x 256 outputs: 133 TFLOP/s); ~40 of them per step, none on the backward pass's critical path.
+__global__ __launch_bounds__(256, 2) void gemm_tn_multi_long_kernel(const fod_tn_job* __restrict__ jobs,
+                                                                    const int* __restrict__ blk_job,
+                                                                    const int* __restrict__ blk_local) {
+  const int jb = blk_job[blockIdx.x];
+  if (jb < 0) return;
+  const fod_tn_job& j = jobs[jb];
+  TnParams p{};
+  p.G = j.G; p.X = j.X; p.dW = j.dW;
+  p.ldg = j.ldg; p.ldx = j.ldx; p.ldw = j.ldw;
+  p.M = j.M; p.N1 = j.N1; p.K2 = j.K2;
+  p.colsum = j.colsum;
+  p.accumulate = j.accumulate;
+  p.g_bytes = (unsigned)(((long)(j.M - 1) * j.ldg + j.N1) * 2);
+  p.x_bytes = (unsigned)(((long)(j.M - 1) * j.ldx + j.K2) * 2);
+  p.tj = (j.K2 + 127) >> 7;
+  p.ti = (j.N1 + 127) >> 7;
+  p.nsplit = j.nsplit;
+  p.m_per_split = j.m_per_split;
+  const int local = blk_local[blockIdx.x];
+  const int tile = local % (p.ti * p.tj);
+  gemm_tn_body<__bf16, MODE_DENSE, 3>(p, tile % p.tj, tile / p.tj, local / (p.ti * p.tj));
 }
 template <typename T>
 __global__ __launch_bounds__(256, 2) void conv2d_wgrad_kernel(const TnParams p) {
-  gemm_tn_body<T, MODE_CONV, 3>(p);
+  gemm_tn_body<T, MODE_CONV, 3>(p, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 template <typename T>
@@ -708,6 +735,24 @@ extern "C" int fod_gemm_tn_multi(const fod_tn_job* jobs, const int* blk_job, con
   FOD_REQUIRE(jobs && blk_job && blk_tile && nblocks > 0, "gemm_tn_multi: bad args");
   hipLaunchKernelGGL(gemm_tn_multi_kernel, dim3(nblocks), dim3(256), 0, stream, jobs, blk_job, blk_tile);
   FOD_LAUNCH_CHECK();
+  return FOD_OK;
+}
+
+extern "C" int fod_gemm_tn_multi_long(const fod_tn_job* jobs, const int* blk_job, const int* blk_local, int nblocks,
+                                      hipStream_t stream) {
+  FOD_REQUIRE(jobs && blk_job && blk_local && nblocks > 0, "gemm_tn_multi_long: bad args");
+  hipLaunchKernelGGL(gemm_tn_multi_long_kernel, dim3(nblocks), dim3(256), 0, stream, jobs, blk_job, blk_local);
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
+}
+
+extern "C" int fod_tn_plan_long(int M, int rows_hint, int* m_per_split, int* nsplit) {
+  FOD_REQUIRE(M > 0 && m_per_split && nsplit, "tn_plan_long: bad args");
+  if (rows_hint < MSTEP) rows_hint = MSTEP;
+  int s = (M + rows_hint / 2) / rows_hint;
+  if (s < 1) s = 1;
+  *m_per_split = ((M + s - 1) / s + MSTEP - 1) / MSTEP * MSTEP;
+  *nsplit = ceil_div(M, *m_per_split);
   return FOD_OK;
 }
 

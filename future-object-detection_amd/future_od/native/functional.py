@@ -245,6 +245,12 @@ class _WgradQueue:
     def __init__(self):
         import os
         self.enabled = os.environ.get("FOD_WGRAD_QUEUE", "1") != "0" and os.environ.get("FOD_TN_SMALL", "1") != "0"
+        # the LONG weight gradients (nn.Linear layers applied to more than 512 rows: the encoder, the memory side of
+        # the decoder) wait too and share one fod_gemm_tn_multi_long launch; rows per M-split of that launch
+        self.long_enabled = os.environ.get("FOD_WGRAD_QUEUE_LONG", "1") != "0"
+        self.long_rows = int(os.environ.get("FOD_WGRAD_LONG_ROWS", "2048"))
+        self.long_jobs = []
+        self._plans = {}
         self.jobs = []
         self.members = {}            # index into jobs -> further (G, X, M) contributions to that job's outputs
         self.keep = []
@@ -291,11 +297,24 @@ class _WgradQueue:
             return False
         return db is None or db.is_contiguous()
 
+    @staticmethod
+    def _fits_long(g, x, dw, db, M, N1, K2):
+        if g.dtype != torch.bfloat16 or x.dtype != torch.bfloat16 or not g.is_cuda:
+            return False
+        if not (g.is_contiguous() and x.is_contiguous() and dw.is_contiguous() and (db is None or db.is_contiguous())):
+            return False
+        if N1 % 8 or K2 % 8 or (g.data_ptr() | x.data_ptr() | dw.data_ptr()) % 16:
+            return False
+        return 2 * M * max(N1, K2) < 0xFFFFFF00 and 4 * N1 * K2 < 0x7FFFFF00
+
     def tn(self, ok, g, x, dw, db, owner=None):
         """dw [N1, K2] = g [M, N1]^T x [M, K2], db [N1] = column sums of g (dw, db all-zero f32).  `owner`: the weight
         parameter, if further uses of it in this pass may add to this job (`chain`)."""
         N1, K2 = g.shape[-1], x.shape[-1]
         M = g.numel() // N1
+        if ok and M > 512 and self.long_enabled and self._fits_long(g, x, dw, db, M, N1, K2):
+            return self._push((g.data_ptr(), x.data_ptr(), dw.data_ptr(), 0 if db is None else db.data_ptr(), N1, K2, K2,
+                               M, N1, K2, 0, 0, 0), g, x, dw, db, long=True)
         if not (ok and g.is_contiguous() and x.is_contiguous() and self._fits(g, x, dw, db, M, N1, K2, N1, K2)):
             return ops.gemm_tn_acc(g, x, dw, colsum=db, zeroed=True)
         self._push((g.data_ptr(), x.data_ptr(), dw.data_ptr(), 0 if db is None else db.data_ptr(), N1, K2, K2,
@@ -333,12 +352,12 @@ class _WgradQueue:
         self._push((g.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), D, K, K, rows, P * D, K, 0, D, rows * D),
                    g, x, dw, db)
 
-    def _push(self, job, g, x, dw, db):
+    def _push(self, job, g, x, dw, db, long=False):
         task = torch._C._current_graph_task_id()
-        if task != self.task and self.jobs:          # left behind by a backward pass that raised: not this pass's work
-            self.jobs, self.keep, self.members = [], [], {}
+        if task != self.task and (self.jobs or self.long_jobs):    # left behind by a backward pass that raised
+            self.jobs, self.long_jobs, self.keep, self.members = [], [], [], {}
             self.serial += 1
-        self.jobs.append(job)
+        (self.long_jobs if long else self.jobs).append(job)
         # detach(): a second handle on the same memory -- the gradient tensor itself must stay singly referenced, or
         # autograd copies it instead of adopting it as .grad
         self.keep.append((g, x, dw.detach(), None if db is None else db.detach()))
@@ -369,7 +388,7 @@ class _WgradQueue:
             bj.extend([slot] * tiles)
             bt.extend(range(tiles))
             for e, n in [(j, len(more))] + [(m, 0) for m in more]:
-                arr[slot] = L.TnJob(*e[:12], n, e[12])
+                arr[slot] = L.TnJob(*e[:12], n, e[12], 0, 0)
                 slot += 1
         head = np.frombuffer(bytes(arr), dtype=np.uint8)
         pad = (-head.size) % 16
@@ -387,21 +406,62 @@ class _WgradQueue:
         if self.enabled and torch.device(device).type == "cuda":
             self._top_up(device)
 
+    def _pack_long(self, jobs):
+        """Table + block maps of a fod_gemm_tn_multi_long launch.  The blocks of one M-split of a job re-read the same
+        rows of G and X: they go to ONE XCD (block ids congruent mod 8 share an L2), splits dealt round-robin; idle
+        blocks (job -1) pad the shorter XCD queues."""
+        import ctypes as C
+        import numpy as np
+        arr = (L.TnJob * len(jobs))()
+        queues = [[] for _ in range(8)]
+        turn = 0
+        for slot, i in enumerate(sorted(range(len(jobs)), key=lambda i: -jobs[i][7] * jobs[i][8] * jobs[i][9])):
+            j = jobs[i]
+            plan = self._plans.get(j[7])
+            if plan is None:
+                mps, ns = C.c_int(), C.c_int()
+                L.call("fod_tn_plan_long", j[7], self.long_rows, C.addressof(mps), C.addressof(ns))
+                plan = self._plans[j[7]] = (mps.value, ns.value)
+            arr[slot] = L.TnJob(*j[:12], 0, j[12], plan[0], plan[1])
+            ntile = ((j[8] + 127) // 128) * ((j[9] + 127) // 128)
+            for sp in range(plan[1]):
+                queues[turn % 8].extend((slot, sp * ntile + t) for t in range(ntile))
+                turn += 1
+        depth = max(len(q) for q in queues)
+        bj = np.full((depth, 8), -1, dtype=np.int32)
+        bl = np.zeros((depth, 8), dtype=np.int32)
+        for xcd, q in enumerate(queues):
+            if q:
+                a = np.asarray(q, dtype=np.int32)
+                bj[:len(q), xcd] = a[:, 0]
+                bl[:len(q), xcd] = a[:, 1]
+        head = np.frombuffer(bytes(arr), dtype=np.uint8)
+        pad = (-head.size) % 16
+        raw = np.concatenate([head, np.zeros(pad, np.uint8), bj.reshape(-1).view(np.uint8), bl.reshape(-1).view(np.uint8)])
+        return raw, head.size + pad, depth * 8
+
     def flush(self):
-        jobs = self.jobs
-        if not jobs:
+        jobs, long_jobs = self.jobs, self.long_jobs
+        if not jobs and not long_jobs:
             return
         keep, members = self.keep, self.members
-        self.jobs, self.keep, self.members = [], [], {}
+        self.jobs, self.long_jobs, self.keep, self.members = [], [], [], {}
         self.serial += 1
         dev = keep[0][0].device
-        sig = (tuple(jobs), tuple((i, tuple(m)) for i, m in sorted(members.items()))) if members else tuple(jobs)
+        if jobs:
+            self._launch("fod_gemm_tn_multi", jobs, members, dev, keep)
+        if long_jobs:
+            self._launch("fod_gemm_tn_multi_long", long_jobs, {}, dev, keep)
+
+    def _launch(self, entry, jobs, members, dev, keep):
+        long = entry == "fod_gemm_tn_multi_long"
+        sig = (entry, tuple(jobs), tuple((i, tuple(m)) for i, m in sorted(members.items())))
         tab = self._tables.get(sig)
         if tab is None:
-            raw, off, nblocks = self._pack(jobs, members)
+            raw, off, nblocks = self._pack_long(jobs) if long else self._pack(jobs, members)
             if torch.cuda.is_current_stream_capturing():
                 if not self._spares or raw.size > self.SPARE_BYTES or self._spares[-1][1].device != dev:
-                    return self._one_by_one(jobs, members)
+                    return self._one_by_one(jobs, members, long)
                 pin, table = self._spares.pop()
                 self._baked.append((pin, table, keep))
                 pin[:raw.size].copy_(torch.from_numpy(raw))
@@ -416,13 +476,18 @@ class _WgradQueue:
                 self._top_up(dev)
         table, off, nblocks = tab
         base = table.data_ptr()
-        L.call("fod_gemm_tn_multi", base, base + off, base + off + 4 * nblocks, nblocks, ops.stream(),
+        L.call(entry, base, base + off, base + off + 4 * nblocks, nblocks, ops.stream(),
                work=sum(2.0 * j[7] * j[8] * j[9] for j in jobs)
                + sum(2.0 * m[7] * m[8] * m[9] for ms in members.values() for m in ms), tag="fod_gemm_tn_acc")
         self.launches += 1
         self.carried += len(jobs) + sum(len(m) for m in members.values())
 
-    def _one_by_one(self, jobs, members):
+    def _one_by_one(self, jobs, members, long=False):
+        if long:
+            for G, X, dW, cs, ldg, ldx, ldw, M, N1, K2, acc, _sc, _ss in jobs:
+                L.call("fod_gemm_tn_acc", L.BF16, G, ldg, X, ldx, dW, ldw, M, N1, K2, 0, cs, 1, ops.stream(),
+                       work=2.0 * M * N1 * K2)
+            return
         for i, (G, X, dW, cs, ldg, ldx, ldw, M, N1, K2, acc, seg_cols, seg_stride) in enumerate(jobs):
             L.call("fod_gemm_tn_grouped", L.BF16, G, ldg, seg_cols, seg_stride, X, ldx, dW, ldw, M, N1, K2, cs,
                    acc, ops.stream(), work=2.0 * M * N1 * K2, tag="fod_gemm_tn_acc")

@@ -56,7 +56,8 @@ class TnJob(C.Structure):          # fod_tn_job (include/fod.h)
     _fields_ = [("G", C.c_void_p), ("X", C.c_void_p), ("dW", C.c_void_p), ("colsum", C.c_void_p),
                 ("ldg", C.c_long), ("ldx", C.c_long), ("ldw", C.c_long),
                 ("M", C.c_int), ("N1", C.c_int), ("K2", C.c_int), ("accumulate", C.c_int),
-                ("g_seg_cols", C.c_int), ("chain", C.c_int), ("g_seg_stride", C.c_long)]
+                ("g_seg_cols", C.c_int), ("chain", C.c_int), ("g_seg_stride", C.c_long),
+                ("m_per_split", C.c_int), ("nsplit", C.c_int)]
 
 
 _i, _l, _f, _p = C.c_int, C.c_long, C.c_float, C.c_void_p
@@ -70,6 +71,8 @@ SIGNATURES = {
     "fod_gemm_nt_grouped": [_i, _p, _l, _i, _l, _p, _l, _p, _l, _i, _l, _i, _i, _i, _EP, _p],
     "fod_gemm_tn_grouped": [_i, _p, _l, _i, _l, _p, _l, _p, _l, _i, _i, _i, _p, _i, _p],
     "fod_gemm_tn_multi": [_p, _p, _p, _i, _p],
+    "fod_gemm_tn_multi_long": [_p, _p, _p, _i, _p],
+    "fod_tn_plan_long": [_i, _i, _p, _p],
     "fod_colsum_acc": [_i, _p, _l, _i, _i, _i, _p, _p],
     "fod_conv2d_fwd": [_i, _p, _p, _p, _CG, _EP, _p],
     "fod_conv2d_dgrad": [_i, _p, _p, _p, _CG, _EP, _p],

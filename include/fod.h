@@ -108,8 +108,18 @@ typedef struct fod_tn_job {
                            table order, before the one store: a parameter used several times in a backward pass.  Only
                            G, X, ldg, ldx, M, K2, g_seg_* of such an entry are read; blk_job never points at one */
   long g_seg_stride;
+  int m_per_split, nsplit;   /* fod_gemm_tn_multi_long only: rows per M-split (from fod_tn_plan_long) and their number */
 } fod_tn_job;
 int fod_gemm_tn_multi(const fod_tn_job* jobs, const int* blk_job, const int* blk_tile, int nblocks, fod_stream_t stream);
+/* The same for LONG reductions (bf16 nn.Linear weight gradients with M > 512; N1, K2, ldg, ldx multiples of 8, 16-byte
+ * aligned operands < 4 GiB, no G segments, no chains): 128 x 128 tiles, M split into jobs[j].nsplit pieces of
+ * jobs[j].m_per_split rows (fod_tn_plan_long: pieces of about rows_hint rows, a multiple of the kernel's step), partial
+ * tiles added with f32 atomics when nsplit > 1 -- dW / colsum must then be zero (or hold the value to add to) on entry.
+ * Block b computes block blk_local[b] = (split * ti + tile_i) * tj + tile_j (ti, tj = ceil(N1 / 128), ceil(K2 / 128)) of
+ * jobs[blk_job[b]]; blk_job[b] < 0 marks an idle block (padding that keeps a job's splits on one L2). */
+int fod_gemm_tn_multi_long(const fod_tn_job* jobs, const int* blk_job, const int* blk_local, int nblocks,
+                           fod_stream_t stream);
+int fod_tn_plan_long(int M, int rows_hint, int* m_per_split, int* nsplit);
 
 int fod_colsum_acc(int dtype, const void* G, long ldg, int M, int N, int group_rows, float* out,
                    fod_stream_t stream);

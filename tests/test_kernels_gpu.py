@@ -760,6 +760,43 @@ def test_gemm_tn_multi_matches_single_launches():
         assert db is None or torch.equal(db, db_ref), c
 
 
+def test_gemm_tn_multi_long_matches_single_launches():
+    """fod_gemm_tn_multi_long (the long weight gradients of a backward pass in one launch, M split per job, splits dealt
+    to XCDs, idle padding blocks) against one fod_gemm_tn_acc launch per job and against fp32 matmuls."""
+    from future_od.native import functional as Fn
+    dtype = torch.bfloat16
+    cases = [(14500, 256, 256), (2900, 2048, 256), (4350, 256, 2048), (3000, 264, 72), (513, 8, 8), (7250, 512, 256)]
+    q = Fn._WgradQueue()
+    q.enabled = q.hold = q.long_enabled = True
+    outs = []
+    for i, (M, N1, K2) in enumerate(cases):
+        g, x = rnd((M, N1), dtype, 70 + i).to(DEV), rnd((M, K2), dtype, 80 + i).to(DEV)
+        want_db = i % 2 == 0
+        dw_ref = torch.zeros(N1, K2, device=DEV)
+        db_ref = torch.zeros(N1, device=DEV) if want_db else None
+        ops.gemm_tn_acc(g, x, dw_ref, colsum=db_ref, zeroed=True)
+        dw = torch.zeros(N1, K2, device=DEV)
+        db = torch.zeros(N1, device=DEV) if want_db else None
+        q.tn(True, g, x, dw, db)
+        outs.append((g, x, dw, db, dw_ref, db_ref))
+    assert len(q.long_jobs) == len(cases) and not q.jobs and q.launches == 0
+    q.flush()
+    assert q.launches == 1 and q.carried == len(cases) and not q.long_jobs
+    for (M, N1, K2), (g, x, dw, db, dw_ref, db_ref) in zip(cases, outs):
+        check(dw, g.float().t() @ x.float(), dtype, math.sqrt(M), f"tn multi long {(M, N1, K2)}")
+        check(dw, dw_ref, torch.float32, math.sqrt(M), f"tn multi long vs single {(M, N1, K2)}")   # summation order only
+        if db is not None:
+            check(db, g.float().sum(0), torch.float32, math.sqrt(M), "tn multi long bias")
+            check(db, db_ref, torch.float32, math.sqrt(M), "tn multi long bias vs single")
+    # the same jobs again through the cached table, on top of the previous results (atomics accumulate): twice the value
+    for g, x, dw, db, _, _ in outs:
+        q.tn(True, g, x, dw, db)
+    q.flush()
+    for (M, N1, K2), (g, x, dw, db, dw_ref, db_ref) in zip(cases, outs):
+        single = q._plans[M][1] == 1
+        check(dw, dw_ref if single else 2 * dw_ref, torch.float32, 2 * math.sqrt(M), f"second launch {(M, N1, K2)}")
+
+
 def test_wgrad_queue_in_autograd():
     """Deferred weight gradients through autograd: a layer used ONCE per pass is queued (its .grad is the buffer the
     multi launch fills), the second use of a layer used TWICE joins the first use's job (one store of the sum, no gradient
