@@ -463,7 +463,7 @@ class _WgradQueue:
                 if not self._spares or raw.size > self.SPARE_BYTES or self._spares[-1][1].device != dev:
                     return self._one_by_one(jobs, members, long)
                 pin, table = self._spares.pop()
-                self._baked.append((pin, table, keep))
+                self._baked.append((pin, table))         # the graph reads both at every replay: never reused
                 pin[:raw.size].copy_(torch.from_numpy(raw))
                 table[:raw.size].copy_(pin[:raw.size], non_blocking=True)
                 tab = (table, off, nblocks)
