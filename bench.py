@@ -247,6 +247,12 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         summ, nprof = None, 2
+        if profile and use_graph:
+            # the profiling leg launches eagerly but must time the kernels the replayed step is made of: the weight
+            # gradients that a captured step queues and launches together are queued here too (an eager step does not
+            # by default: it is bound by the launching thread, and the bookkeeping costs it time)
+            from future_od.native import functional as Fn
+            Fn.WGRADS.eager = True
         if profile and rank != 0:
             for _ in range(nprof + 1):               # the steps hold collectives: every rank runs them, rank 0 measures
                 eager_step()
@@ -258,6 +264,8 @@ def main():
                 eager_step()
             L.PROFILER.stop()
             summ = L.PROFILER.summary()
+        if profile and use_graph:
+            Fn.WGRADS.eager = False
         final = float(loss.detach())
         if distributed and profile:
             # what the first real multi-GPU run needs to be diagnosable: who took part, how many gradient bytes were

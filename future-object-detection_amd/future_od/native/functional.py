@@ -231,7 +231,8 @@ class _WgradQueue:
     node returns no gradient of its own, so there is neither a flush nor a gradient-sum kernel, and the parameter's
     gradient stays inside the arena (one flat all-reduce in data-parallel runs).
 
-    Not deferred (the site launches at once, as without the queue): parameters that already hold a .grad (autograd adds
+    Not deferred (the site launches at once, as without the queue): eagerly launched steps (see `eager` below),
+    parameters that already hold a .grad (autograd adds
     the returned tensor to it on arrival), parameters with tensor hooks, operands outside the short kernel's domain,
     FOD_WGRAD_QUEUE=0, torch's own DistributedDataParallel reducer (it copies gradients into buckets on arrival;
     parallel.FodDataParallel switches the queue off for it).
@@ -247,10 +248,16 @@ class _WgradQueue:
         self.enabled = os.environ.get("FOD_WGRAD_QUEUE", "1") != "0" and os.environ.get("FOD_TN_SMALL", "1") != "0"
         # the LONG weight gradients (nn.Linear layers applied to more than 512 rows: the encoder, the memory side of
         # the decoder) wait too and share one fod_gemm_tn_multi_long launch; rows per M-split of that launch
+        # Only while a stream capture records the step (future_od/graph.py -- the product's launch mode): an eagerly
+        # launched step is bound by the launching thread, not by the GPU, and the queue's bookkeeping (~30 us per site)
+        # made it 5 ms slower (28.7 -> 34.0 ms).  `eager` = True (FOD_WGRAD_QUEUE_EAGER=1; tests, bench.py's profiling
+        # leg) queues there too.
+        self.eager = os.environ.get("FOD_WGRAD_QUEUE_EAGER", "0") == "1"
         self.long_enabled = os.environ.get("FOD_WGRAD_QUEUE_LONG", "1") != "0"
         self.long_rows = int(os.environ.get("FOD_WGRAD_LONG_ROWS", "2048"))
         self.long_jobs = []
         self._plans = {}
+        self._maps = {}
         self.jobs = []
         self.members = {}            # index into jobs -> further (G, X, M) contributions to that job's outputs
         self.keep = []
@@ -267,7 +274,7 @@ class _WgradQueue:
     # -- sites
     def site(self, params):
         """A backward node about to produce the gradients of `params`: True if its short weight gradients may wait."""
-        if not self.enabled:
+        if not self.enabled or not (self.eager or torch.cuda.is_current_stream_capturing()):
             return False
         ok = True
         for p in params:
@@ -375,26 +382,90 @@ class _WgradQueue:
         self.flush()
 
     # -- launch
+    # A table = the job array (pointers: rebuilt per flush, one numpy call) + the block maps, which depend on the jobs'
+    # SHAPES only and are cached per shape list (building them is milliseconds of Python; eagerly launched steps, whose
+    # activation addresses differ from step to step, would pay that every time).
+    _JOB_DTYPE = None
+
+    @classmethod
+    def _job_array(cls, rows):
+        import ctypes as C
+        import numpy as np
+        if cls._JOB_DTYPE is None:
+            cls._JOB_DTYPE = np.dtype([(n, np.uint64 if t is C.c_void_p else (np.int64 if t is C.c_long else np.int32))
+                                       for n, t in L.TnJob._fields_])
+            assert cls._JOB_DTYPE.itemsize == C.sizeof(L.TnJob)
+        head = np.array(rows, dtype=cls._JOB_DTYPE).view(np.uint8)
+        pad = (-head.size) % 16
+        return head if pad == 0 else np.concatenate([head, np.zeros(pad, np.uint8)])
+
     def _pack(self, jobs, members):
         import numpy as np
-        arr = (L.TnJob * (len(jobs) + sum(len(m) for m in members.values())))()
-        bj, bt = [], []
-        rows = lambda i: jobs[i][7] + sum(m[7] for m in members.get(i, ()))
-        slot = 0
-        for i in sorted(range(len(jobs)), key=lambda i: -rows(i)):           # long reductions first
-            j = jobs[i]
+        key = tuple((j[7], j[8], j[9], tuple(m[7] for m in members.get(i, ()))) for i, j in enumerate(jobs))
+        cached = self._maps.get(key)
+        if cached is None:
+            rows = lambda i: jobs[i][7] + sum(m[7] for m in members.get(i, ()))
+            order = sorted(range(len(jobs)), key=lambda i: -rows(i))             # long reductions first
+            bj, bt, slot = [], [], 0
+            for i in order:
+                j = jobs[i]
+                tiles = ((j[8] + 63) // 64) * ((j[9] + 63) // 64)
+                bj.extend([slot] * tiles)
+                bt.extend(range(tiles))
+                slot += 1 + len(members.get(i, ()))
+            if len(self._maps) > 64:
+                self._maps.clear()
+            cached = self._maps[key] = (order, np.asarray(bj + bt, dtype=np.int32).view(np.uint8), len(bj))
+        order, maps, nblocks = cached
+        table = []
+        for i in order:
             more = members.get(i, ())
-            tiles = ((j[8] + 63) // 64) * ((j[9] + 63) // 64)
-            bj.extend([slot] * tiles)
-            bt.extend(range(tiles))
-            for e, n in [(j, len(more))] + [(m, 0) for m in more]:
-                arr[slot] = L.TnJob(*e[:12], n, e[12], 0, 0)
-                slot += 1
-        head = np.frombuffer(bytes(arr), dtype=np.uint8)
-        pad = (-head.size) % 16
-        maps = np.asarray(bj + bt, dtype=np.int32).view(np.uint8)
-        raw = np.concatenate([head, np.zeros(pad, np.uint8), maps])
-        return raw, head.size + pad, len(bj)
+            for e, n in [(jobs[i], len(more))] + [(m, 0) for m in more]:
+                table.append(e[:12] + (n, e[12], 0, 0))
+        head = self._job_array(table)
+        return np.concatenate([head, maps]), head.size, nblocks
+
+    def _pack_long(self, jobs):
+        """Table + block maps of a fod_gemm_tn_multi_long launch.  The blocks of one M-split of a job re-read the same
+        rows of G and X: they go to ONE XCD (block ids congruent mod 8 share an L2), splits dealt round-robin; idle
+        blocks (job -1) pad the shorter XCD queues."""
+        import ctypes as C
+        import numpy as np
+        key = ("long",) + tuple((j[7], j[8], j[9]) for j in jobs)
+        cached = self._maps.get(key)
+        if cached is None:
+            order = sorted(range(len(jobs)), key=lambda i: -jobs[i][7] * jobs[i][8] * jobs[i][9])
+            plans = []
+            queues = [[] for _ in range(8)]
+            turn = 0
+            for slot, i in enumerate(order):
+                j = jobs[i]
+                plan = self._plans.get(j[7])
+                if plan is None:
+                    mps, ns = C.c_int(), C.c_int()
+                    L.call("fod_tn_plan_long", j[7], self.long_rows, C.addressof(mps), C.addressof(ns))
+                    plan = self._plans[j[7]] = (mps.value, ns.value)
+                plans.append(plan)
+                ntile = ((j[8] + 127) // 128) * ((j[9] + 127) // 128)
+                for sp in range(plan[1]):
+                    queues[turn % 8].append((slot, sp * ntile, ntile))
+                    turn += 1
+            depth = max(sum(r[2] for r in q) for q in queues)
+            bj = np.full((depth, 8), -1, dtype=np.int32)
+            bl = np.zeros((depth, 8), dtype=np.int32)
+            for xcd, q in enumerate(queues):
+                at = 0
+                for slot, first, ntile in q:
+                    bj[at:at + ntile, xcd] = slot
+                    bl[at:at + ntile, xcd] = np.arange(first, first + ntile, dtype=np.int32)
+                    at += ntile
+            maps = np.concatenate([bj.reshape(-1), bl.reshape(-1)]).view(np.uint8)
+            if len(self._maps) > 64:
+                self._maps.clear()
+            cached = self._maps[key] = (order, plans, maps, depth * 8)
+        order, plans, maps, nblocks = cached
+        head = self._job_array([jobs[i][:12] + (0, jobs[i][12]) + plans[k] for k, i in enumerate(order)])
+        return np.concatenate([head, maps]), head.size, nblocks
 
     def _top_up(self, device):
         while len(self._spares) < 8:
@@ -405,40 +476,6 @@ class _WgradQueue:
         """Set aside the capture-time tables (call outside a capture; future_od/graph.py does before it captures)."""
         if self.enabled and torch.device(device).type == "cuda":
             self._top_up(device)
-
-    def _pack_long(self, jobs):
-        """Table + block maps of a fod_gemm_tn_multi_long launch.  The blocks of one M-split of a job re-read the same
-        rows of G and X: they go to ONE XCD (block ids congruent mod 8 share an L2), splits dealt round-robin; idle
-        blocks (job -1) pad the shorter XCD queues."""
-        import ctypes as C
-        import numpy as np
-        arr = (L.TnJob * len(jobs))()
-        queues = [[] for _ in range(8)]
-        turn = 0
-        for slot, i in enumerate(sorted(range(len(jobs)), key=lambda i: -jobs[i][7] * jobs[i][8] * jobs[i][9])):
-            j = jobs[i]
-            plan = self._plans.get(j[7])
-            if plan is None:
-                mps, ns = C.c_int(), C.c_int()
-                L.call("fod_tn_plan_long", j[7], self.long_rows, C.addressof(mps), C.addressof(ns))
-                plan = self._plans[j[7]] = (mps.value, ns.value)
-            arr[slot] = L.TnJob(*j[:12], 0, j[12], plan[0], plan[1])
-            ntile = ((j[8] + 127) // 128) * ((j[9] + 127) // 128)
-            for sp in range(plan[1]):
-                queues[turn % 8].extend((slot, sp * ntile + t) for t in range(ntile))
-                turn += 1
-        depth = max(len(q) for q in queues)
-        bj = np.full((depth, 8), -1, dtype=np.int32)
-        bl = np.zeros((depth, 8), dtype=np.int32)
-        for xcd, q in enumerate(queues):
-            if q:
-                a = np.asarray(q, dtype=np.int32)
-                bj[:len(q), xcd] = a[:, 0]
-                bl[:len(q), xcd] = a[:, 1]
-        head = np.frombuffer(bytes(arr), dtype=np.uint8)
-        pad = (-head.size) % 16
-        raw = np.concatenate([head, np.zeros(pad, np.uint8), bj.reshape(-1).view(np.uint8), bl.reshape(-1).view(np.uint8)])
-        return raw, head.size + pad, depth * 8
 
     def flush(self):
         jobs, long_jobs = self.jobs, self.long_jobs

@@ -823,11 +823,11 @@ def test_wgrad_queue_in_autograd():
         return [p.grad.clone() for p in params]
 
     q = Fn.WGRADS
-    was = q.enabled
+    was = q.enabled, q.eager
     try:
         q.enabled = False
         ref1, ref2 = run(1), run(2)
-        q.enabled = True
+        q.enabled = q.eager = True                     # (outside a capture the queue is off unless asked for)
         l0, c0 = q.launches, q.carried
         got1 = run(1)
         # lin_b, the second use of `shared` (first to run in backward) queued; the first use joins that job as a further
@@ -836,7 +836,7 @@ def test_wgrad_queue_in_autograd():
         got2 = run(2)                                  # second pass: every .grad exists -> nothing deferred
         assert (q.launches - l0, q.carried - c0) == (2, 8)
     finally:
-        q.enabled = was
+        q.enabled, q.eager = was
     # the shared layer's two contributions are summed inside one block's f32 accumulators (the second product chain
     # continues the first) instead of by autograd after two stores: equal up to f32 rounding, not bit-equal
     for got, ref in ((got1, ref1), (got2, ref2)):

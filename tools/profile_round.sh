@@ -4,6 +4,9 @@
 tag=${1:-rXX}
 set -e
 cd /tmp && export TMPDIR=/tmp
+# the traced runs launch eagerly (--no-graph: per-kernel attribution needs it) but must consist of the kernels of the
+# replayed step: queue the Linear weight gradients as a captured step does
+export FOD_WGRAD_QUEUE_EAGER=1
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/$tag
 rm -rf $out && mkdir -p $out
