@@ -1,11 +1,10 @@
 set -e
-mkdir -p gpurun_out/r02final
-timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r02final/tests.log 2>&1 || { tail -40 gpurun_out/r02final/tests.log; exit 1; }
-tail -2 gpurun_out/r02final/tests.log
-timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/r02final/smoke.log 2>&1 || { tail -20 gpurun_out/r02final/smoke.log; exit 1; }
-tail -1 gpurun_out/r02final/smoke.log
-timeout -k 10 600 python bench.py > gpurun_out/r02final/bench_line.json 2> gpurun_out/r02final/bench.err || { tail -20 gpurun_out/r02final/bench.err; exit 1; }
+mkdir -p gpurun_out/r02x2
+timeout -k 10 300 python bench.py --gpus 1 --force-ddp --no-cpu-baseline --no-extras > gpurun_out/r02x2/ddp1_graph.json 2> gpurun_out/r02x2/ddp1_graph.err || { tail -20 gpurun_out/r02x2/ddp1_graph.err; exit 1; }
+timeout -k 10 300 python bench.py --gpus 1 --force-ddp --no-graph --no-cpu-baseline --no-extras > gpurun_out/r02x2/ddp1_eager.json 2> gpurun_out/r02x2/ddp1_eager.err || { tail -20 gpurun_out/r02x2/ddp1_eager.err; exit 1; }
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29521 bench.py --gpus 2 --rehearse --steps 4 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/r02x2/rehearse2.json 2> gpurun_out/r02x2/rehearse2.err || { tail -20 gpurun_out/r02x2/rehearse2.err; exit 1; }
 python - <<'P'
 import json
-d=json.load(open("gpurun_out/r02final/bench_line.json")); print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["also"]["headline-k2"]["value"], d["cpu_baseline"]["value"], d["fod_launches_per_step"], d["kernel_breakdown"]["fod_gemm_tn_acc"])
+for n in ("ddp1_graph","ddp1_eager","rehearse2"):
+    d=json.loads(open(f"gpurun_out/r02x2/{n}.json").read().strip().splitlines()[-1]); print(n, d["value"], d["ms_per_step"], d.get("fod_launches_per_step"), json.dumps(d.get("ddp"))[:300])
 P
