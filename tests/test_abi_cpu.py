@@ -156,3 +156,62 @@ def test_average_meter_semantics_and_checkpoint_state():
     assert m2.avg == m.avg and m2.count == 4
     m.new_epoch()
     assert m.history == [3.5] and m.avg == 0 and m.count == 0
+
+
+def test_weight_gradient_job_tables():
+    """Host side of the queued weight gradients (native/functional.py: WGRADS): the job array built with numpy has the
+    layout of the C struct fod_tn_job, every (job, tile) / (job, split, tile) gets exactly one block, chained segments
+    follow their head, the blocks of one M-split of a long job sit in ONE XCD column (block index mod 8), idle blocks
+    are marked -1, and fod_tn_plan_long cuts M into pieces that are multiples of the kernel's step and cover it."""
+    import ctypes as C
+
+    import numpy as np
+
+    from future_od.native import functional as Fn
+    from future_od.native import lib as L
+    q = Fn._WgradQueue()
+    size = C.sizeof(L.TnJob)
+
+    def job(n, M, N1, K2, seg_cols=0, seg_stride=0):
+        return (1000 * n + 16, 2000 * n + 32, 3000 * n + 48, 4000 * n + 64, N1, K2, K2, M, N1, K2, 0, seg_cols, seg_stride)
+
+    jobs = [job(1, 300, 256, 256), job(2, 512, 264, 72), job(3, 7, 8, 2048), job(4, 300, 192, 256, 64, 300 * 64)]
+    members = {0: [job(5, 64, 256, 256), job(6, 300, 256, 256)]}
+    raw, off, nblocks = q._pack(jobs, members)
+    njobs = len(jobs) + 2
+    assert off == (njobs * size + 15) // 16 * 16 and raw.size == off + 8 * nblocks
+    table = (L.TnJob * njobs).from_buffer_copy(raw[:njobs * size].tobytes())
+    bj, bt = raw[off:off + 4 * nblocks].view(np.int32), raw[off + 4 * nblocks:].view(np.int32)
+    heads = sorted(set(bj.tolist()))
+    assert len(heads) == len(jobs)
+    seen = set()
+    for slot in heads:
+        t = table[slot]
+        tiles = ((t.N1 + 63) // 64) * ((t.K2 + 63) // 64)
+        assert sorted(bt[bj == slot].tolist()) == list(range(tiles))
+        seen.add(t.G)
+        for k in range(t.chain):                            # the segments that add into this job follow it in the table
+            assert table[slot + 1 + k].G in (members[0][0][0], members[0][1][0]) and table[slot + 1 + k].chain == 0
+    assert seen == {j[0] for j in jobs}
+    first = table[heads[0]]                                  # longest reduction first: 300 + 64 + 300 rows
+    assert (first.G, first.chain, first.M) == (jobs[0][0], 2, 300)
+    seg = next(table[s] for s in heads if table[s].G == jobs[3][0])
+    assert (seg.g_seg_cols, seg.g_seg_stride, seg.ldg) == (64, 300 * 64, 192)
+
+    long_jobs = [job(10 + i, 14500, n1, k2) for i, (n1, k2) in enumerate([(512, 256), (256, 256), (2048, 256), (256, 2048)])]
+    long_jobs.append(job(20, 513, 8, 8))
+    raw, off, nblocks = q._pack_long(long_jobs)
+    assert nblocks % 8 == 0 and raw.size == off + 8 * nblocks
+    table = (L.TnJob * len(long_jobs)).from_buffer_copy(raw[:len(long_jobs) * size].tobytes())
+    bj = raw[off:off + 4 * nblocks].view(np.int32).reshape(-1, 8)
+    bl = raw[off + 4 * nblocks:].view(np.int32).reshape(-1, 8)
+    for slot, t in enumerate(table):
+        assert t.m_per_split % 32 == 0 and (t.nsplit - 1) * t.m_per_split < t.M <= t.nsplit * t.m_per_split
+        ntile = ((t.N1 + 127) // 128) * ((t.K2 + 127) // 128)
+        mine = bj == slot
+        assert sorted(bl[mine].tolist()) == list(range(ntile * t.nsplit))
+        for sp in range(t.nsplit):                           # one XCD per M-split
+            cols = {c for r, c in zip(*np.nonzero(mine & (bl // ntile == sp)))}
+            assert len(cols) == 1, (slot, sp, cols)
+    assert table[-1].nsplit == 1 and table[0].N1 * table[0].K2 == 2048 * 256      # largest problem first
+    assert int((bj == -1).sum()) == nblocks - sum(((t.N1 + 127) // 128) * ((t.K2 + 127) // 128) * t.nsplit for t in table)
