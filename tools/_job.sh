@@ -1,10 +1,16 @@
-set -e
-mkdir -p gpurun_out/r02x2
-timeout -k 10 300 python bench.py --gpus 1 --force-ddp --no-cpu-baseline --no-extras > gpurun_out/r02x2/ddp1_graph.json 2> gpurun_out/r02x2/ddp1_graph.err || { tail -20 gpurun_out/r02x2/ddp1_graph.err; exit 1; }
-timeout -k 10 300 python bench.py --gpus 1 --force-ddp --no-graph --no-cpu-baseline --no-extras > gpurun_out/r02x2/ddp1_eager.json 2> gpurun_out/r02x2/ddp1_eager.err || { tail -20 gpurun_out/r02x2/ddp1_eager.err; exit 1; }
-timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29521 bench.py --gpus 2 --rehearse --steps 4 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/r02x2/rehearse2.json 2> gpurun_out/r02x2/rehearse2.err || { tail -20 gpurun_out/r02x2/rehearse2.err; exit 1; }
+mkdir -p gpurun_out/r02xw
+for w in cfg2 nusc500-stage1 nusc500-stage2 t8; do
+  timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline --no-extras --no-roofline > gpurun_out/r02xw/bench_$w.json 2> gpurun_out/r02xw/bench_$w.err || tail -5 gpurun_out/r02xw/bench_$w.err
+done
+timeout -k 10 300 python bench.py --train-mode --no-cpu-baseline --no-extras --no-roofline > gpurun_out/r02xw/bench_trainmode_headline.json 2> gpurun_out/r02xw/bench_trainmode_headline.err
+timeout -k 10 300 python bench.py --workload cfg2 --train-mode --no-cpu-baseline --no-extras --no-roofline > gpurun_out/r02xw/bench_trainmode_cfg2.json 2> gpurun_out/r02xw/bench_trainmode_cfg2.err
+timeout -k 10 300 python bench.py --workload nusc500-stage1 --train-mode --no-cpu-baseline --no-extras --no-roofline > gpurun_out/r02xw/bench_trainmode_nusc500-stage1.json 2> gpurun_out/r02xw/bench_trainmode_nusc500-stage1.err
+timeout -k 10 300 python bench.py --forward-only --no-cpu-baseline --no-extras --no-roofline > gpurun_out/r02xw/bench_forward_headline.json 2> gpurun_out/r02xw/bench_forward_headline.err
 python - <<'P'
-import json
-for n in ("ddp1_graph","ddp1_eager","rehearse2"):
-    d=json.loads(open(f"gpurun_out/r02x2/{n}.json").read().strip().splitlines()[-1]); print(n, d["value"], d["ms_per_step"], d.get("fod_launches_per_step"), json.dumps(d.get("ddp"))[:300])
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r02xw/*.json")):
+    try:
+        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split("/")[-1], round(d["value"],1), round(d["ms_per_step"],2))
+    except Exception as e: print(f, "ERR", e)
 P
+true
