@@ -246,6 +246,8 @@ class _WgradQueue:
     def __init__(self):
         import os
         self.enabled = os.environ.get("FOD_WGRAD_QUEUE", "1") != "0" and os.environ.get("FOD_TN_SMALL", "1") != "0"
+        if not hasattr(torch._C, "_current_graph_task_id"):      # (private API: how the end of a backward pass is found)
+            self.enabled = False
         # the LONG weight gradients (nn.Linear layers applied to more than 512 rows: the encoder, the memory side of
         # the decoder) wait too and share one fod_gemm_tn_multi_long launch; rows per M-split of that launch
         # Only while a stream capture records the step (future_od/graph.py -- the product's launch mode): an eagerly
