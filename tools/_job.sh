@@ -1,16 +1,7 @@
-mkdir -p gpurun_out/r02xw
-for w in cfg2 nusc500-stage1 nusc500-stage2 t8; do
-  timeout -k 10 300 python bench.py --workload $w --no-cpu-baseline --no-extras --no-roofline > gpurun_out/r02xw/bench_$w.json 2> gpurun_out/r02xw/bench_$w.err || tail -5 gpurun_out/r02xw/bench_$w.err
-done
-timeout -k 10 300 python bench.py --train-mode --no-cpu-baseline --no-extras --no-roofline > gpurun_out/r02xw/bench_trainmode_headline.json 2> gpurun_out/r02xw/bench_trainmode_headline.err
-timeout -k 10 300 python bench.py --workload cfg2 --train-mode --no-cpu-baseline --no-extras --no-roofline > gpurun_out/r02xw/bench_trainmode_cfg2.json 2> gpurun_out/r02xw/bench_trainmode_cfg2.err
-timeout -k 10 300 python bench.py --workload nusc500-stage1 --train-mode --no-cpu-baseline --no-extras --no-roofline > gpurun_out/r02xw/bench_trainmode_nusc500-stage1.json 2> gpurun_out/r02xw/bench_trainmode_nusc500-stage1.err
-timeout -k 10 300 python bench.py --forward-only --no-cpu-baseline --no-extras --no-roofline > gpurun_out/r02xw/bench_forward_headline.json 2> gpurun_out/r02xw/bench_forward_headline.err
-python - <<'P'
-import json, glob
-for f in sorted(glob.glob("gpurun_out/r02xw/*.json")):
-    try:
-        d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split("/")[-1], round(d["value"],1), round(d["ms_per_step"],2))
-    except Exception as e: print(f, "ERR", e)
-P
-true
+set -e
+mkdir -p gpurun_out/r02final
+timeout -k 10 600 python -m pytest tests/test_graph_gpu.py tests/test_parallel_gpu.py tests/test_train_gpu.py -x -q > gpurun_out/r02final/tests2.log 2>&1 || { tail -30 gpurun_out/r02final/tests2.log; exit 1; }
+tail -1 gpurun_out/r02final/tests2.log
+timeout -k 10 300 python bench.py --no-cpu-baseline --no-extras > gpurun_out/r02final/bench2.json 2> gpurun_out/r02final/bench2.err
+python -c "
+import json; d=json.load(open('gpurun_out/r02final/bench2.json')); print(d['value'], d['ms_per_step'], d['fod_launches_per_step'])"
