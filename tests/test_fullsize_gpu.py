@@ -88,3 +88,49 @@ def test_full_size_dead_frame_skipping_and_matching_properties():
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
     frozen = [n for n, p in model.named_parameters() if ".layer1." in n or n.endswith("body.conv1.weight")]
     assert frozen and all(not dict(model.named_parameters())[n].requires_grad for n in frozen)
+
+
+def test_full_size_queued_weight_gradients_equal_the_direct_ones():
+    """The weight gradients a captured step queues (short ones: fod_gemm_tn_multi, chained for layers used several
+    times; long ones -- the encoder's and the memory side's Linear layers, 14 500 rows -- fod_gemm_tn_multi_long) against
+    the same backward pass with every gradient launched where it is produced, on the full-size model: the queue's wiring
+    (slices of packed in_proj gradients, grouped projections, shared layers) is exercised where the long path applies.
+    Equal up to f32 summation order (the long launch cuts M differently; atomics)."""
+    from future_od.datasets.synthetic import make_batch
+    from future_od.native import functional as Fn
+    model = _build(num_images=5)
+    data = make_batch(2, T, H, W, seed=13, device=DEV)
+    q = Fn.WGRADS
+    was = q.enabled, q.eager
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+
+    def grads(queue):
+        q.enabled, q.eager = queue, queue
+        for p in model.parameters():
+            p.grad = None
+        _, _, loss, _, _ = model(data=data, distributed=False)
+        loss.backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}, float(loss.detach())
+
+    try:
+        ref, l0 = grads(False)
+        l_before, c_before = q.launches, q.carried
+        got, l1 = grads(True)
+        launched, carried = q.launches - l_before, q.carried - c_before
+    finally:
+        q.enabled, q.eager = was
+    assert l0 == l1
+    assert launched <= 4 and carried >= 150, (launched, carried)        # ~130 short + ~40 long jobs in a few launches
+    assert set(got) == set(ref) and len(got) == len(names)
+    worst = ("", 0.0)
+    for n in names:
+        a, b = got[n], ref[n]
+        assert torch.isfinite(a).all(), n
+        scale = float(b.abs().max())
+        err = float((a - b).abs().max())
+        # f32 sums of <= 14 500 bf16 products in another order: a few ulp of the largest partial sums
+        assert err <= 2e-4 * max(scale, 1e-6) + 1e-7, (n, err, scale)
+        if scale > 0 and err / scale > worst[1]:
+            worst = (n, err / scale)
+    print("largest relative difference", worst)
