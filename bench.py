@@ -49,7 +49,8 @@ def build(args, device, distributed, num_images, dtype="bf16"):
     from future_od.models.st_detr import SpatioTemporalDETRArgs
     from runs._model import build_model
     torch.manual_seed(0)
-    a = SimpleNamespace(device=device, distributed=distributed, compute_dtype=dtype, num_images=num_images)
+    a = SimpleNamespace(device=device, distributed=distributed, compute_dtype=dtype, num_images=num_images,
+                        attn_dtype=getattr(args, "attn_dtype", "bf16"))
     detr = SpatioTemporalDETRArgs(num_classes=8, num_queries=128, lr_backbone=1e-4, pretrained_backbone=False)
     return build_model(a, detr), detr
 
@@ -63,6 +64,60 @@ def pmc_traffic_per_launch(entry):
         with open(path) as f:
             return json.load(f)[entry]["bytes_per_launch"]
     except (OSError, KeyError, ValueError):
+        return None
+
+
+# device kernel name (as the tracer reports it, demangled or not) -> C-ABI entry point whose launches it serves
+_KERNEL_ENTRY = [
+    (r"conv2d_fwd_kernel|conv_stem_fwd_kernel|nt_big_kernel(<|ILi)1", "fod_conv2d_fwd"),
+    (r"conv2d_dgrad|nt_big_kernel(<|ILi)[23]", "fod_conv2d_dgrad"),
+    (r"tn_big_kernel|tn_reduce_kernel", "fod_conv2d_wgrad_acc"),
+    (r"gemm_nt_small_kernel|gemm_nt_kernel|gemm_nt_grouped|nt_big_kernel(<|ILi)0", "fod_gemm_nt"),
+    (r"gemm_tn_multi_long", "fod_gemm_tn_multi_long"), (r"gemm_tn_multi", "fod_gemm_tn_multi"),
+    (r"gemm_tn|colsum", "fod_gemm_tn_acc"),
+    (r"attn_quant_fp8", "fod_attn_quant_fp8"), (r"attn_fwd_fp8", "fod_attn_fwd_fp8"),
+    (r"attn_fwd", "fod_attn_fwd"), (r"attn_bwd", "fod_attn_bwd"),
+    (r"ln_fwd", "fod_layernorm_fwd"), (r"ln_bwd", "fod_layernorm_bwd"), (r"eltwise|dropout_kernel", "fod_eltwise"),
+    (r"multi_adamw", "fod_multi_adamw"), (r"multi_sqnorm", "fod_multi_sqnorm_det"), (r"multi_permute3", "fod_multi_permute3"),
+    (r"maxpool", "fod_maxpool3x3s2"), (r"stem_layout", "fod_clip_to_stem_layout"), (r"lap_dev", "fod_lap_solve_batch_dev"),
+    (r"od_map", "fod_od_map"), (r"set_loss", "fod_set_loss"), (r"permute3|nchw", "fod_permute3_cast"),
+]
+
+
+def _entry_of(kernel_name):
+    import re
+    for pat, entry in _KERNEL_ENTRY:
+        if re.search(pat, kernel_name):
+            return entry
+    return "torch/other"
+
+
+def replay_kernel_times(replay, sessions=3):
+    """Device time per C-ABI entry point of ONE replayed step -- the product's launch mode -- from torch.profiler
+    (roctracer / rocprofiler-sdk kernel records: begin / end timestamps taken by the GPU), mean over `sessions`
+    single-replay sessions.  Returns ({entry: {"ms_per_step", "kernels_per_step"}}, kernels per step) or None when the
+    tracer is unavailable on this box."""
+    try:
+        from torch.autograd import DeviceType
+        from torch.profiler import ProfilerActivity, profile
+        agg, nker = {}, 0
+        for _ in range(sessions):
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                replay()
+                torch.cuda.synchronize()
+            for e in prof.events():
+                if e.device_type != DeviceType.CUDA:
+                    continue
+                a = agg.setdefault(_entry_of(e.name), [0, 0.0])
+                a[0] += 1
+                a[1] += e.device_time                      # microseconds
+                nker += 1
+        if nker == 0:
+            return None
+        return ({k: {"ms_per_step": v[1] / sessions / 1e3, "kernels_per_step": v[0] / sessions} for k, v in agg.items()},
+                nker / sessions)
+    except Exception as exc:                               # noqa: BLE001  (no tracer: the eager event leg is the fallback)
+        sys.stderr.write(f"bench: torch.profiler unavailable ({exc!r}); falling back to the eager event leg\n")
         return None
 
 
@@ -142,6 +197,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="N=1 only: launch every kernel from Python (the default replays the step as one hipGraph)")
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--attn-dtype", default="bf16", choices=["bf16", "fp8", "fp8-all"],
+                    help="BASELINE.json configs[4]: fp8 = MX-fp8 (e4m3, block-scaled MFMA) QK^T / PV in the long-sequence "
+                         "attention launches (encoder self-attention), fp8-all = in every attention launch; with "
+                         "--workload t8 this is configs[4], reported beside the bf16 line of the same workload")
     ap.add_argument("--forward-only", action="store_true",
                     help="the evaluation pass (no_grad forward incl. set loss, post-processing, AP bookkeeping) instead of "
                          "the training step; N = 1; for the record, not the headline")
@@ -246,7 +305,7 @@ def main():
         if distributed:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        summ, nprof = None, 2
+        summ, nprof, replay = None, 2, None
         if profile and use_graph:
             # the profiling leg launches eagerly but must time the kernels the replayed step is made of: the weight
             # gradients that a captured step queues and launches together are queued here too (an eager step does not
@@ -257,15 +316,51 @@ def main():
             for _ in range(nprof + 1):               # the steps hold collectives: every rank runs them, rank 0 measures
                 eager_step()
         if profile and rank == 0:
-            # every entry point timed with events on the launching stream for a few more (eagerly launched) steps
+            # (1) FLOPs and call counts per entry point, and -- as a cross-check / fallback -- event-pair times of eagerly
+            # launched steps.  The collector is held off and, where the device can park a stream on a host flag, the
+            # GPU does not start the step before the launching thread has queued all of it: an event pair then brackets
+            # back-to-back device work, not a host stall (tools/probe_roofline_modes.py).
+            import ctypes
+            import gc
+            import threading
             eager_step()
+            torch.cuda.synchronize()
+            gc.collect()
+            gc.disable()
+            flag, parked = ctypes.c_void_p(), False
+            try:
+                if L._ENTRY["fod_stream_wait_supported"](device.index or 0):
+                    L._plain_call("fod_host_flag_create", ctypes.addressof(flag))
+                    parked = True
+            except Exception:                        # noqa: BLE001
+                parked = False
             L.PROFILER.start()
-            for _ in range(nprof):
+            for i in range(nprof):
+                if parked:
+                    L._plain_call("fod_stream_wait_flag", flag.value, i + 1, torch.cuda.current_stream().cuda_stream)
+                    release = threading.Timer(3.0, L._plain_call, ("fod_host_flag_set", flag.value, i + 1))
+                    release.start()                  # a full queue must not leave the stream parked for good
                 eager_step()
+                if parked:
+                    L._plain_call("fod_host_flag_set", flag.value, i + 1)
+                    release.cancel()
+                    torch.cuda.synchronize()
             L.PROFILER.stop()
             summ = L.PROFILER.summary()
+            gc.enable()
+            if parked:
+                L._plain_call("fod_host_flag_destroy", flag.value)
+            eager_leg_info.update({"stream_parked_during_enqueue": parked, "gc_disabled": True})
         if profile and use_graph:
             Fn.WGRADS.eager = False
+        if profile and use_graph:
+            # (2) the times that go into `roofline`: kernel records of the REPLAYED graph (every rank replays -- the
+            # data-parallel step holds collectives -- rank 0 traces)
+            if rank == 0:
+                replay = replay_kernel_times(step)
+            else:
+                for _ in range(3):
+                    step()
         final = float(loss.detach())
         if distributed and profile:
             # what the first real multi-GPU run needs to be diagnosable: who took part, how many gradient bytes were
@@ -305,14 +400,14 @@ def main():
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        return dt, final, summ, nprof
+        return dt, final, summ, nprof, replay
 
     # N = 1: the whole step is one hipGraph.  N > 1: two graphs (forward + backward, clip + AdamW) with the gradient
     # all-reduce launched eagerly between them (future_od/graph.py); --no-graph: every kernel launched from Python with
     # the all-reduces overlapped with the backbone's backward (future_od/parallel.py)
     use_graph = not a.no_graph
-    ddp_info = {}
-    dt, final_loss, summ, nprof = measure(a.num_images, a.dtype, a.steps, a.warmup, not a.no_roofline)
+    ddp_info, eager_leg_info = {}, {}
+    dt, final_loss, summ, nprof, replay = measure(a.num_images, a.dtype, a.steps, a.warmup, not a.no_roofline)
     seqs = BATCH_PER_GPU * world * a.steps
     value = seqs / dt
 
@@ -343,24 +438,50 @@ def main():
         result["model_frac_of_bf16_peak"] = result["model_tflops_per_gpu"] / PEAK_BF16_TFLOPS
 
     if rank == 0 and summ is not None:
-        total = sum(v["seconds"] for v in summ.values())
-        top = sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])
-        name, rec = top[0]
-        achieved = rec["work"] / rec["seconds"] / 1e12
-        result["device_ms_per_step_profiled"] = 1e3 * total / nprof
-        result["fod_launches_per_step"] = sum(v["calls"] for v in summ.values()) / nprof
+        # per entry point and step: algorithmic FLOPs and calls (from the eagerly launched steps) and device time -- from
+        # the replayed graph's kernel records when the tracer is there, else from the event pairs of the eager leg
+        work = {k: v["work"] / nprof for k, v in summ.items()}
+        calls = {k: v["calls"] / nprof for k, v in summ.items()}
+        if replay is not None:
+            times = {k: v["ms_per_step"] for k, v in replay[0].items()}
+            nlaunch = {k: v["kernels_per_step"] for k, v in replay[0].items()}
+            timing = ("kernel records (torch.profiler / roctracer) of the replayed hipGraph, mean of 3 single-replay "
+                      "sessions; FLOPs and call counts from the same step launched eagerly")
+            result["kernels_per_replayed_step"] = replay[1]
+        else:
+            times = {k: 1e3 * v["seconds"] / nprof for k, v in summ.items()}
+            nlaunch = dict(calls)
+            timing = "HIP events around every C-ABI call of eagerly launched steps (collector off, stream parked during enqueue)"
+        total = sum(times.values())
+        step_ms = 1e3 * dt / a.steps
+        result["device_ms_per_step_profiled"] = total
+        result["fod_launches_per_step"] = sum(calls.values())
         # clip + optimizer reported separately (they ARE inside `ms_per_step`, which is therefore
         # conservative): device time of the gradient-norm and AdamW launches
-        opt_s = sum(summ.get(k, {"seconds": 0.0})["seconds"] for k in ("fod_multi_sqnorm_acc", "fod_multi_adamw"))
-        result["clip_adamw_ms_per_step"] = 1e3 * opt_s / nprof
-        result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
-                              "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
-                              "traffic": pmc_traffic_per_launch(name),
-                              "avg_launch_us": 1e6 * rec["seconds"] / rec["calls"], "launches_per_step": rec["calls"] / nprof,
-                              "share_of_device_time": rec["seconds"] / total}
-        result["kernel_breakdown"] = {k: {"ms_per_step": 1e3 * v["seconds"] / nprof, "calls_per_step": v["calls"] / nprof,
-                                          "tflops": (v["work"] / v["seconds"] / 1e12) if v["work"] else None}
-                                      for k, v in top[:12]}
+        result["clip_adamw_ms_per_step"] = sum(times.get(k, 0.0) for k in ("fod_multi_sqnorm_acc", "fod_multi_sqnorm_det", "fod_multi_adamw"))
+        top = sorted(times.items(), key=lambda kv: -kv[1])
+        name, ms = top[0]
+        outliers = {k: {"calls": v["outliers"], "median_us": v["median_us"], "max_us": v["max_us"]}
+                    for k, v in summ.items() if v["outliers"]}
+        eager_total = sum(1e3 * v["seconds"] / nprof for v in summ.values())
+        result["eager_event_leg"] = dict(eager_leg_info, device_ms_per_step=eager_total, calls_over_10x_median=outliers)
+        # a roofline whose kernel time does not fit inside the step it was taken from is not evidence: say so instead
+        if total > 1.1 * step_ms or ms > step_ms or not work.get(name):
+            result["roofline_invalid"] = {"reason": "profiled device time does not fit the timed step" if work.get(name)
+                                          else "dominant entry has no FLOP count", "kernel": name, "kernel_ms_per_step": ms,
+                                          "sum_entries_ms_per_step": total, "ms_per_step": step_ms, "timing": timing}
+        else:
+            achieved = work[name] / (ms * 1e-3) / 1e12
+            result["roofline"] = {"bound": "mfma", "kernel": name, "achieved": achieved, "peak": PEAK_BF16_TFLOPS,
+                                  "unit": "TFLOP/s", "frac": achieved / PEAK_BF16_TFLOPS,
+                                  "traffic": pmc_traffic_per_launch(name),
+                                  "avg_launch_us": 1e3 * ms / max(nlaunch.get(name, 1.0), 1.0),
+                                  "launches_per_step": nlaunch.get(name), "ms_per_step": ms,
+                                  "share_of_device_time": ms / total, "timing": timing,
+                                  "check": {"sum_entries_ms_per_step": total, "ms_per_step": step_ms}}
+        result["kernel_breakdown"] = {k: {"ms_per_step": v, "launches_per_step": nlaunch.get(k), "calls_per_step": calls.get(k),
+                                          "tflops": (work[k] / (v * 1e-3) / 1e12) if work.get(k) and v > 0 else None}
+                                      for k, v in top[:14]}
     # for the record (N = 1, headline only): the reference's AS-SHIPPED model (num_images = 2: 3 of 5 past frames are
     # dead work and skipped) and the fp32-MFMA parity mode, same step definition, driver-timed like the main line
     if world == 1 and a.workload == "headline" and a.num_images == 5 and not a.no_extras and not a.rehearse:
@@ -369,10 +490,25 @@ def main():
             if dtp == a.dtype and k_img == a.num_images:
                 continue
             st = 4
-            edt, eloss, _, _ = measure(k_img, dtp, st, 2, False)
+            edt, eloss, _, _, _ = measure(k_img, dtp, st, 2, False)
             extras[key] = {"value": BATCH_PER_GPU * st / edt, "unit": "frame-sequences/s", "ms_per_step": 1e3 * edt / st,
                            "steps": st, "warmup": 2, "num_images": k_img, "dtype": dtp, "final_loss": eloss}
         result["also"] = extras
+    if a.attn_dtype != "bf16":
+        # BASELINE.json configs[4] asks for fp8 "vs bf16": the same workload with the bf16 attention kernels, same process,
+        # same box, and the attention entries' device time per replayed step for both
+        result["dtype"] = f"{a.dtype} (attention QK^T / PV: MX-fp8 e4m3, {a.attn_dtype})"
+        attn_keys = ("fod_attn_fwd_fp8", "fod_attn_quant_fp8", "fod_attn_fwd", "fod_attn_bwd")
+        mine = {k: v for k, v in (replay[0].items() if replay else []) if k in attn_keys}
+        fp8_mode, a.attn_dtype = a.attn_dtype, "bf16"
+        bdt, bloss, _bs, _bn, breplay = measure(a.num_images, a.dtype, a.steps, a.warmup, not a.no_roofline)
+        a.attn_dtype = fp8_mode
+        theirs = {k: v for k, v in (breplay[0].items() if breplay else []) if k in attn_keys}
+        result["vs_bf16_attention"] = {
+            "bf16": {"value": BATCH_PER_GPU * world * a.steps / bdt, "ms_per_step": 1e3 * bdt / a.steps, "final_loss": bloss,
+                     "attention_entries": theirs},
+            "fp8": {"value": value, "ms_per_step": 1e3 * dt / a.steps, "final_loss": final_loss, "attention_entries": mine},
+            "throughput_ratio_fp8_over_bf16": value / (BATCH_PER_GPU * world * a.steps / bdt)}
     if distributed:
         dist.barrier()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

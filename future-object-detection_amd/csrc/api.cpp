@@ -25,3 +25,13 @@ extern "C" size_t fod_last_error(char* buf, size_t cap) {
 }
 
 extern "C" int fod_abi_version(void) { return FOD_ABI_VERSION; }
+
+extern "C" size_t fod_workspace_bytes(int kind) {
+  switch (kind) {
+    case FOD_WS_NT_SPLIT: return (size_t)FOD_NT_SPLIT_WS_FLOATS * sizeof(float);
+    case FOD_WS_NT_SPLIT_TICKETS: return (size_t)FOD_NT_SPLIT_TICKETS * sizeof(unsigned);
+    case FOD_WS_TN_PARTIALS: return FOD_TN_WS_BYTES;
+    case FOD_WS_ATTN_SPLIT_PER_TILE: return (size_t)FOD_ATTN_SPLIT_WS_FLOATS_PER_TILE * sizeof(float);
+    default: return 0;
+  }
+}

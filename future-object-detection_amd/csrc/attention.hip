@@ -45,6 +45,7 @@ struct AttnParams {
   int ksplit, kchunk;
   float* split_ws;
   unsigned* split_tickets;
+  float dq_mul;                // extra factor on the finished dQ (fod_attn_shape.dq_scale; 1 unless the fp8 path calls)
 };
 
 // the DROP kernels start by folding the device-side base into their copy of the parameters
@@ -870,7 +871,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p_in)
     }
   }
   if (q0 + fr < p.Tq) {
-    const float fin = BIAS ? p.scale : 1.f;
+    const float fin = (BIAS ? p.scale : 1.f) * p.dq_mul;
     T* d1 = reinterpret_cast<T*>(p.dq1) + (long)b * p.q_bs + (long)q * p.q_ts + h * 32;
     store_acc_t<T>(d1, dq[0], fh, fin);
     if (PARTS == 2) {
@@ -1016,10 +1017,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_lds_kernel(const AttnPara
   }
   if (active && q0 + fr < p.Tq) {
     T* d1 = reinterpret_cast<T*>(p.dq1) + (long)b * p.q_bs + (long)q * p.q_ts + h * 32;
-    store_acc_t<T>(d1, dq[0], fh, p.scale);
+    store_acc_t<T>(d1, dq[0], fh, p.scale * p.dq_mul);
     if (PARTS == 2) {
       T* d2 = reinterpret_cast<T*>(p.dq2) + (long)b * p.q_bs + (long)q * p.q_ts + h * 32;
-      store_acc_t<T>(d2, dq[PARTS - 1], fh, p.scale);
+      store_acc_t<T>(d2, dq[PARTS - 1], fh, p.scale * p.dq_mul);
     }
   }
 }
@@ -1529,6 +1530,7 @@ int fill(AttnParams& p, const fod_attn_shape* s) {
   p.v_bs = s->v_batch_stride; p.v_ts = s->v_token_stride;
   p.o_bs = s->o_batch_stride; p.o_ts = s->o_token_stride;
   p.scale = s->scale;
+  p.dq_mul = s->dq_scale != 0.f ? s->dq_scale : 1.f;
   FOD_REQUIRE(s->drop_p >= 0.f && s->drop_p < 1.f, "attention: drop_p=%f out of [0, 1)", s->drop_p);
   p.drop_threshold = (unsigned)((double)s->drop_p * 4294967296.0);
   p.drop_inv_keep = 1.f / (1.f - s->drop_p);

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/fod.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -183,3 +185,25 @@ FOD_DEVINL float wave_max(float v) {
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Raising a kernel's dynamic-LDS limit: once per DEVICE and thread-safe -- autograd's backward thread and the launching
+// thread can both make a kernel's first call.  One static LdsLimitOnce per kernel instantiation.
+struct LdsLimitOnce {
+  std::once_flag once[64];
+  int rc[64];
+};
+static inline int fod_lds_limit_once(LdsLimitOnce& st, const void* kernel, size_t bytes, const char* who) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    fod_set_error("%s: no current device", who);
+    return FOD_ERR_RUNTIME;
+  }
+  std::call_once(st.once[dev], [&] {
+    st.rc[dev] = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : 1;
+  });
+  if (st.rc[dev]) {
+    fod_set_error("%s: cannot raise the dynamic LDS limit to %zu", who, bytes);
+    return FOD_ERR_RUNTIME;
+  }
+  return FOD_OK;
+}

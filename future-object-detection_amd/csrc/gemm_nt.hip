@@ -712,31 +712,6 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const NtParams p) {
   FOD_STAMP(4);
 }
 
-// Scratch of the split-K launches: 64 tiles x 8 splits x 64 x 64 floats (8 MiB) + 64 tickets per device, allocated and
-// zeroed at the first use outside a stream capture (a capture that comes first keeps the unsplit launch); one per
-// device: launches that use it must be ordered on one stream.
-bool small_split_scratch(hipStream_t stream, float** ws, unsigned** tickets) {
-  static float* g_ws[64] = {};
-  static unsigned* g_tk[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-  if (!g_ws[dev]) {
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
-    void *a = nullptr, *b = nullptr;
-    if (hipMalloc(&a, (size_t)64 * 8 * 4096 * sizeof(float)) != hipSuccess || hipMalloc(&b, 64 * sizeof(unsigned)) != hipSuccess ||
-        hipMemset(b, 0, 64 * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-      (void)hipGetLastError();
-      return false;
-    }
-    g_ws[dev] = reinterpret_cast<float*>(a);
-    g_tk[dev] = reinterpret_cast<unsigned*>(b);
-  }
-  *ws = g_ws[dev];
-  *tickets = g_tk[dev];
-  return true;
-}
-
 // The short-launch kernel is used when its 64 x 64 tiles fit the chip in one wave of blocks.
 bool use_small_nt(int dtype, const NtParams& p) {
   const char* env = getenv("FOD_NT_SMALL");
@@ -822,6 +797,8 @@ void fill_epilogue(NtParams& p, const fod_epilogue* e) {
   p.ldmask = e ? e->ld_mask : 0;
   p.relu = e ? e->relu : 0;
   p.c_is_f32 = e ? e->out_f32 : 0;
+  p.split_ws = e ? reinterpret_cast<float*>(e->split_ws) : nullptr;               // caller-owned (fod.h): NULL = no split-K
+  p.split_tickets = e ? reinterpret_cast<unsigned*>(e->split_tickets) : nullptr;
 }
 
 void decide_vec_epilogue(NtParams& p) {
@@ -868,7 +845,7 @@ extern "C" int fod_gemm_nt(int dtype, const void* A, long lda, int a_row_mod, co
       ks = (int)(256 / tiles);
       if (ks > cap) ks = cap;
       if (ks > K / 256) ks = K / 256;
-      if (ks > 1 && small_split_scratch(stream, &p.split_ws, &p.split_tickets)) p.ksplit = ks;
+      if (ks > 1 && p.split_ws && p.split_tickets) p.ksplit = ks;   // 64 tiles x 8 splits x 64 x 64 f32 = FOD_NT_SPLIT_WS_FLOATS
       else ks = 1;
     }
     hipLaunchKernelGGL(gemm_nt_small_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64), ks), dim3(256), 0, stream, p);

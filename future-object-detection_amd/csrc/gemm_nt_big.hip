@@ -326,16 +326,9 @@ int launch_big(const NtParams& p, hipStream_t stream) {
   NtParams q = p;
   q.gy = ceil_div(p.M, BMB);
   q.gx = ceil_div(p.N, BNB);
-  static bool attr_set[5] = {false, false, false, false, false};
+  static LdsLimitOnce lds_once;                     // one per MODE instantiation
   const size_t lds = (size_t)NSTAGE * STAGE_BYTES;
-  if (!attr_set[MODE]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&nt_big_kernel<MODE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      fod_set_error("gemm_nt_big: cannot raise the dynamic LDS limit to %zu", lds);
-      return FOD_ERR_RUNTIME;
-    }
-    attr_set[MODE] = true;
-  }
+  if (int rc = fod_lds_limit_once(lds_once, reinterpret_cast<const void*>(&nt_big_kernel<MODE>), lds, "gemm_nt_big")) return rc;
   const dim3 grid(q.gx * ((q.gy + 7) / 8 * 8));
   hipLaunchKernelGGL((nt_big_kernel<MODE>), grid, dim3(512), lds, stream, q);
   FOD_LAUNCH_CHECK();

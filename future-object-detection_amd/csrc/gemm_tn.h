@@ -22,6 +22,8 @@ struct TnParams {
   long g_seg_stride;               //   (P same-shaped gradient tensors side by side); 0 = plain [M, N1]
   int Hs, Ws, Cs, Hd, Wd, kh, kw, stride, pad;
   float* ws;                       // gemm_tn_big.hip: per-(split, tile) partial tiles, summed by a second launch; or NULL
+  float* ws_caller;                // the caller's workspace (fod_gemm_tn_acc / fod_conv2d_wgrad_acc `ws`), ws_caller_bytes long
+  size_t ws_caller_bytes;
 };
 
 // gemm_tn_big.hip: the 8-wave LDS-DMA kernel for long bf16 reductions (conv weight gradients, the encoder's Linear

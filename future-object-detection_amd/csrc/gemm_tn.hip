@@ -758,7 +758,7 @@ extern "C" int fod_tn_plan_long(int M, int rows_hint, int* m_per_split, int* nsp
 
 extern "C" int fod_gemm_tn_acc(int dtype, const void* G, long ldg, const void* X, long ldx, float* dW,
                                long ldw, int M, int N1, int K2, const float* row_scale, float* colsum,
-                               int accumulate, hipStream_t stream) {
+                               int accumulate, void* ws, size_t ws_bytes, hipStream_t stream) {
   const int vec = dtype == FOD_BF16 ? 8 : 4;
   FOD_REQUIRE(G && X && dW, "gemm_tn: null operand");
   FOD_REQUIRE(M > 0 && N1 > 0 && K2 > 0, "gemm_tn: empty problem");
@@ -772,6 +772,8 @@ extern "C" int fod_gemm_tn_acc(int dtype, const void* G, long ldg, const void* X
   p.rscale = row_scale;
   p.colsum = colsum;
   p.accumulate = accumulate;
+  p.ws_caller = reinterpret_cast<float*>(ws);
+  p.ws_caller_bytes = ws ? ws_bytes : 0;
   const long esz = dtype == FOD_BF16 ? 2 : 4;
   const long gb = ((long)(M - 1) * ldg + N1) * esz, xb = ((long)(M - 1) * ldx + K2) * esz;
   FOD_REQUIRE(gb < 0xFFFFFFF0L - 16 && xb < 0xFFFFFFF0L - 16, "gemm_tn: operand larger than 4 GiB");
@@ -787,7 +789,7 @@ extern "C" int fod_gemm_tn_acc(int dtype, const void* G, long ldg, const void* X
 
 extern "C" int fod_conv2d_wgrad_acc(int dtype, const void* dy, const void* x, float* dw,
                                     const fod_conv_geom* g, const float* row_scale, int accumulate,
-                                    hipStream_t stream) {
+                                    void* ws, size_t ws_bytes, hipStream_t stream) {
   const int vec = dtype == FOD_BF16 ? 8 : 4;
   FOD_REQUIRE(dy && x && dw && g, "conv_wgrad: null operand");
   FOD_REQUIRE(g->Cin % vec == 0 && g->Cout % vec == 0, "conv_wgrad: channels %d/%d must be multiples of %d",
@@ -808,6 +810,8 @@ extern "C" int fod_conv2d_wgrad_acc(int dtype, const void* dy, const void* x, fl
   p.Hd = g->Ho; p.Wd = g->Wo;
   p.kh = g->kh; p.kw = g->kw; p.stride = g->stride; p.pad = g->pad;
   p.accumulate = accumulate;
+  p.ws_caller = reinterpret_cast<float*>(ws);
+  p.ws_caller_bytes = ws ? ws_bytes : 0;
   const long esz = dtype == FOD_BF16 ? 2 : 4;
   const long gb = (long)p.M * g->Cout * esz, xb = (long)g->Nimg * g->H * g->W * g->Cin * esz;
   FOD_REQUIRE(gb < 0xFFFFFFF0L - 16 && xb < 0xFFFFFFF0L - 16, "conv_wgrad: operand larger than 4 GiB");

@@ -371,40 +371,14 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const TnParams p) {
   *reinterpret_cast<f32x4*>(dst) = acc;
 }
 
-// The partial tiles live in a per-device scratch of this library (64 MiB = 256 blocks x 256 KiB: one round of blocks
-// with room to spare), allocated at the first long weight-gradient launch.  One scratch per device: launches that use
-// it must be ordered on one stream (they are: the backward pass runs on the launching stream).  No allocation happens
-// inside a stream capture -- a capture that comes first keeps the atomic epilogue.
-constexpr size_t WS_BYTES = 64u << 20;
-float* workspace(hipStream_t stream) {
-  static float* ws[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  if (!ws[dev]) {
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return nullptr;
-    void* q = nullptr;
-    if (hipMalloc(&q, WS_BYTES) != hipSuccess) {
-      (void)hipGetLastError();
-      return nullptr;
-    }
-    ws[dev] = reinterpret_cast<float*>(q);
-  }
-  return ws[dev];
-}
-
+// The partial tiles live in the CALLER's workspace (fod_gemm_tn_acc / fod_conv2d_wgrad_acc `ws`, FOD_TN_WS_BYTES = 256
+// blocks x 256 KiB: one round of blocks with room to spare; future_od/native/ops.py keeps one per device and stream).
+// The library allocates nothing; without a workspace (or with one too small for the launch) the atomic epilogue runs.
 template <int MODE, int BI, int BJ>
 int launch_shape(const TnParams& p, hipStream_t stream) {
-  static bool attr_set = false;
+  static LdsLimitOnce lds_once;                    // one per instantiation
   const size_t lds = (size_t)NSTAGE * STAGE_BYTES;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&tn_big_kernel<MODE, BI, BJ>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      fod_set_error("gemm_tn_big: cannot raise the dynamic LDS limit to %zu", lds);
-      return FOD_ERR_RUNTIME;
-    }
-    attr_set = true;
-  }
+  if (int rc = fod_lds_limit_once(lds_once, reinterpret_cast<const void*>(&tn_big_kernel<MODE, BI, BJ>), lds, "gemm_tn_big")) return rc;
   const int ntile = p.ti * p.tj;
   const dim3 grid(p.xcd_order ? 8 * ceil_div((long)ntile * p.nsplit, 8) : ntile * p.nsplit);
   TnParams q = p;
@@ -412,7 +386,9 @@ int launch_shape(const TnParams& p, hipStream_t stream) {
   const char* env_ws = getenv("FOD_TN_WS");                      // "0": f32 atomics straight into dW (experiments)
   const size_t need = (size_t)ntile * p.nsplit * BI * BJ * sizeof(float);
   const bool aligned = ((uintptr_t)p.dW % 16) == 0 && p.ldw % 4 == 0;
-  if (p.nsplit > 1 && need <= WS_BYTES && aligned && !(env_ws && env_ws[0] == '0')) q.ws = workspace(stream);
+  if (p.nsplit > 1 && p.ws_caller && need <= p.ws_caller_bytes && aligned && ((uintptr_t)p.ws_caller % 16) == 0 &&
+      !(env_ws && env_ws[0] == '0'))
+    q.ws = p.ws_caller;
   hipLaunchKernelGGL((tn_big_kernel<MODE, BI, BJ>), grid, dim3(512), lds, stream, q);
   FOD_LAUNCH_CHECK();
   if (q.ws) {

@@ -200,15 +200,8 @@ extern "C" int fod_lap_solve_batch_dev(const float* cost, int nprob, int B, int 
   const size_t cost_bytes = (size_t)M * ld_n * sizeof(float);
   const size_t with_cost = sizeof(LapState) + cost_bytes;
   if (with_cost <= 150 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lap_dev_kernel<true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
-        fod_set_error("lap_dev: cannot raise the dynamic LDS limit");
-        return FOD_ERR_RUNTIME;
-      }
-      attr_set = true;
-    }
+    static LdsLimitOnce lds_once;
+    if (int rc = fod_lds_limit_once(lds_once, reinterpret_cast<const void*>(&lap_dev_kernel<true>), 150 * 1024, "lap_dev")) return rc;
     hipLaunchKernelGGL(lap_dev_kernel<true>, dim3(nprob), dim3(64), with_cost, stream, cost, B, M, ld_n, tgt_offset,
                        match_out, status);
   } else {

@@ -235,7 +235,7 @@ class GraphedStep:
                   if k != "_host_annotations"}
         if self._dropout_active() and (ops.DROP_BASE is None or ops.DROP_BASE.device != dev):
             ops.DROP_BASE = torch.zeros(1, dtype=torch.int64, device=dev)
-        side = torch.cuda.Stream(device=dev)
+        side = _warmup_stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(self.warmup):          # populates every cache (prepared-weight tables, optimizer plan, ...)
@@ -346,6 +346,18 @@ class GraphedStep:
         return g["outs"]
 
 
+_WARMUP_STREAMS = {}
+
+
+def _warmup_stream(dev):
+    """One side stream per device for every capture's eager warm-up steps (torch wants them off the default stream): the
+    per-stream scratch buffers of native/ops.py are then allocated once, not once per capture."""
+    key = (dev.type, dev.index)
+    if key not in _WARMUP_STREAMS:
+        _WARMUP_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _WARMUP_STREAMS[key]
+
+
 class GraphedForward:
     """out = GraphedForward(model)(data): the evaluation pass (`with torch.no_grad(): model(data)`; forward, set loss,
     post-processing, AP bookkeeping) as one hipGraph per batch signature.  The reference's evaluation loop
@@ -376,7 +388,7 @@ class GraphedForward:
             dev = next(v for v in data.values() if isinstance(v, torch.Tensor)).device
             static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in data.items()
                       if k != "_host_annotations"}
-            side = torch.cuda.Stream(device=dev)
+            side = _warmup_stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 for _ in range(self.warmup + 1):

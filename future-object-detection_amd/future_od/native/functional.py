@@ -6,6 +6,8 @@ convs) that are cached per parameter version, so a copy is rebuilt only after an
 Activations and their gradients are in the compute dtype (torch.float32 = parity mode,
 torch.bfloat16 = performance mode); parameter gradients are fp32.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -524,7 +526,8 @@ class _WgradQueue:
     def _one_by_one(self, jobs, members, long=False):
         if long:
             for G, X, dW, cs, ldg, ldx, ldw, M, N1, K2, acc, _sc, _ss in jobs:
-                L.call("fod_gemm_tn_acc", L.BF16, G, ldg, X, ldx, dW, ldw, M, N1, K2, 0, cs, 1, ops.stream(),
+                ws, ws_bytes = ops.tn_workspace(torch.device("cuda", torch.cuda.current_device())) if M >= 8192 else (None, 0)
+                L.call("fod_gemm_tn_acc", L.BF16, G, ldg, X, ldx, dW, ldw, M, N1, K2, 0, cs, 1, ws, ws_bytes, ops.stream(),
                        work=2.0 * M * N1 * K2)
             return
         for i, (G, X, dW, cs, ldg, ldx, ldw, M, N1, K2, acc, seg_cols, seg_stride) in enumerate(jobs):
@@ -1037,13 +1040,36 @@ def dropout(x, p, training):
     return DropoutFn.apply(x.contiguous(), float(p), DROP_SEEDS.next())
 
 
+# fp8 attention (BASELINE.json configs[4], csrc/attention_fp8.hip).  "off": bf16 / f32 kernels everywhere (default);
+# "long": the launches the block-shared LDS kernels take in bf16 (long query sequences: the encoder's self-attention,
+# the joint encoders) run the MX-fp8 forward; "all": every bf16 attention without active dropout does (the decoder's
+# few-query launches then lose their key split across blocks: slower, kept for tests and the record).
+# Set by runs/_model.build_model(args.attn_dtype) / bench.py --attn-dtype; FOD_ATTN_FP8 overrides.
+ATTN_FP8 = {"mode": os.environ.get("FOD_ATTN_FP8", "off")}
+
+
+def _fp8_takes(q1, k1, drop_p):
+    mode = ATTN_FP8["mode"]
+    if mode == "off" or q1.dtype != torch.bfloat16 or drop_p > 0.0:
+        return False
+    few_queries = q1.shape[1] <= 512 and k1.shape[1] >= 128       # launch_all()'s split predicate (attention.hip)
+    return mode == "all" or not few_queries
+
+
 class AttentionFn(Function):
     @staticmethod
     def forward(ctx, q1, k1, v, q2, k2, scale, drop_p=0.0, drop_seed=0):
-        o, lse2 = ops.attn_fwd(q1, k1, v, scale, q2, k2, drop_p=drop_p, drop_seed=drop_seed)
         ctx.drop = (drop_p, drop_seed)
         ctx.scale = scale
         ctx.two = q2 is not None
+        ctx.fp8 = _fp8_takes(q1, k1, drop_p)
+        if ctx.fp8:
+            need_bwd = any(t is not None and t.requires_grad for t in (q1, k1, v, q2, k2))
+            o, lse2, deq = ops.attn_fwd_fp8(q1, k1, v, scale, q2, k2, want_backward=need_bwd)
+            if need_bwd:                 # the backward pass runs on the dequantised operands (same quantised scores)
+                ctx.save_for_backward(deq[0], deq[1], deq[2], deq[3], deq[4], o, lse2)
+            return o
+        o, lse2 = ops.attn_fwd(q1, k1, v, scale, q2, k2, drop_p=drop_p, drop_seed=drop_seed)
         ctx.save_for_backward(q1, k1, v, q2, k2, o, lse2)
         return o
 
@@ -1062,6 +1088,11 @@ class AttentionFn(Function):
             # produced q, k, v takes as it is (no gather copies)
             buf = torch.empty((3,) + tuple(q1.shape), dtype=q1.dtype, device=q1.device)
             slots = dict(dq1_out=buf[0], dk1_out=buf[1], dv_out=buf[2])
+        if ctx.fp8:
+            # q was multiplied by scale * log2(e) before quantisation: scores = (1 / log2 e) q'.k, dq = scale log2(e) dq'
+            dq1, dk1, dq2, dk2, dv = ops.attn_bwd(q1, k1, v, o, do.contiguous(), lse2, 1.0 / ops.LOG2E, q2, k2,
+                                                  dq_scale=ctx.scale * ops.LOG2E, **slots)
+            return dq1, dk1, dv, dq2, dk2, None, None, None
         dq1, dk1, dq2, dk2, dv = ops.attn_bwd(q1, k1, v, o, do.contiguous(), lse2, ctx.scale, q2, k2,
                                               drop_p=ctx.drop[0], drop_seed=ctx.drop[1], **slots)
         return dq1, dk1, dv, dq2, dk2, None, None, None

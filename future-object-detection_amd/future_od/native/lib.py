@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libfod_hip.so"))
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 F32, BF16 = 0, 1
 EW_ADD, EW_MUL, EW_RELU_MASK, EW_SCALE, EW_ADD3, EW_RELU, EW_COPY_B = range(7)
@@ -21,7 +21,8 @@ class FodError(RuntimeError):
 class Epilogue(C.Structure):
     _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("residual", C.c_void_p),
                 ("ld_residual", C.c_long), ("residual_row_mod", C.c_int), ("relu_mask", C.c_void_p),
-                ("ld_mask", C.c_long), ("relu", C.c_int), ("out_f32", C.c_int)]
+                ("ld_mask", C.c_long), ("relu", C.c_int), ("out_f32", C.c_int),
+                ("split_ws", C.c_void_p), ("split_tickets", C.c_void_p)]
 
 
 class ConvGeom(C.Structure):
@@ -40,7 +41,7 @@ class AttnShape(C.Structure):
                 ("k2_batch_stride", C.c_long), ("k2_token_stride", C.c_long),
                 ("dk2_batch_stride", C.c_long), ("dk2_token_stride", C.c_long),
                 ("drop_p", C.c_float), ("drop_seed", C.c_ulonglong), ("drop_seed_dev", C.c_void_p),
-                ("split_ws", C.c_void_p), ("split_tickets", C.c_void_p)]
+                ("split_ws", C.c_void_p), ("split_tickets", C.c_void_p), ("dq_scale", C.c_float)]
 
 
 class PermuteJob(C.Structure):
@@ -67,7 +68,7 @@ _EP, _CG, _AS = _p, _p, _p
 # name -> argtypes, exactly the prototypes of include/fod.h (stream last unless host-only)
 SIGNATURES = {
     "fod_gemm_nt": [_i, _p, _l, _i, _p, _l, _p, _l, _i, _i, _i, _EP, _p],
-    "fod_gemm_tn_acc": [_i, _p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p],
+    "fod_gemm_tn_acc": [_i, _p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p, C.c_size_t, _p],
     "fod_gemm_nt_grouped": [_i, _p, _l, _i, _l, _p, _l, _p, _l, _i, _l, _i, _i, _i, _EP, _p],
     "fod_gemm_tn_grouped": [_i, _p, _l, _i, _l, _p, _l, _p, _l, _i, _i, _i, _p, _i, _p],
     "fod_gemm_tn_multi": [_p, _p, _p, _i, _p],
@@ -78,7 +79,7 @@ SIGNATURES = {
     "fod_conv2d_dgrad": [_i, _p, _p, _p, _CG, _EP, _p],
     "fod_conv_stem_fwd": [_i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _EP, _p],
     "fod_clip_to_stem_layout": [_i, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _l, _l, _p, _p, _p],
-    "fod_conv2d_wgrad_acc": [_i, _p, _p, _p, _CG, _p, _i, _p],
+    "fod_conv2d_wgrad_acc": [_i, _p, _p, _p, _CG, _p, _i, _p, C.c_size_t, _p],
     "fod_maxpool3x3s2": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "fod_dropout": [_i, _p, _p, _l, C.c_ulonglong, _p, _f, _p],
     "fod_multi_permute3": [_p, _p, _p, _i, _p],
@@ -89,6 +90,9 @@ SIGNATURES = {
     "fod_permute3_cast": [_i, _i, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _i, _p],
     "fod_attn_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _AS, _p],
     "fod_attn_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _AS, _p],
+    "fod_attn_fp8_pack_bytes": [_AS, _i, _p, _p],
+    "fod_attn_quant_fp8": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _AS, _p],
+    "fod_attn_fwd_fp8": [_p, _p, _i, _p, _p, _AS, _p],
     "fod_layernorm_fwd": [_i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
     "fod_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "fod_eltwise": [_i, _i, _p, _p, _p, _p, _l, _i, _i, _i, _f, _p],
@@ -121,7 +125,8 @@ SIGNATURES = {
     "fod_multi_sqnorm_det": [_p, _p, _p, _p, _i, _p, _p, _p],
     "fod_multi_adamw": [_p, _p, _p, _p, _p, _i, _f, _f, _f, _f, _f, _p, _p, _f, _p],
 }
-EXPORTS = sorted(list(SIGNATURES) + ["fod_last_error", "fod_abi_version", "fod_multi_chunk"])
+EXPORTS = sorted(list(SIGNATURES) + ["fod_last_error", "fod_abi_version", "fod_multi_chunk", "fod_workspace_bytes"])
+WS_NT_SPLIT, WS_NT_SPLIT_TICKETS, WS_TN_PARTIALS, WS_ATTN_SPLIT_PER_TILE = range(4)      # fod_workspace_bytes(kind)
 
 
 def _load():
@@ -136,6 +141,8 @@ def _load():
         raise FodError(f"libfod_hip.so ABI {lib.fod_abi_version()} != binding ABI {ABI_VERSION}: rebuild")
     lib.fod_last_error.restype = C.c_size_t
     lib.fod_last_error.argtypes = [C.c_char_p, C.c_size_t]
+    lib.fod_workspace_bytes.restype = C.c_size_t
+    lib.fod_workspace_bytes.argtypes = [C.c_int]
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = C.c_int
@@ -193,15 +200,23 @@ class Profiler:
         self.enabled = False
 
     def summary(self):
+        """{entry: calls, seconds, work, median_us, max_us, outliers (calls > 10 x the entry's median)}: an event pair also
+        times whatever stalled the launching thread between its two records while the GPU sat idle, so a host hiccup
+        shows up as an outlier here instead of hiding in a sum (BENCH_r02: 24.7 ms booked to a 4.6 ms entry)."""
         import torch
         torch.cuda.synchronize()
         agg = {}
         for name, work, e0, e1 in self.records:
-            a = agg.setdefault(name, [0, 0.0, 0.0])
-            a[0] += 1
-            a[1] += e0.elapsed_time(e1) * 1e-3
-            a[2] += work
-        return {k: {"calls": v[0], "seconds": v[1], "work": v[2]} for k, v in agg.items()}
+            a = agg.setdefault(name, [[], 0.0])
+            a[0].append(e0.elapsed_time(e1) * 1e-3)
+            a[1] += work
+        out = {}
+        for k, (ts, work) in agg.items():
+            ts_sorted = sorted(ts)
+            med = ts_sorted[len(ts) // 2]
+            out[k] = {"calls": len(ts), "seconds": sum(ts), "work": work, "median_us": med * 1e6, "max_us": ts_sorted[-1] * 1e6,
+                      "outliers": sum(1 for t in ts if t > 10.0 * med and t > 50e-6)}
+        return out
 
 
 PROFILER = Profiler()

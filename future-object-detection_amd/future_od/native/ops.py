@@ -60,13 +60,46 @@ def _chk(t, name, dtype=None):
     return t
 
 
+# ---- caller-owned scratch of the library (include/fod.h: it allocates no device memory and keeps no device state) ------
+# One buffer per (kind, device, stream) for eagerly launched work and one per (kind, device) for everything captured
+# into graphs (replays of this process's graphs are launched from one thread onto one stream at a time): launches of one
+# stream are ordered, a replay running next to an eager step or two eager streams must not share partial tiles.  A
+# buffer is never freed -- a captured graph holds its address (the retire-don't-free rule of the attention split
+# workspace below).
+_WS = {}
+
+
+def _workspace(kind, device):
+    key = (kind, device.index, "graph" if torch.cuda.is_current_stream_capturing() else stream())
+    hit = _WS.get(key)
+    if hit is None:
+        nbytes = L.LIB.fod_workspace_bytes(kind)
+        hit = torch.zeros(nbytes // 4, dtype=torch.int32, device=device)     # the ticket words must start at zero
+        _WS[key] = hit
+    return hit
+
+
 def _epi(scale=None, shift=None, residual=None, ld_residual=0, residual_row_mod=0, relu_mask=None,
-         ld_mask=0, relu=False, out_f32=False):
-    if scale is None and shift is None and residual is None and relu_mask is None and not relu and not out_f32:
+         ld_mask=0, relu=False, out_f32=False, split_for=None):
+    """split_for = (device, M, N, K) of a fod_gemm_nt call: attaches the split-K scratch when the problem is one the
+    library would split (deep K on few tiles, the condition of csrc/gemm_nt.hip: fod_gemm_nt)."""
+    want_split = (split_for is not None and split_for[3] >= 1024
+                  and ((split_for[1] + 63) // 64) * ((split_for[2] + 63) // 64) <= 64)
+    if (scale is None and shift is None and residual is None and relu_mask is None and not relu and not out_f32
+            and not want_split):
         return None
+    ws = tk = None
+    if want_split:
+        ws, tk = _workspace(L.WS_NT_SPLIT, split_for[0]), _workspace(L.WS_NT_SPLIT_TICKETS, split_for[0])
     e = Epilogue(ptr(scale), ptr(shift), ptr(residual), ld_residual, residual_row_mod,
-                 ptr(relu_mask), ld_mask, int(relu), int(out_f32))
+                 ptr(relu_mask), ld_mask, int(relu), int(out_f32), ptr(ws), ptr(tk))
     return _Addr(e)
+
+
+def tn_workspace(device):
+    """(address, bytes) of the partial-tile workspace of the long weight gradients for the current stream."""
+    ws = _workspace(L.WS_TN_PARTIALS, device)
+    return ws.data_ptr(), ws.numel() * 4
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
@@ -99,7 +132,8 @@ def gemm_nt(a, b, *, a_row_mod=0, m_rows=None, scale=None, shift=None, residual=
     else:
         _chk(out, "out"); assert out.numel() == M * N
     call("fod_gemm_nt", dt(a), ptr(a), K, a_row_mod, ptr(b), K, ptr(out), N, M, N, K,
-         _epi(scale, shift, residual, N, residual_row_mod, relu_mask, N, relu, out_f32), stream(),
+         _epi(scale, shift, residual, N, residual_row_mod, relu_mask, N, relu, out_f32,
+              split_for=(a.device, M, N, K) if a.dtype == torch.bfloat16 else None), stream(),
          work=2.0 * M * N * K)
     return out
 
@@ -114,8 +148,9 @@ def gemm_tn_acc(g, x, dw, row_scale=None, colsum=None, zeroed=False):
         _chk(row_scale, "row_scale", torch.float32); assert row_scale.numel() == N1
     if colsum is not None:
         _chk(colsum, "colsum", torch.float32); assert colsum.numel() == N1
+    ws, ws_bytes = tn_workspace(g.device) if M >= 8192 else (None, 0)      # only long reductions take partial tiles
     call("fod_gemm_tn_acc", dt(g), ptr(g), N1, ptr(x), K2, ptr(dw), K2, M, N1, K2, ptr(row_scale), ptr(colsum),
-         0 if zeroed else 1, stream(),
+         0 if zeroed else 1, ws, ws_bytes, stream(),
          work=2.0 * M * N1 * K2)
     return dw
 
@@ -274,8 +309,9 @@ def conv2d_wgrad_acc(dy, x, dw, geom, row_scale=None, zeroed=False):
     assert dw.numel() == geom.Cout * geom.kh * geom.kw * geom.Cin
     if row_scale is not None:
         _chk(row_scale, "row_scale", torch.float32); assert row_scale.numel() == geom.Cout
+    ws, ws_bytes = tn_workspace(dy.device) if dy.numel() // geom.Cout >= 8192 else (None, 0)
     call("fod_conv2d_wgrad_acc", dt(dy), ptr(dy), ptr(x), ptr(dw), _Addr(geom), ptr(row_scale),
-         0 if zeroed else 1, stream(),
+         0 if zeroed else 1, ws, ws_bytes, stream(),
          work=_conv_flops(geom))
     return dw
 
@@ -350,7 +386,7 @@ def _bt(t, name, dtype):
     return bs, ts
 
 
-def _attn_shape(q1, k1, v, o, scale, k2=None, dk2=None, drop_p=0.0, drop_seed=0):
+def _attn_shape(q1, k1, v, o, scale, k2=None, dk2=None, drop_p=0.0, drop_seed=0, dq_scale=0.0):
     dtp = q1.dtype
     B, Tq, E = q1.shape
     S = k1.shape[1]
@@ -372,7 +408,8 @@ def _attn_shape(q1, k1, v, o, scale, k2=None, dk2=None, drop_p=0.0, drop_seed=0)
     if Tq <= 512 and S >= 256:
         ws, tk = _attn_split_workspace(q1.device, B * H * ((Tq + 31) // 32))
     return AttnShape(B, H, Tq, S, qb, qt, kb, kt, vb, vt, ob, ot, scale, k2b, k2t, d2b, d2t, float(drop_p),
-                     int(drop_seed) & 0xFFFFFFFFFFFFFFFF, ptr(DROP_BASE) if drop_p > 0.0 else None, ptr(ws), ptr(tk)), H
+                     int(drop_seed) & 0xFFFFFFFFFFFFFFFF, ptr(DROP_BASE) if drop_p > 0.0 else None, ptr(ws), ptr(tk),
+                     float(dq_scale)), H
 
 
 _ATTN_SPLIT = {}
@@ -416,8 +453,43 @@ def attn_fwd(q1, k1, v, scale, q2=None, k2=None, drop_p=0.0, drop_seed=0):
     return o, lse2
 
 
+LOG2E = 1.4426950408889634
+
+
+def attn_fwd_fp8(q1, k1, v, scale, q2=None, k2=None, want_backward=True):
+    """fp8 (MX e4m3) attention forward, BASELINE.json configs[4]: quantise (fod_attn_quant_fp8) then attend
+    (fod_attn_fwd_fp8).  bf16 operands as attn_fwd.  Returns (o, lse2, deq) with deq = the bf16 copies of the
+    dequantised (q1 * scale * log2 e, k1, v, q2 * scale * log2 e, k2) the backward pass runs on -- attn_bwd(*deq,
+    scale=1 / log2 e, dq_scale=scale * log2 e) -- or None when want_backward is False."""
+    if q1.dtype != torch.bfloat16:
+        raise L.FodError("attn_fwd_fp8: bf16 operands only (the fp32 parity mode has no fp8 variant)")
+    o = torch.empty(q1.shape, dtype=q1.dtype, device=q1.device)
+    if q2 is not None:
+        _same_bt(q1, q2, "q2")
+    shp, H = _attn_shape(q1, k1, v, o, scale, k2)
+    shp.split_ws = shp.split_tickets = None
+    parts = 2 if q2 is not None else 1
+    B, Tq, E = q1.shape
+    S = k1.shape[1]
+    qb, kb = C.c_size_t(), C.c_size_t()
+    L._plain_call("fod_attn_fp8_pack_bytes", C.addressof(shp), parts, C.addressof(qb), C.addressof(kb))
+    qpack = torch.empty(qb.value, dtype=torch.uint8, device=q1.device)
+    kvpack = torch.empty(kb.value, dtype=torch.uint8, device=q1.device)
+    deq = None
+    if want_backward:
+        mk = lambda T: torch.empty((B, T, E), dtype=q1.dtype, device=q1.device)
+        deq = (mk(Tq), mk(S), mk(S), mk(Tq) if parts == 2 else None, mk(S) if parts == 2 else None)
+    d = deq or (None,) * 5
+    call("fod_attn_quant_fp8", ptr(q1), ptr(k1), ptr(q2), ptr(k2), ptr(v), ptr(qpack), ptr(kvpack),
+         ptr(d[0]), ptr(d[1]), ptr(d[3]), ptr(d[4]), ptr(d[2]), _Addr(shp), stream(), tag="fod_attn_quant_fp8")
+    lse2 = torch.empty((B, H, Tq), dtype=torch.float32, device=q1.device)
+    call("fod_attn_fwd_fp8", ptr(qpack), ptr(kvpack), parts, ptr(o), ptr(lse2), _Addr(shp), stream(),
+         work=2.0 * B * H * Tq * S * 32 * (parts + 1))
+    return o, lse2, deq
+
+
 def attn_bwd(q1, k1, v, o, dout, lse2, scale, q2=None, k2=None, dk1_out=None, dv_out=None, dk2_out=None,
-             dq1_out=None, dq2_out=None, drop_p=0.0, drop_seed=0):
+             dq1_out=None, dq2_out=None, drop_p=0.0, drop_seed=0, dq_scale=0.0):
     """Gradients (dq1, dk1, dq2, dk2, dv).  dk1_out / dv_out / dk2_out: optional destinations (e.g. slots of a
     larger gradient buffer); dk1_out / dv_out must have k1's / v's strides, dk2_out is always per batch element."""
     _chk(lse2, "lse2", torch.float32)
@@ -437,7 +509,7 @@ def attn_bwd(q1, k1, v, o, dout, lse2, scale, q2=None, k2=None, dk1_out=None, dv
         _same_bt(dq2, q1, "dq2")
         B, S, E = k1.shape
         dk2 = dk2_out if dk2_out is not None else torch.empty((B, S, E), dtype=k1.dtype, device=k1.device)
-    shp, H = _attn_shape(q1, k1, v, o, scale, k2, dk2, drop_p=drop_p, drop_seed=drop_seed)
+    shp, H = _attn_shape(q1, k1, v, o, scale, k2, dk2, drop_p=drop_p, drop_seed=drop_seed, dq_scale=dq_scale)
     assert lse2.shape == (q1.shape[0], H, q1.shape[1])
     delta = torch.empty_like(lse2)
     call("fod_attn_bwd", dt(q1), ptr(q1), ptr(k1), ptr(q2), ptr(k2), ptr(v), ptr(o), ptr(dout), ptr(lse2),

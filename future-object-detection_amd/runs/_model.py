@@ -4,6 +4,7 @@ from the HIP-backed modules.  Extra knobs are read from `args` if present and de
 reference's literals, so the reference's run scripts work unchanged:
 
     args.compute_dtype : "bf16" (default) | "fp32"      -- arithmetic mode of the kernels
+    args.attn_dtype    : "bf16" | "fp8" | "fp8-all"    -- MX-fp8 attention cores (eval-mode math; csrc/attention_fp8.hip)
     args.num_images    : decoder cross-attention blocks (reference literal: 2)
     args.backbone      : "resnet50" (reference literal) | "resnet18" | "resnet34"
     args.skip_dead_frames : True (default) -- do not compute frames that cannot reach the output
@@ -77,6 +78,12 @@ def build_model(args, detr_args: SpatioTemporalDETRArgs):
             image_memory_mode=getattr(args, "image_memory_mode", "attend one at a time")),
         pos_encoder=PositionalEncoder(no_temporal=getattr(args, "no_temporal", True)))
     core.compute_dtype = _DTYPES[getattr(args, "compute_dtype", "bf16")]
+    attn_dtype = getattr(args, "attn_dtype", None)
+    if attn_dtype is not None:
+        # BASELINE.json configs[4]: "fp8" = MX-fp8 QK^T / PV in the long-sequence attention launches (the encoder's
+        # self-attention), "fp8-all" = in every attention launch; a process-wide switch of the kernel layer
+        from future_od.native import functional as Fn
+        Fn.ATTN_FP8["mode"] = {"bf16": "off", "fp8": "long", "fp8-all": "all"}[attn_dtype]
     core.skip_dead_frames = bool(getattr(args, "skip_dead_frames", True))
     model = SpatioTemporalDETR(args=detr_args, model=core)
     model.to(args.device)

@@ -37,7 +37,7 @@ enum { FOD_OK = 0, FOD_ERR_ARG = 1, FOD_ERR_LAUNCH = 2, FOD_ERR_RUNTIME = 3 };
 size_t fod_last_error(char* buf, size_t cap);
 /* ABI version of this header; the loader refuses a library that disagrees. */
 int fod_abi_version(void);
-#define FOD_ABI_VERSION 2
+#define FOD_ABI_VERSION 3
 
 /* Fused epilogue of the NT contraction family.  In order:
  *   v = acc * scale[n] + shift[n];  v += residual[row(m), n];  v = relu ? max(v,0) : v;
@@ -53,7 +53,22 @@ typedef struct fod_epilogue {
   long ld_mask;
   int relu;
   int out_f32;
+  /* fod_gemm_nt only, optional (NULL = never split): caller-owned scratch that lets a deep-K problem on few tiles (the
+   * decoder's feed-forward, 256 x 256 x 2048) split K across blocks.  split_ws: f32 [FOD_NT_SPLIT_WS_FLOATS],
+   * split_tickets: u32 [FOD_NT_SPLIT_TICKETS], all zero before the first launch (the kernels leave them zero).  One
+   * scratch may serve every launch of ONE stream; launches on different streams need their own. */
+  void* split_ws;
+  void* split_tickets;
 } fod_epilogue;
+#define FOD_NT_SPLIT_WS_FLOATS (64 * 8 * 4096)
+#define FOD_NT_SPLIT_TICKETS 64
+/* bytes of the partial-tile workspace fod_gemm_tn_acc / fod_conv2d_wgrad_acc use for long reductions (one round of 256
+ * blocks x 128 x 256 f32 with room to spare); a smaller or NULL workspace selects the f32-atomics epilogue */
+#define FOD_TN_WS_BYTES ((size_t)64 << 20)
+/* The library allocates NO device memory and keeps no device state: every scratch is the caller's (the attention key
+ * split: fod_attn_shape.split_ws; the two above).  Sizes, for bindings that cannot read macros: */
+enum { FOD_WS_NT_SPLIT = 0, FOD_WS_NT_SPLIT_TICKETS = 1, FOD_WS_TN_PARTIALS = 2, FOD_WS_ATTN_SPLIT_PER_TILE = 3 };
+size_t fod_workspace_bytes(int kind);
 
 /* C[m,n] = epi( sum_k A[(m % a_row_mod) , k] * B[n, k] )      A:[*,K] lda, B:[N,K] ldb, C:[M,N] ldc
  * Replaces nn.Linear forward (B = weight) and input-gradient (B = weight^T) on the path:
@@ -69,7 +84,8 @@ int fod_gemm_nt(int dtype, const void* A, long lda, int a_row_mod, const void* B
  * colsum are all-zero on entry; a launch that needs only one M-split then uses plain stores. */
 int fod_gemm_tn_acc(int dtype, const void* G, long ldg, const void* X, long ldx, float* dW, long ldw,
                     int M, int N1, int K2, const float* row_scale, float* colsum, int accumulate,
-                    fod_stream_t stream);
+                    void* ws /* optional, FOD_TN_WS_BYTES: deterministic partial tiles instead of atomics */,
+                    size_t ws_bytes, fod_stream_t stream);
 
 /* Grouped forms for P same-shaped Linear layers that share their input (the decoder's query-side projections:
  * query_content / key_content / value of future_od/models/transformer.py:66-70, the per-image query_sine
@@ -168,7 +184,8 @@ int fod_conv2d_dgrad(int dtype, const void* dy, const void* w_t, void* dx, const
                      const fod_epilogue* epi, fod_stream_t stream);
 /* dw[co][r][s][ci] += row_scale[co] * sum_pixels dy * x   (f32, channels_last OIHW) */
 int fod_conv2d_wgrad_acc(int dtype, const void* dy, const void* x, float* dw, const fod_conv_geom* g,
-                         const float* row_scale, int accumulate, fod_stream_t stream);
+                         const float* row_scale, int accumulate, void* ws /* optional, as fod_gemm_tn_acc */,
+                         size_t ws_bytes, fod_stream_t stream);
 
 /* 3x3 stride-2 pad-1 max pooling, NHWC (torchvision ResNet stem; forward only: stem is frozen). */
 int fod_maxpool3x3s2(int dtype, const void* x, void* y, int Nimg, int H, int W, int C, int Ho, int Wo,
@@ -228,6 +245,10 @@ typedef struct fod_attn_shape {
    * zero before the first launch (the kernels leave them zero).  NULL = no split across blocks. */
   void* split_ws;
   void* split_tickets;
+  /* fod_attn_bwd only: extra factor on dq1 / dq2 (0 = 1).  The fp8 path hands the backward pass queries that were
+   * multiplied by scale * log2(e) before quantisation (fod_attn_quant_fp8) and calls it with scale = 1 / log2(e):
+   * d/dq = (scale * log2 e) * d/dq'. */
+  float dq_scale;
 } fod_attn_shape;
 #define FOD_ATTN_SPLIT_WS_FLOATS_PER_TILE (8 * 2176)
 
@@ -241,6 +262,22 @@ int fod_attn_bwd(int dtype, const void* q1, const void* k1, const void* q2, cons
                  const void* o, const void* dout, const float* lse2, float* delta /* scratch [B,H,Tq] */,
                  void* dq1, void* dk1, void* dq2, void* dk2, void* dv, const fod_attn_shape* shape,
                  fod_stream_t stream);
+
+/* fp8 attention forward (BASELINE.json configs[4]; csrc/attention_fp8.hip): OCP e4m3 operands with one E8M0 scale per
+ * 32-element block (a token's head slice for q / k, 32 keys of a channel for v), v_mfma_scale_f32_32x32x64_f8f6f4.
+ * bf16 tensors in and out, eval mode (drop_p must be 0), same cores as fod_attn_fwd (transformer.py:404,417,172-178).
+ *   fod_attn_fp8_pack_bytes : sizes of the two caller-owned packs for a shape
+ *   fod_attn_quant_fp8      : q (times scale * log2 e), k, v -> packs; optionally (all or none) contiguous [B,T,H*32]
+ *                             bf16 copies of the DEQUANTISED operands: fod_attn_bwd on those copies with
+ *                             shape.scale = 1 / log2(e), shape.dq_scale = scale * log2(e) is the backward pass --
+ *                             it recomputes the scores from the same quantised operands
+ *   fod_attn_fwd_fp8        : o [B,Tq,H*32] bf16, lse2 f32 [B,H,Tq] from the packs */
+int fod_attn_fp8_pack_bytes(const fod_attn_shape* shape, int parts, size_t* q_bytes, size_t* kv_bytes);
+int fod_attn_quant_fp8(const void* q1, const void* k1, const void* q2, const void* k2, const void* v,
+                       void* q_pack, void* kv_pack, void* q1_deq, void* k1_deq, void* q2_deq, void* k2_deq,
+                       void* v_deq, const fod_attn_shape* shape, fod_stream_t stream);
+int fod_attn_fwd_fp8(const void* q_pack, const void* kv_pack, int parts, void* o, float* lse2,
+                     const fod_attn_shape* shape, fod_stream_t stream);
 
 /* y = LayerNorm(x + residual[row(m)]) * gamma + beta over the last dim D (D % 64 == 0, D <= 1024).
  * row(m) = (res_row_div > 0 ? m / res_row_div : m), then % res_row_mod if > 0.

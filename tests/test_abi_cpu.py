@@ -33,6 +33,35 @@ def test_library_exports_match_header():
     assert L.LIB.fod_abi_version() == L.ABI_VERSION
 
 
+def test_library_owns_no_device_memory_and_scratch_is_the_callers():
+    """VERDICT r2 item 4 / ADVICE r2: no entry point allocates device memory or keeps device state.  The sources hold no
+    hipMalloc / hipMemset / hipDeviceSynchronize outside the host-side LAP solver's pinned buffers; the scratch of the
+    split-K NT launches travels in fod_epilogue, the partial-tile workspace of the long weight gradients is an argument,
+    and the sizes can be queried."""
+    import glob
+    csrc = os.path.join(ROOT, "future-object-detection_amd", "csrc")
+    for path in glob.glob(os.path.join(csrc, "*")):
+        text = open(path).read()
+        if os.path.basename(path) == "lap.cpp":
+            continue
+        for word in ("hipMalloc(", "hipMemset(", "hipDeviceSynchronize("):
+            assert word not in text, (os.path.basename(path), word)
+    from future_od.native import lib as L
+    fields = [f for f, _ in L.Epilogue._fields_]
+    assert fields[-2:] == ["split_ws", "split_tickets"]
+    assert [f for f, _ in L.AttnShape._fields_][-1] == "dq_scale"
+    hdr = open(os.path.join(ROOT, "include", "fod.h")).read()
+    for name in ("fod_gemm_tn_acc", "fod_conv2d_wgrad_acc"):
+        proto = re.search(name + r"\s*\(([^;]*)\);", hdr).group(1)
+        assert "void* ws" in proto and "size_t ws_bytes" in proto, name
+        assert L.SIGNATURES[name][-3:] == [L._p, ctypes.c_size_t, L._p]
+    assert L.LIB.fod_workspace_bytes(L.WS_NT_SPLIT) == 64 * 8 * 4096 * 4
+    assert L.LIB.fod_workspace_bytes(L.WS_NT_SPLIT_TICKETS) == 64 * 4
+    assert L.LIB.fod_workspace_bytes(L.WS_TN_PARTIALS) == 64 << 20
+    assert L.LIB.fod_workspace_bytes(L.WS_ATTN_SPLIT_PER_TILE) == 8 * 2176 * 4
+    assert L.LIB.fod_workspace_bytes(99) == 0
+
+
 def test_error_path_is_loud():
     from future_od.native import lib as L
     from future_od.native import ops

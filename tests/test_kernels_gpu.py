@@ -386,6 +386,128 @@ def test_attention_saturated_softmax_forward_backward_consistency(shape):
         assert err < 3e-2, (name, err)
 
 
+# ------------------------------------------------------------------------------------------------ fp8 attention
+def _mx_e4m3(x, dim):
+    """MX quantise-dequantise along `dim` in blocks of 32 (csrc/attention_fp8.hip: e8m0_for / quant_chunk): one
+    power-of-two scale per block that puts the block's largest magnitude in [128, 256), values to OCP e4m3 by
+    round-to-nearest-even.  x float32; returns float32 (every value is exact in bf16)."""
+    x = x.transpose(dim, -1)
+    shp = x.shape
+    n = shp[-1]
+    pad = (-n) % 32
+    xb = F.pad(x, (0, pad)).reshape(*shp[:-1], (n + pad) // 32, 32)
+    amax = xb.abs().amax(-1, keepdim=True)
+    _, ex = torch.frexp(amax)                               # amax = m 2^ex, m in [0.5, 1): floor(log2 amax) = ex - 1
+    scale = torch.where(amax > 0, torch.ldexp(torch.ones_like(amax), (ex - 1 - 7).clamp(-126, 126)), torch.ones_like(amax))
+    q = (xb / scale).to(torch.float8_e4m3fn).float() * scale
+    return q.reshape(*shp[:-1], n + pad)[..., :n].transpose(dim, -1).contiguous()
+
+
+FP8_SHAPES = [(1, 8, 1450, 1450, 1), (2, 8, 128, 1450, 2), (1, 2, 77, 150, 1), (2, 2, 33, 1, 2), (1, 1, 300, 64, 2),
+              (1, 2, 600, 333, 1)]
+
+
+@pytest.mark.parametrize("peaked", [False, True])
+@pytest.mark.parametrize("shape", FP8_SHAPES)
+def test_attention_fp8_forward_and_backward(shape, peaked):
+    """BASELINE.json configs[4]: MX-fp8 (e4m3, E8M0 block scales) QK^T / PV forward on the encoder shape (1450 x 1450,
+    one part) and the conditional cross-attention shape (128 x 1450, two parts), plus ragged / tiny extents.
+      * the quantiser: the dequantised copies the backward runs on are BIT-EQUAL to the MX quantisation restated in torch;
+      * forward vs fp32 torch on those quantised operands (what remains is P in e4m3, <= 2^-4 relative per probability,
+        and the bf16 output): max |err| <= 6e-2 max|ref|, mean |err| <= 1e-2 max|ref|, lse2 within 0.1 (log2 units);
+      * forward vs fp32 torch on the ORIGINAL operands (the price of fp8): max |err| <= 0.15 max|ref|, mean <= 3e-2;
+      * backward (bf16 kernels on the dequantised operands, the same quantised scores) vs float64 autograd of the
+        quantised-operand attention with straight-through quantisers: relative error of every gradient <= 6e-2.
+    `peaked`: queries x 4, a softmax with a few dominant keys (the averaging that hides P's rounding is gone)."""
+    dtype = torch.bfloat16
+    B, H, Tq, S, parts = shape
+    E = H * 32
+    qs = 4.0 if peaked else 1.0
+    q1, k1, v = rnd((B, Tq, E), dtype, 1, qs), rnd((B, S, E), dtype, 2), rnd((B, S, E), dtype, 3)
+    q2 = rnd((B, Tq, E), dtype, 4, qs) if parts == 2 else None
+    k2 = rnd((B, S, E), dtype, 5) if parts == 2 else None
+    scale = 1.0 / math.sqrt(32 * parts)
+    c = np.float32(scale) * np.float32(1.4426950408889634)
+    g = lambda t: None if t is None else t.to(DEV)
+    o, lse2, deq = ops.attn_fwd_fp8(g(q1), g(k1), g(v), scale, g(q2), g(k2), want_backward=True)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse2).all()
+
+    heads = lambda t: t.view(B, -1, H, 32).transpose(1, 2)                       # [B, H, T, 32]
+    unheads = lambda t: t.transpose(1, 2).reshape(B, -1, E)
+    qd = lambda t: unheads(_mx_e4m3(heads(t.float() * torch.tensor(c)), -1))
+    kd = lambda t: unheads(_mx_e4m3(heads(t.float()), -1))
+    vd = lambda t: unheads(_mx_e4m3(heads(t.float()), -2))                        # blocks of 32 consecutive keys per channel
+    want = (qd(q1), kd(k1), vd(v), None if parts == 1 else qd(q2), None if parts == 1 else kd(k2))
+    for name, got, ref in zip(("q1", "k1", "v", "q2", "k2"), deq, want):
+        if ref is not None:
+            assert torch.equal(got.float().cpu(), ref), (name, float((got.float().cpu() - ref).abs().max()))
+
+    def attend(a1, b1, vv, a2, b2, log2_units):
+        s2 = heads(a1) @ heads(b1).transpose(-1, -2)
+        if a2 is not None:
+            s2 = s2 + heads(a2) @ heads(b2).transpose(-1, -2)
+        s2 = s2 * (1.0 if log2_units else scale * 1.4426950408889634)
+        prob = torch.softmax(s2 * math.log(2.0), dim=-1)
+        return unheads(prob @ heads(vv)), torch.logsumexp(s2 * math.log(2.0), -1) / math.log(2.0)
+
+    # ---- forward against the quantised-operand reference and against the unquantised one
+    leaves = [None if t is None else t.double().requires_grad_(True) for t in (q1, k1, v, q2, k2)]
+
+    def ste(leaf, deq_value, mul):
+        exact = leaf * mul
+        return exact + (deq_value.double() - exact).detach()
+
+    ops_q = [ste(leaves[0], want[0], float(c)), ste(leaves[1], want[1], 1.0), ste(leaves[2], want[2], 1.0),
+             None if parts == 1 else ste(leaves[3], want[3], float(c)), None if parts == 1 else ste(leaves[4], want[4], 1.0)]
+    o_q, lse_q = attend(ops_q[0], ops_q[1], ops_q[2], ops_q[3], ops_q[4], True)
+    with torch.no_grad():
+        o_f, _ = attend(q1.double(), k1.double(), v.double(), None if parts == 1 else q2.double(),
+                        None if parts == 1 else k2.double(), False)
+    got = o.float().cpu().double()
+    for name, ref, mx, mean in (("quantised operands", o_q.detach(), 6e-2, 1e-2), ("original operands", o_f, 0.15, 3e-2)):
+        span = float(ref.abs().max())
+        err = (got - ref).abs()
+        print(f"fp8 attention {shape} peaked={peaked} vs {name}: max {float(err.max()) / span:.3e} mean {float(err.mean()) / span:.3e} of max|ref|")
+        assert float(err.max()) <= mx * span and float(err.mean()) <= mean * span, (name, float(err.max()), float(err.mean()), span)
+    assert float((lse2.cpu().double() - lse_q.detach()).abs().max()) <= 0.1
+
+    # ---- backward: the bf16 kernels on the dequantised operands, scale 1 / log2(e), dq scaled by scale * log2(e)
+    dout = rnd((B, Tq, E), dtype, 6)
+    o_q.backward(dout.double())
+    grads = ops.attn_bwd(deq[0], deq[1], deq[2], o, g(dout), lse2, 1.0 / ops.LOG2E, deq[3], deq[4], dq_scale=float(c))
+    refs = (leaves[0].grad, leaves[1].grad, None if parts == 1 else leaves[3].grad,
+            None if parts == 1 else leaves[4].grad, leaves[2].grad)
+    for name, gk, want_g in zip(("dq1", "dk1", "dq2", "dk2", "dv"), grads, refs):
+        if want_g is None:
+            continue
+        assert torch.isfinite(gk.float()).all(), name
+        rel = float((gk.float().cpu().double() - want_g).norm() / (want_g.norm() + 1e-30))
+        assert rel <= 6e-2, (name, rel)
+
+
+def test_attention_fp8_through_autograd_switch():
+    """The model-level switch (Fn.ATTN_FP8, runs/_model.py attn_dtype): 'long' sends only the long-query launches through
+    the fp8 forward, 'all' every one; gradients flow to the original (unquantised) leaves."""
+    from future_od.native import functional as Fn
+    dtype = torch.bfloat16
+    was = Fn.ATTN_FP8["mode"]
+    try:
+        for mode, Tq, expect in (("long", 700, True), ("long", 128, False), ("all", 128, True), ("off", 700, False)):
+            Fn.ATTN_FP8["mode"] = mode
+            q = rnd((1, Tq, 64), dtype, 1).to(DEV).requires_grad_(True)
+            k = rnd((1, 300, 64), dtype, 2).to(DEV).requires_grad_(True)
+            v = rnd((1, 300, 64), dtype, 3).to(DEV).requires_grad_(True)
+            o = Fn.attention(q, k, v, 1.0 / math.sqrt(32))
+            assert o.grad_fn.fp8 == expect, (mode, Tq)
+            o.float().square().sum().backward()
+            ref = _attn_ref(q.detach().float().cpu(), k.detach().float().cpu(), v.detach().float().cpu(), 1.0 / math.sqrt(32))
+            assert float((o.detach().float().cpu() - ref).abs().max()) <= 0.15 * float(ref.abs().max())
+            for t in (q, k, v):
+                assert t.grad is not None and torch.isfinite(t.grad.float()).all() and float(t.grad.float().abs().max()) > 0
+    finally:
+        Fn.ATTN_FP8["mode"] = was
+
+
 def _drop_keep_mask(B, H, Tq, S, seed, p):
     """The attention kernels' stateless keep decision, restated in numpy (include/fod.h: fod_attn_shape.drop_*)."""
     M = np.uint64(0xFFFFFFFF)
