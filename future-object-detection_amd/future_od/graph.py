@@ -53,6 +53,13 @@ def _stage_inputs(g, data):
             g.setdefault("keep", {})[k] = src        # the id stays unique while the tensor is alive
 
 
+
+class CaptureError(RuntimeError):
+    """The step could not be CAPTURED (raised by GraphedStep / GraphedForward at the first call for a batch signature,
+    with parameters and optimizer state rolled back): the caller may launch eagerly instead.  Errors of a replay are not
+    of this type and are not to be swallowed."""
+
+
 class GraphedStep:
     """step = GraphedStep(model, optimizer);  post, loss, stats, od = step(data)
 
@@ -222,11 +229,39 @@ class GraphedStep:
         Fn.PREP.mark_stale()
 
     def _capture(self, data):
+        # the capture's eager warm-up steps are real optimizer steps: with rollback_warmup they are undone whether the
+        # capture succeeds or not -- a caller that falls back to the eager step after a failed capture must not apply a
+        # batch three or four times
         snap = self._snapshot() if self.rollback_warmup else None
-        out = self._capture_inner(data)
-        if snap is not None:
-            self._restore(snap)
+        try:
+            out = self._capture_inner(data)
+        finally:
+            if snap is not None:
+                self._restore(snap)
+        # the optimizer tables this graph's AdamW node reads: learning-rate changes go into THAT plan (__call__), and
+        # the record keeps it alive for as long as the graph lives
+        out["plan"] = getattr(self.opt, "_launched_plan", None)
         return out
+
+    def _capture_agreed(self, data):
+        """_capture(), with every failure INSIDE the capture (and only those: replay-time errors are not caught anywhere)
+        turned into CaptureError -- after, under data parallel, the ranks have agreed on the outcome: a rank that alone
+        fell back to the eagerly launched step would issue other collectives than its peers."""
+        err, g = None, None
+        try:
+            g = self._capture(data)
+        except Exception as e:                            # noqa: BLE001  (re-raised below as CaptureError)
+            err = e
+        if self.ddp:
+            import torch.distributed as dist
+            dev = next(v for v in data.values() if isinstance(v, torch.Tensor)).device
+            ok = torch.tensor([0.0 if err is not None else 1.0], device=dev if dist.get_backend() != "gloo" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) == 0.0 and err is None:
+                err = RuntimeError("another rank could not capture the step")
+        if err is not None:
+            raise CaptureError(f"{type(err).__name__}: {err}") from err
+        return g
 
     def _capture_inner(self, data):
         self._check(data)
@@ -302,9 +337,12 @@ class GraphedStep:
         sig = self._signature(data)
         g = self._graphs.get(sig)
         if g is None:
-            g = self._graphs[sig] = self._capture(data)
+            g = self._graphs[sig] = self._capture_agreed(data)
+        _check_matcher(g)                                 # a failure of the previous replay's device solver: raised here
         _stage_inputs(g, data)
-        self.opt.sync_hyperparams()
+        self.opt.sync_hyperparams()                       # the current plan (eager steps) ...
+        if g.get("plan") is not None:
+            self.opt.sync_hyperparams(g["plan"])          # ... and the one baked into this graph, if it is another
         import os, time
         dbg = os.environ.get("FOD_GRAPH_TIMING") == "1"
         def tick(label, _t=[time.perf_counter()]):
@@ -346,6 +384,12 @@ class GraphedStep:
         return g["outs"]
 
 
+def _check_matcher(g):
+    from future_od.models.set_criterion import check_device_matcher
+    dev = next(v for v in g["static"].values() if isinstance(v, torch.Tensor)).device
+    check_device_matcher(dev)
+
+
 _WARMUP_STREAMS = {}
 
 
@@ -376,6 +420,27 @@ class GraphedForward:
             post, _state, loss, stats, od = self.model(data=data, distributed=False)
         return post, loss, stats, od
 
+    def _capture(self, data):
+        dev = next(v for v in data.values() if isinstance(v, torch.Tensor)).device
+        static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in data.items()
+                  if k != "_host_annotations"}
+        side = _warmup_stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(self.warmup + 1):
+                # the second pass refreshes every prepared weight copy eagerly: its job table (pinned upload) must
+                # exist before the capture -- nothing may be allocated on the host inside one
+                self._run(static)
+                Fn.PREP.mark_stale()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        Fn.PREP.refresh()                         # the graph reads the prepared weight copies; they are refreshed
+        with torch.cuda.graph(graph):             # eagerly before a replay, and only when a parameter has changed
+            outs = self._run(static)
+        torch.cuda.synchronize(dev)
+        return {"graph": graph, "static": static, "outs": outs}
+
     def __call__(self, data):
         if self.model.training:
             raise RuntimeError("GraphedForward: evaluation only (model.eval()); training steps go through GraphedStep")
@@ -385,25 +450,12 @@ class GraphedForward:
             for k, v in data.items():
                 if isinstance(v, torch.Tensor) and not v.is_cuda:
                     raise RuntimeError(f"GraphedForward: batch entry {k!r} is not on the device")
-            dev = next(v for v in data.values() if isinstance(v, torch.Tensor)).device
-            static = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in data.items()
-                      if k != "_host_annotations"}
-            side = _warmup_stream(dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):
-                for _ in range(self.warmup + 1):
-                    # the second pass refreshes every prepared weight copy eagerly: its job table (pinned upload) must
-                    # exist before the capture -- nothing may be allocated on the host inside one
-                    self._run(static)
-                    Fn.PREP.mark_stale()
-            torch.cuda.current_stream(dev).wait_stream(side)
-            torch.cuda.synchronize(dev)
-            graph = torch.cuda.CUDAGraph()
-            Fn.PREP.refresh()                         # the graph reads the prepared weight copies; they are refreshed
-            with torch.cuda.graph(graph):             # eagerly before a replay, and only when a parameter has changed
-                outs = self._run(static)
-            torch.cuda.synchronize(dev)
-            g = self._graphs[sig] = {"graph": graph, "static": static, "outs": outs}
+            try:
+                g = self._capture(data)
+            except Exception as e:                    # noqa: BLE001
+                raise CaptureError(f"{type(e).__name__}: {e}") from e
+            self._graphs[sig] = g
+        _check_matcher(g)
         _stage_inputs(g, data)
         Fn.PREP.refresh()                             # one launch if an optimizer step happened since, nothing otherwise
         g["graph"].replay()

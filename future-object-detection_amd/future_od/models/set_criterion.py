@@ -214,6 +214,15 @@ def _lap_status(device):
     return _LAP_STATUS[key]
 
 
+def check_device_matcher(device):
+    """Raise the device solver's failure of an EARLIER launch, if its status word has arrived (non-blocking).  Eager steps
+    look at the word before every solve; a replayed graph runs no Python, so future_od/graph.py calls this before each
+    replay: a non-finite cost matrix surfaces one step late there too instead of at the end of the epoch."""
+    st = _LAP_STATUS.get((torch.device(device).type, torch.device(device).index))
+    if st is not None:
+        st.check()
+
+
 def device_matching_enabled(device):
     """The matcher runs entirely on the GPU by default (FOD_DEVICE_MATCH=0: host solver, asynchronous or blocking)."""
     import os

@@ -145,7 +145,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 else:
                     # out of spare slots: the next eager step rebuilds the plan (and its ring); this one's tables are
                     # baked into the capture in progress and stay alive
-                    self._retired_plans = (getattr(self, "_retired_plans", []) + [plan])[-8:]
+                    self._retired_plans = getattr(self, "_retired_plans", []) + [plan]
                     self._plan = None
             else:
                 ev = torch.cuda.Event()
@@ -165,24 +165,24 @@ class FusedAdamW(torch.optim.Optimizer):
     def disable_device_step(self):
         self._dev_step = self._dev_betas = self._bias_dev = None
 
-    def sync_hyperparams(self):
-        """Write changed learning rates / weight decays into the device table IN PLACE (a captured step reads that
-        table; the scheduler only changes the python-side groups).  Returns True if something changed."""
-        plan = getattr(self, "_plan", None)
+    def sync_hyperparams(self, plan=None):
+        """Write changed learning rates / weight decays into a plan's device table IN PLACE (a captured step reads the
+        table of the plan that was current when it was CAPTURED -- `plan`, kept in the graph's record by
+        future_od/graph.py -- which need not be the optimizer's current one any more: an eager step in between may have
+        rebuilt it).  Default: the current plan.  Returns True if something was written."""
+        if plan is None:
+            plan = getattr(self, "_plan", None)
         if plan is None:
             return False
         lrs = [(g["lr"], g["weight_decay"]) for g in self.param_groups]
         if lrs == plan["lrs"]:
             return False
-        rows = []
-        for grp in self.param_groups:
-            for p in grp["params"]:
-                if p.grad is not None:
-                    rows.append((grp["lr"], grp["weight_decay"]))
+        group_of = {id(p): grp for grp in self.param_groups for p in grp["params"]}
+        rows = [(group_of[id(p)]["lr"], group_of[id(p)]["weight_decay"]) for p in plan["params"]]
         assert len(rows) == plan["tab"][2].shape[0], "parameter set changed under a captured step"
         host = torch.tensor(rows, dtype=torch.float32).pin_memory()
         plan["tab"][2].copy_(host, non_blocking=True)
-        self._keep_lr = host
+        plan["keep_lr"] = host                   # the copy reads it when it runs
         plan["lrs"] = lrs
         return True
 
@@ -229,14 +229,16 @@ class FusedAdamW(torch.optim.Optimizer):
             ok = (plan["lrs"] == [(g["lr"], g["weight_decay"]) for g in self.param_groups]
                   and self._refresh_grad_pointers(plan))
             if ok:
+                self._launched_plan = plan
                 self._launch(plan["tab"], plan["dev"], betas, eps)
                 return None
         old_plan = getattr(self, "_plan", None)
         if old_plan is not None:
             # its device tables may be baked into a captured step (future_od/graph.py): kept alive, never freed
-            self._retired_plans = (getattr(self, "_retired_plans", []) + [old_plan])[-8:]
+            self._retired_plans = getattr(self, "_retired_plans", []) + [old_plan]
         plan = self._build_plan()
         self._plan = plan
+        self._launched_plan = plan               # None: the general path below (its tables are not reusable)
         if plan is not None:
             self._launch(plan["tab"], plan["dev"], betas, eps)
             return None
@@ -279,5 +281,5 @@ class FusedAdamW(torch.optim.Optimizer):
         if getattr(self, "_dev_step", None) is not None:              # that baked the old ones in must be re-captured
             self._dev_step.fill_(float(self._step_no))
         if getattr(self, "_plan", None) is not None:
-            self._retired_plans = (getattr(self, "_retired_plans", []) + [self._plan])[-8:]
+            self._retired_plans = getattr(self, "_retired_plans", []) + [self._plan]
         self._plan = None

@@ -6,6 +6,7 @@ import os
 import torch
 import torch.distributed as distrib
 
+from future_od.graph import CaptureError
 from future_od.models.set_criterion import join_matchers
 from future_od.utils.distributed import EXIT, gather_distrib_od_map_stuffs, reduce_distrib_loss
 from future_od.utils.od_map import aggregate_mean_average_precision
@@ -192,8 +193,8 @@ class Trainer:
             if graphed is not None:
                 try:
                     out, loss, stats, od = graphed(data)      # zero_grad + forward + backward + clip + AdamW: one launch
-                except Exception as e:                        # not capturable here: the eager step from now on
-                    print(f"[fod] captured training step unavailable ({type(e).__name__}: {e}); launching eagerly")
+                except CaptureError as e:                     # not capturable here (parameters rolled back, all ranks
+                    print(f"[fod] captured training step unavailable ({e}); launching eagerly")   # agreed): eager from now on
                     self._graphed, graphed = False, None
             if graphed is not None:
                 self._training_iterations += 1
@@ -210,8 +211,8 @@ class Trainer:
                     try:
                         out, loss, stats, od = graphed_eval(data)     # the evaluation pass: one launch
                         done = True
-                    except Exception as e:
-                        print(f"[fod] captured evaluation pass unavailable ({type(e).__name__}: {e}); launching eagerly")
+                    except CaptureError as e:
+                        print(f"[fod] captured evaluation pass unavailable ({e}); launching eagerly")
                         self._graphed_eval, graphed_eval = False, None
                 if not done:
                     out, _state, loss, stats, od = self._model(data=data, visualize=False, epoch=self._epoch,

@@ -82,7 +82,6 @@ def build_model(args, detr_args: SpatioTemporalDETRArgs):
     if attn_dtype is not None:
         # BASELINE.json configs[4]: "fp8" = MX-fp8 QK^T / PV in the long-sequence attention launches (the encoder's
         # self-attention), "fp8-all" = in every attention launch; a process-wide switch of the kernel layer
-        from future_od.native import functional as Fn
         Fn.ATTN_FP8["mode"] = {"bf16": "off", "fp8": "long", "fp8-all": "all"}[attn_dtype]
     core.skip_dead_frames = bool(getattr(args, "skip_dead_frames", True))
     model = SpatioTemporalDETR(args=detr_args, model=core)

@@ -245,3 +245,85 @@ def test_optimizer_state_reload_forces_a_new_capture():
     assert o_g._step_no == 8 and step.replays == 3 and len(step._graphs) == 1
     for got, want in ((l4, le[3]), (l7, le[6]), (l8, le[7])):
         assert abs(got - want) <= 2e-5 * max(abs(want), 1.0), (got, want)
+
+
+def test_learning_rate_changes_reach_the_plan_each_graph_was_captured_with():
+    """a captured step reads the lr / weight-decay table of the optimizer plan that was current at ITS capture.
+    Capture signature A, change the lr, capture signature B (its warm-up rebuilds the plan), change the lr again, replay
+    A: the update must use the new lr -- against the same sequence launched eagerly.  A stale table would move every
+    parameter by the lr difference (8e-5) in that one step."""
+    from future_od.datasets.synthetic import make_batch
+    from future_od.graph import GraphedStep
+    da = make_batch(2, 3, 96, 128, seed=21, max_boxes=9, device=DEV)
+    db = make_batch(1, 3, 96, 128, seed=22, max_boxes=9, device=DEV)           # another batch signature: a second graph
+    m_e, o_e = _build("fp32")
+    m_g, o_g = _build("fp32")
+    step = GraphedStep(m_g, o_g, warmup=2, rollback_warmup=True)               # one update per call, as the Trainer uses it
+    plan = [(da, 1e-4), (db, 5e-5), (da, 2e-5), (db, 1e-5), (da, 1e-4)]
+    for data, lr in plan:
+        for opt in (o_e, o_g):
+            for grp in opt.param_groups:
+                grp["lr"] = lr
+        _eager_step(m_e, o_e, data)
+        step(data)
+    assert len(step._graphs) == 2 and step.replays == len(plan)
+    torch.cuda.synchronize()
+    worst = max(float((pe.detach() - pg.detach()).abs().max()) for pe, pg in zip(m_e.parameters(), m_g.parameters()))
+    assert worst < 3e-5, worst
+    # every plan a graph was captured with is still alive (no [-8:] truncation) and is the one the graph records
+    for g in step._graphs.values():
+        assert g["plan"] is not None and g["plan"]["lrs"][0][0] == 1e-4
+
+
+def test_failed_capture_rolls_the_warmup_steps_back_and_raises_capture_error(monkeypatch):
+    """the capture's eager warm-up steps are real optimizer steps; a capture that fails AFTER them must leave
+    parameters, moments and the step count as they were (the Trainer then runs the eager step on the same batch), and
+    the failure must come out as CaptureError -- the only thing the Trainer's fallback catches."""
+    from future_od.datasets.synthetic import make_batch
+    from future_od.graph import CaptureError, GraphedStep
+    data = make_batch(2, 3, 96, 128, seed=23, max_boxes=9, device=DEV)
+    model, opt = _build("fp32")
+    _eager_step(model, opt, data)                                               # moments exist, step count 1
+    before = [p.detach().clone() for p in model.parameters()]
+    moments = [opt.state[p]["exp_avg"].clone() for p in model.parameters() if p in opt.state and "exp_avg" in opt.state[p]]
+    step = GraphedStep(model, opt, warmup=2, rollback_warmup=True)
+
+    class Boom(RuntimeError):
+        pass
+
+    def broken_graph(*a, **k):
+        raise Boom("no capture today")
+
+    monkeypatch.setattr(torch.cuda, "graph", broken_graph)
+    with pytest.raises(CaptureError, match="Boom"):
+        step(data)
+    monkeypatch.undo()
+    torch.cuda.synchronize()
+    assert opt._step_no == 1
+    for p, b in zip(model.parameters(), before):
+        assert torch.equal(p.detach(), b)
+    now = [opt.state[p]["exp_avg"] for p in model.parameters() if p in opt.state and "exp_avg" in opt.state[p]]
+    assert all(torch.equal(a, b) for a, b in zip(now, moments))
+    # and the object still works: the next call captures and steps once
+    step(data)
+    assert opt._step_no == 2 and step.replays == 1
+
+
+def test_matcher_failure_inside_a_replay_is_raised_at_the_next_call():
+    """the device solver's failure word is only read by Python; a replayed graph runs none.  A batch whose
+    frames are NaN makes the cost matrices non-finite inside the replay: the NEXT call must raise (one step late, as the
+    eager path does), not the end of the epoch."""
+    from future_od.datasets.synthetic import make_batch
+    from future_od.graph import GraphedForward
+    from future_od.native.lib import FodError
+    data = make_batch(2, 3, 96, 128, seed=24, max_boxes=9, device=DEV)
+    model, _ = _build("fp32")
+    fwd = GraphedForward(model)
+    fwd(data)
+    bad = dict(data)
+    bad["video"] = torch.full_like(data["video"], float("nan"))
+    fwd(bad)                                            # replays with NaN frames: the solver flags it on the device
+    torch.cuda.synchronize()
+    with pytest.raises(FodError, match="non-finite"):
+        fwd(data)
+    fwd(data)                                           # the word was cleared: the pass works again

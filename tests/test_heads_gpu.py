@@ -143,6 +143,30 @@ def test_post_proc_and_od_map(golden):
     close(bp, torch.cat([bb[..., :2] - 0.5 * bb[..., 2:], bb[..., :2] + 0.5 * bb[..., 2:]], -1), atol=1e-4)
 
 
+def test_od_map_with_nan_scores_stays_in_range():
+    """Regression (round 2, DESIGN.md 3: "a NaN score must not become a wild index"): fod_od_map ranks by comparisons;
+    NaN scores all claimed rank 0 and left the other slots uninitialised -- a GPU memory fault one kernel after a
+    diverged forward.  NaN ranks last: the launch completes, confidences of real detections stay finite and ordered,
+    every output has its shape, nothing faults."""
+    gg = torch.Generator().manual_seed(3)
+    B, M, C1, N = 2, 128, 9, 12
+    scores = torch.rand(B, M, C1, generator=gg)
+    scores[0, ::3] = float("nan")                       # a third of one sample's detections ...
+    scores[1] = float("nan")                            # ... and all of the other's
+    boxes = torch.rand(B, M, 4, generator=gg) * 100
+    boxes[..., 2:] += boxes[..., :2] + 4
+    ab = torch.rand(B, N, 4, generator=gg) * 100
+    ab[..., 2:] += ab[..., :2] + 4
+    out = ops.od_map(scores.to(DEV), boxes.to(DEV), ab.to(DEV), torch.randint(0, 8, (B, N), generator=gg).to(DEV),
+                     torch.ones(B, N, dtype=torch.int64).to(DEV), (448, 800))
+    torch.cuda.synchronize()
+    confs = out[0].cpu()                                # [T, C1, B * 50]: sample 0 first
+    assert confs.shape == (10, C1, B * 50) and out[1].shape == confs.shape and out[3].shape == (C1, 4)
+    first = confs[0, :, :50]                            # sample 0: 85 finite scores per class -> its top 50 are all finite
+    assert torch.isfinite(first).all() and (first[:, :-1] >= first[:, 1:]).all()
+    assert int(out[3].sum()) >= 0
+
+
 def test_group_linear_function_matches_separate_linears():
     """GroupLinearFn (one launch for P Linear layers of one input, bf16) against P LinearFn calls: same outputs
     and gradients up to bf16 rounding of the differently ordered sums; unused outputs get zero gradient."""

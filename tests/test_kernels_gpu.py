@@ -415,7 +415,8 @@ def test_attention_fp8_forward_and_backward(shape, peaked):
       * the quantiser: the dequantised copies the backward runs on are BIT-EQUAL to the MX quantisation restated in torch;
       * forward vs fp32 torch on those quantised operands (what remains is P in e4m3, <= 2^-4 relative per probability,
         and the bf16 output): max |err| <= 6e-2 max|ref|, mean |err| <= 1e-2 max|ref|, lse2 within 0.1 (log2 units);
-      * forward vs fp32 torch on the ORIGINAL operands (the price of fp8): max |err| <= 0.15 max|ref|, mean <= 3e-2;
+      * forward vs fp32 torch on the ORIGINAL operands (the price of fp8: e4m3 queries / keys move a score of magnitude
+        s by up to ~3 % of s): max |err| <= 0.15 max|ref| (0.3 for the peaked case), mean <= 3e-2;
       * backward (bf16 kernels on the dequantised operands, the same quantised scores) vs float64 autograd of the
         quantised-operand attention with straight-through quantisers: relative error of every gradient <= 6e-2.
     `peaked`: queries x 4, a softmax with a few dominant keys (the averaging that hides P's rounding is gone)."""
@@ -464,7 +465,8 @@ def test_attention_fp8_forward_and_backward(shape, peaked):
         o_f, _ = attend(q1.double(), k1.double(), v.double(), None if parts == 1 else q2.double(),
                         None if parts == 1 else k2.double(), False)
     got = o.float().cpu().double()
-    for name, ref, mx, mean in (("quantised operands", o_q.detach(), 6e-2, 1e-2), ("original operands", o_f, 0.15, 3e-2)):
+    for name, ref, mx, mean in (("quantised operands", o_q.detach(), 6e-2, 1e-2),
+                                ("original operands", o_f, 0.3 if peaked else 0.15, 3e-2)):
         span = float(ref.abs().max())
         err = (got - ref).abs()
         print(f"fp8 attention {shape} peaked={peaked} vs {name}: max {float(err.max()) / span:.3e} mean {float(err.mean()) / span:.3e} of max|ref|")
@@ -967,3 +969,56 @@ def test_wgrad_queue_in_autograd():
                 assert torch.equal(a, b), i
             else:
                 assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-3), i
+
+
+def test_first_calls_from_two_threads():
+    """autograd's backward thread and the launching thread can both make a kernel's FIRST call (the
+    once-per-device raising of a dynamic-LDS limit, the per-stream scratch buffers of native/ops.py).  A fresh process,
+    two threads on two streams, each making first calls of the 8-wave LDS-DMA kernels (conv weight gradient with
+    partial tiles, deep NT GEMM) and of a split-K NT launch at the same time; results against the same calls made
+    serially afterwards."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, threading, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+from future_od.native import ops
+from future_od.native.lib import ConvGeom
+dev = torch.device("cuda", 0)
+g = torch.Generator().manual_seed(0)
+x = torch.randn(2, 57, 100, 256, generator=g).to(torch.bfloat16).to(dev)
+dy = torch.randn(2, 57, 100, 256, generator=g).to(torch.bfloat16).to(dev)
+geom = ConvGeom(2, 57, 100, 256, 57, 100, 256, 3, 3, 1, 1)
+a = torch.randn(4096, 2048, generator=g).to(torch.bfloat16).to(dev)
+b = torch.randn(512, 2048, generator=g).to(torch.bfloat16).to(dev)
+a2 = torch.randn(256, 2048, generator=g).to(torch.bfloat16).to(dev)
+b2 = torch.randn(256, 2048, generator=g).to(torch.bfloat16).to(dev)
+torch.cuda.synchronize()
+def work():
+    dw = torch.zeros(256, 3, 3, 256, device=dev)
+    ops.conv2d_wgrad_acc(dy, x, dw, geom, zeroed=True)
+    return dw, ops.gemm_nt(a, b), ops.gemm_nt(a2, b2)
+out, err = [None, None], []
+barrier = threading.Barrier(2)
+def run(i):
+    try:
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            barrier.wait()
+            out[i] = work()
+            torch.cuda.synchronize()
+    except Exception as e:
+        err.append(repr(e))
+ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+[t.start() for t in ts]; [t.join() for t in ts]
+assert not err, err
+ref = work(); torch.cuda.synchronize()
+for i in range(2):
+    for got, want in zip(out[i], ref):
+        assert torch.equal(got, want), (i, float((got.float() - want.float()).abs().max()))
+print("TWO_THREADS_OK")
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code, root, os.path.join(root, "future-object-detection_amd")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "TWO_THREADS_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
