@@ -7,7 +7,8 @@
     (BASELINE.json north_star: "within 1e-3 rel fp32"); Hungarian indices bit-exact against the oracle's matcher
     (scipy) on the PRODUCT's own outputs, and their agreement with the oracle's end-to-end indices is printed.
   * bf16 mode (the benched dtype) at the same extent: its deviation from the fp32 oracle is MEASURED, printed and
-    held to the bounds DESIGN.md states (logits <= 6e-2 of range, boxes <= 2e-2 abs, loss <= 5 %).
+    held to the bounds DESIGN.md states (logits <= 1.5e-2 of range, boxes <= 1e-2 abs, loss <= 0.5 %; measured on the
+    box: 3.6e-3, 2.2e-3, 4e-5).
 
 The oracle needs ~10-20 s of the box's host cores for this one forward; it runs once per session (module fixture)."""
 import pytest
@@ -86,6 +87,6 @@ def test_bf16_mode_deviation_at_the_headline_extent(reference):
     rel_loss = abs(loss - ref_loss) / abs(ref_loss)
     print(f"bf16 vs fp32 oracle at 900x1600: logits max {e_l:.3e} mean {m_l:.3e} (range {s_l:.3e}: {e_l / s_l:.2e}), "
           f"boxes max {e_b:.3e} mean {m_b:.3e}, loss {loss:.5f} vs {ref_loss:.5f} ({rel_loss:.2e})")
-    assert e_l <= 6e-2 * s_l
-    assert e_b <= 2e-2
-    assert rel_loss <= 5e-2
+    assert e_l <= 1.5e-2 * s_l
+    assert e_b <= 1e-2
+    assert rel_loss <= 5e-3

@@ -311,7 +311,7 @@ def test_failed_capture_rolls_the_warmup_steps_back_and_raises_capture_error(mon
 
 def test_matcher_failure_inside_a_replay_is_raised_at_the_next_call():
     """the device solver's failure word is only read by Python; a replayed graph runs none.  A batch whose
-    frames are NaN makes the cost matrices non-finite inside the replay: the NEXT call must raise (one step late, as the
+    annotated boxes are NaN makes the cost matrices non-finite inside the replay: the NEXT call must raise (one step late, as the
     eager path does), not the end of the epoch."""
     from future_od.datasets.synthetic import make_batch
     from future_od.graph import GraphedForward
@@ -320,9 +320,9 @@ def test_matcher_failure_inside_a_replay_is_raised_at_the_next_call():
     model, _ = _build("fp32")
     fwd = GraphedForward(model)
     fwd(data)
-    bad = dict(data)
-    bad["video"] = torch.full_like(data["video"], float("nan"))
-    fwd(bad)                                            # replays with NaN frames: the solver flags it on the device
+    bad = {k: v for k, v in data.items() if k != "_host_annotations"}
+    bad["boxes"] = torch.full_like(data["boxes"], float("nan"))       # NaN annotations -> NaN L1 / GIoU costs
+    fwd(bad)                                            # (NaN frames would not do: the first ReLU turns NaN into 0)
     torch.cuda.synchronize()
     with pytest.raises(FodError, match="non-finite"):
         fwd(data)
