@@ -60,6 +60,19 @@ class CaptureError(RuntimeError):
     of this type and are not to be swallowed."""
 
 
+class _Bf16Pending:
+    """An asynchronous bf16 all-reduce whose result still has to go back into the f32 gradient tensor."""
+
+    def __init__(self, work, buf, dst, scale):
+        self.work, self.buf, self.dst, self.scale = work, buf, dst, scale
+
+    def wait(self):
+        self.work.wait()
+        self.dst.copy_(self.buf)
+        if self.scale != 1.0:
+            self.dst.mul_(self.scale)
+
+
 class GraphedStep:
     """step = GraphedStep(model, optimizer);  post, loss, stats, od = step(data)
 
@@ -96,6 +109,8 @@ class GraphedStep:
         # rehearsed on RCCL here.
         import os
         self.overlap = os.environ.get("FOD_GRAPH_OVERLAP", "0") == "1"
+        self.grad_bf16 = os.environ.get("FOD_GRAD_BF16", "0") == "1"
+        self._bf16_bufs = {}
 
     def broadcast_parameters(self, src=0):
         """Rank `src`'s parameters and buffers to every rank (what DistributedDataParallel's constructor does)."""
@@ -163,6 +178,8 @@ class GraphedStep:
 
     def _all_reduce(self, t, average=True, async_op=False):
         group = self.group
+        if self.grad_bf16 and average and t.dtype == torch.float32 and t.numel() >= (1 << 16):
+            return self._all_reduce_bf16(t, async_op)
         if average and self._native_avg():
             return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
         # gloo (rehearsal on one GPU): sum, then scale (an asynchronous call leaves the scaling to its caller).  The
@@ -174,6 +191,29 @@ class GraphedStep:
         if average and not async_op:
             t.div_(self.world)
         return work
+
+    def _all_reduce_bf16(self, t, async_op):
+        """FOD_GRAD_BF16=1 ("bf16 gradient buckets halve it to 107.8 MB"): the large f32 gradient tensors
+        travel as bf16 -- cast, average, cast back into the f32 tensor the optimizer reads.  Every rank ends with the
+        SAME f32 values (the average of the ranks' bf16-rounded gradients, rounded to bf16 once more by the collective's
+        output type), so replicas stay bit-equal; what changes is the gradient's precision (8 significant bits), which
+        is why this is a switch and not the default."""
+        buf = self._bf16_bufs.get(t.data_ptr())
+        if buf is None or buf.numel() != t.numel():
+            buf = self._bf16_bufs[t.data_ptr()] = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+        buf.copy_(t)
+        if self._native_avg():
+            work = dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+        else:
+            if not async_op:
+                torch.cuda.current_stream(t.device).synchronize()
+            work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        if async_op:
+            return _Bf16Pending(work, buf, t, 1.0 if self._native_avg() else 1.0 / self.world)
+        t.copy_(buf)
+        if not self._native_avg():
+            t.div_(self.world)
+        return None
 
     def _reduce_targets(self, arena_from=0, skip=()):
         """What a captured backward piece leaves to be averaged: the arena region that holds gradients as ONE flat tensor
@@ -372,11 +412,10 @@ class GraphedStep:
                 if sync:
                     for t in g["targets_bb"]:
                         self._all_reduce(t)
-                    for w in pending:
+                    for w, t in zip(pending, g["targets"]):
                         w.wait()                     # stream-ordered for RCCL: the launching stream waits, not the host
-                    if pending and not self._native_avg():
-                        for t in g["targets"]:
-                            t.div_(self.world)
+                        if not self._native_avg() and not isinstance(w, _Bf16Pending):
+                            t.div_(self.world)       # (gloo sums; a bf16 hand-off scales in its own wait)
             g["graph_opt"].replay()
         self.opt._step_no += 1
         self.replays += 1

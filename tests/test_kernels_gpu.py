@@ -418,7 +418,7 @@ def test_attention_fp8_forward_and_backward(shape, peaked):
       * forward vs fp32 torch on the ORIGINAL operands (the price of fp8: e4m3 queries / keys move a score of magnitude
         s by up to ~3 % of s): max |err| <= 0.15 max|ref| (0.3 for the peaked case), mean <= 3e-2;
       * backward (bf16 kernels on the dequantised operands, the same quantised scores) vs float64 autograd of the
-        quantised-operand attention with straight-through quantisers: relative error of every gradient <= 6e-2.
+        quantised-operand attention with straight-through quantisers: ||error|| <= 6e-2 ||gradient|| (+ 1e-2 per element).
     `peaked`: queries x 4, a softmax with a few dominant keys (the averaging that hides P's rounding is gone)."""
     dtype = torch.bfloat16
     B, H, Tq, S, parts = shape
@@ -483,8 +483,9 @@ def test_attention_fp8_forward_and_backward(shape, peaked):
         if want_g is None:
             continue
         assert torch.isfinite(gk.float()).all(), name
-        rel = float((gk.float().cpu().double() - want_g).norm() / (want_g.norm() + 1e-30))
-        assert rel <= 6e-2, (name, rel)
+        # (the floor: with a single key the exact query gradient is zero and only rounding noise is left)
+        err_n, want_n = float((gk.float().cpu().double() - want_g).norm()), float(want_g.norm())
+        assert err_n <= 6e-2 * want_n + 1e-2 * math.sqrt(want_g.numel()), (name, err_n, want_n)
 
 
 def test_attention_fp8_through_autograd_switch():

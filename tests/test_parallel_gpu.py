@@ -191,11 +191,14 @@ def _graph_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", ["0", "1"])
-def test_two_ranks_captured_step_matches_eager_data_parallel(overlap, monkeypatch):
+@pytest.mark.parametrize("overlap,grad_bf16", [("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")])
+def test_two_ranks_captured_step_matches_eager_data_parallel(overlap, grad_bf16, monkeypatch):
     """overlap = "1": the captured backward split at the backbone's output, the transformer's gradients all-reduced
-    asynchronously while the backbone's backward graph runs (FOD_GRAPH_OVERLAP, off by default)."""
+    asynchronously while the backbone's backward graph runs (FOD_GRAPH_OVERLAP).  grad_bf16 = "1": the large gradient
+    tensors travel as bf16 (FOD_GRAD_BF16, half the bytes): the ranks must still end BIT-EQUAL; against the f32-averaged
+    eager reference the parameters then differ by the gradients' bf16 rounding through Adam's normalisation."""
     monkeypatch.setenv("FOD_GRAPH_OVERLAP", overlap)
+    monkeypatch.setenv("FOD_GRAD_BF16", grad_bf16)
     import torch.multiprocessing as mp
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
@@ -218,7 +221,7 @@ def test_two_ranks_captured_step_matches_eager_data_parallel(overlap, monkeypatc
     for rank, worst, spread, losses, comm, replays in res:
         assert replays == 7
         assert spread == 0.0, (rank, spread)                   # every rank applied the same averaged gradients
-        assert worst < 5e-4, (rank, worst)                     # fp32: atomics' summation order through Adam's normalisation
+        assert worst < (5e-4 if grad_bf16 == "0" else 5e-3), (rank, worst)   # fp32: atomics' summation order through Adam's normalisation
         assert comm["tensors"] >= 1 and comm["bytes"] > 1 << 20, comm
         assert all(l == l and abs(l) < 1e6 for l in losses), losses
     assert res[0][4] == res[1][4]                              # same all-reduce layout on both ranks
