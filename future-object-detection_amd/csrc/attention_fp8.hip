@@ -154,50 +154,69 @@ __global__ __launch_bounds__(256) void attn_quant_fp8_kernel(const Fp8Params p) 
       if (deq_out && valid) *reinterpret_cast<bf16x8_t*>(dk + ((long)b * p.S + key) * E + head * 32 + 8 * j) = deq;
     }
   }
-  // ---- values: one thread per channel, 64 keys in registers; an MX block = 32 consecutive keys of one channel
-  for (int ch = tid; ch < E; ch += 256) {
-    const int head = ch >> 5, d = ch & 31;
-    const __bf16* src = p.v + (long)b * p.v_bs + ch;
-    float x[64];
+  // ---- values: the 64 x 256-channel tile goes through LDS (16-byte global accesses both ways); one thread per channel
+  // then owns a column: an MX block = 32 consecutive keys of one channel
+  __shared__ __attribute__((aligned(16))) __bf16 vt[64][256];
+  for (int c0 = 0; c0 < E; c0 += 256) {
+    const int cw = min(256, E - c0), cpr = cw >> 3;                // channels in this pass, 16-byte chunks per row
+    __syncthreads();
+    for (int it = tid; it < 64 * cpr; it += 256) {
+      const int row = it / cpr, c8 = it - row * cpr;
+      bf16x8_t v8;
 #pragma unroll
-    for (int k = 0; k < 64; ++k) x[k] = (k0 + k < p.S) ? (float)src[(long)(k0 + k) * p.v_ts] : 0.f;
-    unsigned char* rec = p.kvpack + (((long)b * p.H + head) * p.nkt + kt) * REC;
-    int byte[2];
-    float inv[2], up[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {                 // MX block s = keys 32 s .. 32 s + 31 of this channel
-      float amax = 0.f;
-#pragma unroll
-      for (int k = 0; k < 32; ++k) amax = fmaxf(amax, fabsf(x[32 * s + k]));
-      amax = fminf(amax, 3.0e38f);
-      byte[s] = e8m0_for(amax);
-      inv[s] = inv_pow2_of_byte(byte[s]);
-      up[s] = pow2_of_byte(byte[s]);
-      rec[rec_vscale(p.parts) + d * 2 + s] = (unsigned char)byte[s];
+      for (int i = 0; i < 8; ++i) v8[i] = (__bf16)0.f;
+      if (k0 + row < p.S) v8 = *reinterpret_cast<const bf16x8_t*>(p.v + (long)b * p.v_bs + (long)(k0 + row) * p.v_ts + c0 + 8 * c8);
+      *reinterpret_cast<bf16x8_t*>(&vt[row][8 * c8]) = v8;
     }
+    __syncthreads();
+    if (tid < cw) {
+      const int ch = c0 + tid, head = ch >> 5, d = ch & 31;
+      float x[64];
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      int w[8];
+      for (int k = 0; k < 64; ++k) x[k] = (float)vt[k][tid];
+      unsigned char* rec = p.kvpack + (((long)b * p.H + head) * p.nkt + kt) * REC;
+      int byte[2];
+      float inv[2], up[2];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float f = inv[i >> 2];             // bytes 4 i .. 4 i + 3 belong to block (4 i) >> 4
-        w[i] = pack4(x[kappa8(hh, 4 * i)] * f, x[kappa8(hh, 4 * i + 1)] * f, x[kappa8(hh, 4 * i + 2)] * f, x[kappa8(hh, 4 * i + 3)] * f);
+      for (int s = 0; s < 2; ++s) {                 // MX block s = keys 32 s .. 32 s + 31 of this channel
+        float amax = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) amax = fmaxf(amax, fabsf(x[32 * s + k]));
+        amax = fminf(amax, 3.0e38f);
+        byte[s] = e8m0_for(amax);
+        inv[s] = inv_pow2_of_byte(byte[s]);
+        up[s] = pow2_of_byte(byte[s]);
+        rec[rec_vscale(p.parts) + d * 2 + s] = (unsigned char)byte[s];
       }
-      unsigned char* img = rec + p.parts * 2048;
-      *reinterpret_cast<int4*>(img + vimg_at(d, 2 * hh)) = make_int4(w[0], w[1], w[2], w[3]);
-      *reinterpret_cast<int4*>(img + vimg_at(d, 2 * hh + 1)) = make_int4(w[4], w[5], w[6], w[7]);
-      if (deq_out) {
-        typedef __attribute__((ext_vector_type(2))) float f32x2;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        int w[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], true);
-          const float y[4] = {lo[0], lo[1], hi[0], hi[1]};
+          const float f = inv[i >> 2];             // bytes 4 i .. 4 i + 3 belong to block (4 i) >> 4
+          w[i] = pack4(x[kappa8(hh, 4 * i)] * f, x[kappa8(hh, 4 * i + 1)] * f, x[kappa8(hh, 4 * i + 2)] * f, x[kappa8(hh, 4 * i + 3)] * f);
+        }
+        unsigned char* img = rec + p.parts * 2048;
+        *reinterpret_cast<int4*>(img + vimg_at(d, 2 * hh)) = make_int4(w[0], w[1], w[2], w[3]);
+        *reinterpret_cast<int4*>(img + vimg_at(d, 2 * hh + 1)) = make_int4(w[4], w[5], w[6], w[7]);
+        if (deq_out) {
+          typedef __attribute__((ext_vector_type(2))) float f32x2;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int key = k0 + kappa8(hh, 4 * i + e);
-            if (key < p.S) p.vd[((long)b * p.S + key) * E + ch] = (__bf16)(y[e] * up[i >> 2]);
+          for (int i = 0; i < 8; ++i) {
+            const f32x2 lo = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(w[i], true);
+            const float y[4] = {lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vt[kappa8(hh, 4 * i + e)][tid] = (__bf16)(y[e] * up[i >> 2]);
           }
         }
+      }
+    }
+    if (deq_out) {
+      __syncthreads();
+      for (int it = tid; it < 64 * cpr; it += 256) {
+        const int row = it / cpr, c8 = it - row * cpr;
+        if (k0 + row < p.S)
+          *reinterpret_cast<bf16x8_t*>(p.vd + ((long)b * p.S + k0 + row) * E + c0 + 8 * c8) = *reinterpret_cast<const bf16x8_t*>(&vt[row][8 * c8]);
       }
     }
   }

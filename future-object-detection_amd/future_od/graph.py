@@ -109,6 +109,7 @@ class GraphedStep:
         # rehearsed on RCCL here.
         import os
         self.overlap = os.environ.get("FOD_GRAPH_OVERLAP", "0") == "1"
+        self.overlap_mode = os.environ.get("FOD_GRAPH_OVERLAP_MODE", "async")     # "after": experiment, see __call__
         self.grad_bf16 = os.environ.get("FOD_GRAD_BF16", "0") == "1"
         self._bf16_bufs = {}
 
@@ -400,7 +401,9 @@ class GraphedStep:
         if self.ddp:
             pending = []
             if sync:
-                if g["graph_bb"] is not None:
+                if g["graph_bb"] is not None and self.overlap_mode == "after":
+                    pass                             # (experiment: split graphs, every collective behind A2)
+                elif g["graph_bb"] is not None:
                     # issued behind graph A1 on the collective's own stream: runs while graph A2 does
                     pending = [self._all_reduce(t, async_op=True) for t in g["targets"]]
                 else:
@@ -410,6 +413,9 @@ class GraphedStep:
             if g["graph_bb"] is not None:
                 g["graph_bb"].replay()
                 if sync:
+                    if self.overlap_mode == "after":
+                        for t in g["targets"]:
+                            self._all_reduce(t)
                     for t in g["targets_bb"]:
                         self._all_reduce(t)
                     for w, t in zip(pending, g["targets"]):

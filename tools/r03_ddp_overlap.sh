@@ -9,7 +9,7 @@ for rep in 1 2; do
     FOD_GRAPH_OVERLAP=$ov timeout -k 10 300 $B > $out/ddp_ov${ov}_rep${rep}.json 2> $out/ddp_ov${ov}_rep${rep}.err || { tail -20 $out/ddp_ov${ov}_rep${rep}.err; exit 1; }
     python - <<PY
 import json
-d = json.load(open("$out/ddp_ov${ov}_rep${rep}.json"))
+d = json.loads(open("$out/ddp_ov${ov}_rep${rep}.json").read().strip().splitlines()[-1])
 print("overlap=$ov rep=$rep ms/step", round(d["ms_per_step"], 3), d.get("ddp", {}).get("mode", "")[:60])
 PY
   done
@@ -19,4 +19,4 @@ for ov in 0 1; do
   grep "graph timing" $out/ddp_timing_ov${ov}.log | tail -12
 done
 FOD_GRAD_BF16=1 timeout -k 10 300 $B > $out/ddp_bf16grads.json 2> $out/ddp_bf16grads.err || { tail -20 $out/ddp_bf16grads.err; exit 1; }
-python -c "import json; d=json.load(open('$out/ddp_bf16grads.json')); print('bf16 gradient all-reduce ms/step', round(d['ms_per_step'],3))"
+python -c "import json; d=json.loads(open('$out/ddp_bf16grads.json').read().strip().splitlines()[-1]); print('bf16 gradient all-reduce ms/step', round(d['ms_per_step'],3))"
