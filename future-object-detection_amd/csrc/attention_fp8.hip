@@ -27,6 +27,8 @@
 //   2. fod_attn_fwd_fp8: the attention forward over those images.
 // P is quantised with a fixed block scale 2^-SHIFT (stored value = p 2^SHIFT <= 256 < 448 = e4m3 max); the running
 // maximum is deferred by at most THR = 4 so p <= 16.  Smallest non-zero p: 2^-9-SHIFT = 2^-13 of the row's maximum.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -223,13 +225,16 @@ __global__ __launch_bounds__(256) void attn_quant_fp8_kernel(const Fp8Params p) 
 }
 
 // ------------------------------------------------------------------------------------------------
-// 8 waves = 256 queries per block, 64-key tiles staged once per block by a linear register-staged copy of the tile's
-// record (double-buffered, one barrier per tile, next tile's loads in flight during the arithmetic).
-template <int PARTS>
+// 8 waves = 256 queries per block; ST 64-key tiles per STAGE, staged once per block by a linear register-staged copy of
+// the tiles' records (double-buffered, one barrier per stage, next stage's loads in flight during the arithmetic).
+// ST = 2: half the barriers, and between two barriers the eight waves may drift apart by a tile -- they otherwise move
+// in lockstep and want the matrix pipe, then the vector pipe, all at the same time.
+template <int PARTS, int ST>
 __global__ __launch_bounds__(512, PARTS == 1 ? 4 : 3) void attn_fwd_fp8_kernel(const Fp8Params p) {
   constexpr int NW = 8, NT = NW * 64;
-  constexpr int REC = rec_bytes(PARTS), NCH = REC / 16;
-  static_assert(NCH <= NT, "one 16-byte chunk per thread");
+  constexpr int REC = rec_bytes(PARTS), NCH = ST * REC / 16;
+  static_assert(NCH <= 2 * NT, "at most two 16-byte chunks per thread");
+  constexpr bool TWO = NCH > NT;
   constexpr float THR = 4.f, SHIFT = 4.f;
   constexpr int SP = 127 - 4;                    // E8M0 of the P^T blocks: stored value = p * 2^SHIFT
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(512, PARTS == 1 ? 4 : 3) void attn_fwd_fp8_kernel(c
   const int h = blockIdx.y, b = blockIdx.z;
   const bool active = q0 < p.Tq;
   const int q = min(q0 + fr, p.Tq - 1);
-  __shared__ __attribute__((aligned(16))) unsigned char tiles[2][REC];
+  __shared__ __attribute__((aligned(16))) unsigned char tiles[2][ST * REC];
 
   // Q^T operand: bytes 0..15 = this lane-half's 16 channels of part 1, bytes 16..31 = of part 2 (zeros when there is one
   // part: the K side's second block may then hold anything finite)
@@ -253,90 +258,110 @@ __global__ __launch_bounds__(512, PARTS == 1 ? 4 : 3) void attn_fwd_fp8_kernel(c
     bq = i32x8{a.x, a.y, a.z, a.w, c2.x, c2.y, c2.z, c2.w};
     sq = p.qpack[(long)p.B * p.H * p.Tq * PARTS * 32 + slot * PARTS + (PARTS == 2 ? fh : 0)];   // lane-half s: block s
   }
-  i32x8 ones;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) ones[i] = fr == 0 ? 0x38383838 : 0;      // e4m3 1.0 in row 0, both key blocks
+  const int one_word = fr == 0 ? 0x38383838 : 0;                        // e4m3 1.0 in row 0, both key blocks
 
-  const unsigned char* rec0 = p.kvpack + ((long)b * p.H + h) * p.nkt * REC + (size_t)min(tid, NCH - 1) * 16;
-  unsigned char* dst0 = &tiles[0][0] + min(tid, NCH - 1) * 16;       // threads past the record repeat its last chunk
-  uint4 pre;
-  auto request = [&](int kt) { pre = *reinterpret_cast<const uint4*>(rec0 + (size_t)kt * REC); };
-  auto commit = [&](int buf) { *reinterpret_cast<uint4*>(dst0 + buf * REC) = pre; };
+  // chunk c of stage st = bytes [16 c, 16 c + 16) of the stage's ST consecutive records.  The last stage may hold fewer
+  // tiles than ST: its loads then run into the next (b, h) pair's records or the pack's trailing pad record
+  // (fod_attn_fp8_pack_bytes adds one) and land on a tile nobody reads -- every load stays unconditional and unclamped.
+  const int c_a = min(tid, NCH - 1), c_b = min(tid + NT, NCH - 1);
+  const unsigned char* src_a = p.kvpack + ((long)b * p.H + h) * p.nkt * REC + (size_t)c_a * 16;
+  const unsigned char* src_b = p.kvpack + ((long)b * p.H + h) * p.nkt * REC + (size_t)c_b * 16;
+  unsigned char* dst_a = &tiles[0][0] + c_a * 16;
+  unsigned char* dst_b = &tiles[0][0] + c_b * 16;
+  uint4 pre_a, pre_b = make_uint4(0, 0, 0, 0);
+  auto request = [&](int st) {
+    pre_a = *reinterpret_cast<const uint4*>(src_a + (size_t)st * (ST * REC));
+    if (TWO) pre_b = *reinterpret_cast<const uint4*>(src_b + (size_t)st * (ST * REC));
+  };
+  auto commit = [&](int buf) {
+    *reinterpret_cast<uint4*>(dst_a + buf * (ST * REC)) = pre_a;
+    if (TWO) *reinterpret_cast<uint4*>(dst_b + buf * (ST * REC)) = pre_b;
+  };
 
   float negm = 0.f;
   f32x16 NEGMB, oacc, lacc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { NEGMB[r] = SHIFT; oacc[r] = 0.f; lacc[r] = 0.f; }
 
-  const int nkt = p.nkt;
+  const int nkt = p.nkt, nst = (nkt + ST - 1) / ST;
   request(0);
   commit(0);
-  if (nkt > 1) request(1);
+  if (nst > 1) request(1);
   __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const unsigned char* T = &tiles[kt & 1][0];
+  for (int st = 0; st < nst; ++st) {
     if (active) {
-      const int k0 = kt * 64;
-      f32x16 sacc[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int row = 32 * t + fr;
-        const int4 a0 = *reinterpret_cast<const int4*>(T + kimg_at(row, fh));
-        int4 a1 = a0;
-        if (PARTS == 2) a1 = *reinterpret_cast<const int4*>(T + 2048 + kimg_at(row, fh));
-        const i32x8 ak = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-        const int sk = T[rec_kscale(PARTS) + (PARTS == 2 ? fh * 64 : 0) + row];          // lane-half s supplies block s
-        sacc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ak, bq, NEGMB, 0, 0, 0, sk, 0, sq);
-      }
-      if (k0 + 64 > p.S) {                         // last tile only: keys past S (zero rows in the images)
+      for (int u = 0; u < ST; ++u) {
+        const int kt = st * ST + u;
+        if (kt >= nkt) break;
+        const unsigned char* T = &tiles[st & 1][0] + u * REC;
+        const int k0 = kt * 64;
+        f32x16 sacc[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (k0 + 32 * t + acc_row(r, lane) >= p.S) sacc[t][r] = -INFINITY;
-      }
-      float mxa[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) mxa[u] = fmaxf(sacc[0][u], sacc[1][u]);
-#pragma unroll
-      for (int r = 4; r < 16; ++r) mxa[r & 3] = fmaxf(fmaxf(mxa[r & 3], sacc[0][r]), sacc[1][r]);
-      float mx = fmaxf(fmaxf(mxa[0], mxa[1]), fmaxf(mxa[2], mxa[3]));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      if (kt == 0 || __any(mx > THR + SHIFT)) {
-        // raise the running maximum (see attn_fwd_lds_kernel): O, l, the bias and this tile's scores move together;
-        // the first tile sets it exactly and leaves the still-zero O / l alone
-        const float d = kt == 0 ? mx - SHIFT : fmaxf(mx - SHIFT, 0.f);
-        if (kt != 0) {
-          const float alpha = ex2f(-d);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
-          lacc[0] *= alpha;
+        for (int t = 0; t < 2; ++t) {
+          const int row = 32 * t + fr;
+          const int4 a0 = *reinterpret_cast<const int4*>(T + kimg_at(row, fh));
+          int4 a1 = a0;
+          if (PARTS == 2) a1 = *reinterpret_cast<const int4*>(T + 2048 + kimg_at(row, fh));
+          const i32x8 ak = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          const int sk = T[rec_kscale(PARTS) + (PARTS == 2 ? fh * 64 : 0) + row];          // lane-half s supplies block s
+          sacc[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ak, bq, NEGMB, 0, 0, 0, sk, 0, sq);
         }
-        negm -= d;
+        if (k0 + 64 > p.S) {                         // last tile only: keys past S (zero rows in the images)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) NEGMB[r] = negm + SHIFT;
+          for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int r = 0; r < 16; ++r)
+              if (k0 + 32 * t + acc_row(r, lane) >= p.S) sacc[t][r] = -INFINITY;
+        }
+        float mxa[4];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) sacc[t][r] -= d;
+        for (int w4 = 0; w4 < 4; ++w4) mxa[w4] = fmaxf(sacc[0][w4], sacc[1][w4]);
+#pragma unroll
+        for (int r = 4; r < 16; ++r) mxa[r & 3] = fmaxf(fmaxf(mxa[r & 3], sacc[0][r]), sacc[1][r]);
+        float mx = fmaxf(fmaxf(mxa[0], mxa[1]), fmaxf(mxa[2], mxa[3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (kt == 0 || __any(mx > THR + SHIFT)) {
+          // raise the running maximum (see attn_fwd_lds_kernel): O, l, the bias and this tile's scores move together;
+          // the first tile sets it exactly and leaves the still-zero O / l alone
+          const float d = kt == 0 ? mx - SHIFT : fmaxf(mx - SHIFT, 0.f);
+          if (kt != 0) {
+            const float alpha = ex2f(-d);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+            lacc[0] *= alpha;
+          }
+          negm -= d;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) NEGMB[r] = negm + SHIFT;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[t][r] -= d;
+        }
+        // P^T * 2^SHIFT in e4m3: byte j = 4 w + e of this lane-half is key kappa8(fh, j) = tile (w >> 2), register 4 (w & 3) + e
+        // (block s of the operand = bytes 16 s .. of both lane-halves = score tile s: one constant scale for all)
+        i32x8 bp;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          const int t = w >> 2, r0 = 4 * (w & 3);
+          bp[w] = pack4(ex2f(sacc[t][r0]), ex2f(sacc[t][r0 + 1]), ex2f(sacc[t][r0 + 2]), ex2f(sacc[t][r0 + 3]));
+        }
+        const unsigned char* vimg = T + PARTS * 2048;
+        const int4 v0 = *reinterpret_cast<const int4*>(vimg + vimg_at(fr, 2 * fh)), v1 = *reinterpret_cast<const int4*>(vimg + vimg_at(fr, 2 * fh + 1));
+        const i32x8 av = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const int sv = T[rec_vscale(PARTS) + fr * 2 + fh];                                 // block fh = keys 32 fh .. of channel fr
+        oacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bp, oacc, 0, 0, 0, sv, 0, SP);
+        // the ones operand is rebuilt per tile (8 moves) instead of living in 8 registers through the loop: the kernel
+        // sits at the 128-register line that lets two blocks share a CU (the empty asm keeps the moves in the loop)
+        int ow = one_word;
+        asm volatile("" : "+v"(ow));
+        const i32x8 ones = {ow, ow, ow, ow, ow, ow, ow, ow};
+        lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones, bp, lacc, 0, 0, 0, 127, 0, SP);
       }
-      // P^T * 2^SHIFT in e4m3: byte j = 4 w + e of this lane-half is key kappa8(fh, j) = tile (w >> 2), register 4 (w & 3) + e
-      // (block s of the operand = bytes 16 s .. of both lane-halves = score tile s: one constant scale for all)
-      i32x8 bp;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) {
-        const int t = w >> 2, r0 = 4 * (w & 3);
-        bp[w] = pack4(ex2f(sacc[t][r0]), ex2f(sacc[t][r0 + 1]), ex2f(sacc[t][r0 + 2]), ex2f(sacc[t][r0 + 3]));
-      }
-      const unsigned char* vimg = T + PARTS * 2048;
-      const int4 v0 = *reinterpret_cast<const int4*>(vimg + vimg_at(fr, 2 * fh)), v1 = *reinterpret_cast<const int4*>(vimg + vimg_at(fr, 2 * fh + 1));
-      const i32x8 av = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      const int sv = T[rec_vscale(PARTS) + fr * 2 + fh];                                 // block fh = keys 32 fh .. of channel fr
-      oacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bp, oacc, 0, 0, 0, sv, 0, SP);
-      lacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ones, bp, lacc, 0, 0, 0, 127, 0, SP);
     }
-    if (kt + 1 < nkt) commit((kt & 1) ^ 1);
-    if (kt + 2 < nkt) request(kt + 2);
+    if (st + 1 < nst) commit((st & 1) ^ 1);
+    if (st + 2 < nst) request(st + 2);
     __syncthreads();
   }
   if (active && q0 + fr < p.Tq) {
@@ -380,7 +405,7 @@ extern "C" int fod_attn_fp8_pack_bytes(const fod_attn_shape* shape, int parts, s
   if (rc) return rc;
   FOD_REQUIRE(q_bytes && kv_bytes, "attention fp8: null size outputs");
   *q_bytes = ((size_t)p.B * p.H * p.Tq * parts * 33 + 15) / 16 * 16;
-  *kv_bytes = (size_t)p.B * p.H * p.nkt * rec_bytes(parts);
+  *kv_bytes = ((size_t)p.B * p.H * p.nkt + 1) * rec_bytes(parts);      // + one pad record: see attn_fwd_fp8_kernel's staging
   return FOD_OK;
 }
 
@@ -413,8 +438,12 @@ extern "C" int fod_attn_fwd_fp8(const void* q_pack, const void* kv_pack, int par
   p.qpack = (unsigned char*)const_cast<void*>(q_pack); p.kvpack = (unsigned char*)const_cast<void*>(kv_pack);
   p.o = (__bf16*)o; p.lse2 = lse2;
   const dim3 grid(ceil_div(p.Tq, 256), p.H, p.B);
-  if (parts == 2) hipLaunchKernelGGL((attn_fwd_fp8_kernel<2>), grid, dim3(512), 0, stream, p);
-  else hipLaunchKernelGGL((attn_fwd_fp8_kernel<1>), grid, dim3(512), 0, stream, p);
+  static const char* env_st = getenv("FOD_FP8_STAGE");           // "1": one 64-key tile per barrier (experiments)
+  const bool one = env_st && env_st[0] == '1';
+  if (parts == 2 && one) hipLaunchKernelGGL((attn_fwd_fp8_kernel<2, 1>), grid, dim3(512), 0, stream, p);
+  else if (parts == 2) hipLaunchKernelGGL((attn_fwd_fp8_kernel<2, 2>), grid, dim3(512), 0, stream, p);
+  else if (one) hipLaunchKernelGGL((attn_fwd_fp8_kernel<1, 1>), grid, dim3(512), 0, stream, p);
+  else hipLaunchKernelGGL((attn_fwd_fp8_kernel<1, 2>), grid, dim3(512), 0, stream, p);
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }

@@ -322,6 +322,7 @@ class GraphedStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         Fn.WGRADS.prepare(dev)                    # pinned job tables for the captures below (none can be made inside)
+        ops.preallocate_graph_workspaces(dev)     # scratch of the captured launches: allocated and zeroed out here
         if not self.ddp:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -480,6 +481,7 @@ class GraphedForward:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
+        ops.preallocate_graph_workspaces(dev)
         Fn.PREP.refresh()                         # the graph reads the prepared weight copies; they are refreshed
         with torch.cuda.graph(graph):             # eagerly before a replay, and only when a parameter has changed
             outs = self._run(static)

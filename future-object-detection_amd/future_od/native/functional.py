@@ -81,6 +81,7 @@ class _Prepared:
         if tab is None:
             tab = self._build_tables([j for e in stale for j in e.jobs])
             if len(self._tables) > 16:
+                self._retired = getattr(self, "_retired", []) + [({}, dict(self._tables))]   # a graph may have baked one in
                 self._tables.clear()
             self._tables[key] = tab
         jobs_dev, blk_job, blk_chunk, nblocks, _keep = tab
@@ -117,6 +118,10 @@ class _Prepared:
         self.epoch += 1
 
     def clear(self):
+        # the old buffers and job tables are retired, not freed: a captured graph of an earlier model replays kernels
+        # that read them -- the refresh launch's job table holds raw POINTERS, and a recycled table is a wild access
+        # (observed: a GPU memory fault when a graph of model 1 was replayed after model 2 had been built)
+        self._retired = getattr(self, "_retired", []) + [(self._store, dict(self._tables))]
         self._store = {}                 # a NEW dict: per-parameter memos (prep_linear) compare its identity
         self._tables.clear()
 

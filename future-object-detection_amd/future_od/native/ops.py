@@ -69,14 +69,24 @@ def _chk(t, name, dtype=None):
 _WS = {}
 
 
-def _workspace(kind, device):
-    key = (kind, device.index, "graph" if torch.cuda.is_current_stream_capturing() else stream())
+def _workspace(kind, device, captured=None):
+    if captured is None:
+        captured = torch.cuda.is_current_stream_capturing()
+    key = (kind, device.index, "graph" if captured else stream())
     hit = _WS.get(key)
     if hit is None:
         nbytes = L.LIB.fod_workspace_bytes(kind)
         hit = torch.zeros(nbytes // 4, dtype=torch.int32, device=device)     # the ticket words must start at zero
         _WS[key] = hit
     return hit
+
+
+def preallocate_graph_workspaces(device):
+    """Called by future_od/graph.py BEFORE a capture: the scratch buffers captured launches use exist already, so their
+    allocation and zero-fill do not become nodes of the graph (a 64 MiB memset per replay otherwise)."""
+    device = torch.device(device)
+    for kind in (L.WS_NT_SPLIT, L.WS_NT_SPLIT_TICKETS, L.WS_TN_PARTIALS):
+        _workspace(kind, device, captured=True)
 
 
 def _epi(scale=None, shift=None, residual=None, ld_residual=0, residual_row_mod=0, relu_mask=None,

@@ -114,3 +114,36 @@ if which in ("all", "attn"):
         tb = timeit(lambda: ops.attn_bwd(q, k, v, o, o, lse, sc, q2, k2))
         f = 2.0 * B * H * Tq * S * 32
         print(f"{str((B, H, Tq, S, parts)):28s} {f * (parts + 1) / tf / 1e12:8.1f} {f * (3 * parts + 2) / tb / 1e12:8.1f}   {tf * 1e6:.1f}/{tb * 1e6:.1f}")
+
+if which in ("attn8",):
+    # BASELINE.json configs[4]: the MX-fp8 forward (quantiser and attention timed separately) beside the bf16 forward,
+    # interleaved rounds on one device; encoder shape at T=6 (10 frames) and T=8 (14 frames), and the cross-attention shape
+    import ctypes as C
+    from future_od.native import lib as L
+    print(f"{'attention B,H,Tq,S,parts':28s}   bf16 fwd us | fp8 quant us (with / without dequantised copies) | fp8 fwd us   (min over rounds)")
+    for B, H, Tq, S, parts in [(10, 8, 1450, 1450, 1), (14, 8, 1450, 1450, 1), (2, 8, 128, 1450, 2)]:
+        E = H * 32
+        mk = lambda T: torch.randn(B, T, E, device=DEV).to(dtype)
+        q, k, v = mk(Tq), mk(S), mk(S)
+        q2, k2 = (mk(Tq), mk(S)) if parts == 2 else (None, None)
+        sc = 1 / math.sqrt(32 * parts)
+        o = torch.empty_like(q)
+        shp, _ = ops._attn_shape(q, k, v, o, sc, k2)
+        shp.split_ws = shp.split_tickets = None
+        qb, kb = C.c_size_t(), C.c_size_t()
+        L._plain_call("fod_attn_fp8_pack_bytes", C.addressof(shp), parts, C.addressof(qb), C.addressof(kb))
+        qpack = torch.empty(qb.value, dtype=torch.uint8, device=DEV); kvpack = torch.empty(kb.value, dtype=torch.uint8, device=DEV)
+        deq = [mk(Tq), mk(S), mk(S), mk(Tq) if parts == 2 else None, mk(S) if parts == 2 else None]
+        lse = torch.empty((B, H, Tq), dtype=torch.float32, device=DEV)
+        P = ops.ptr
+        quant = lambda d: L._plain_call("fod_attn_quant_fp8", P(q), P(k), P(q2), P(k2), P(v), P(qpack), P(kvpack), P(d[0]), P(d[1]),
+                                        P(d[3]), P(d[4]), P(d[2]), C.addressof(shp), ops.stream())
+        fwd8 = lambda: L._plain_call("fod_attn_fwd_fp8", P(qpack), P(kvpack), parts, P(o), P(lse), C.addressof(shp), ops.stream())
+        res = {"bf16": [], "quant+deq": [], "quant": [], "fp8": []}
+        for _ in range(4):
+            res["bf16"].append(timeit(lambda: ops.attn_fwd(q, k, v, sc, q2, k2), iters=10))
+            res["quant+deq"].append(timeit(lambda: quant(deq), iters=10))
+            res["quant"].append(timeit(lambda: quant([None] * 5), iters=10))
+            res["fp8"].append(timeit(fwd8, iters=10))
+        m = {k_: min(v_) * 1e6 for k_, v_ in res.items()}
+        print(f"{str((B, H, Tq, S, parts)):28s}   {m['bf16']:8.1f} | {m['quant+deq']:8.1f} / {m['quant']:8.1f} | {m['fp8']:8.1f}")

@@ -33,11 +33,12 @@ def main():
     dist.init_process_group("nccl", init_method="env://")
     from types import SimpleNamespace
     data = make_batch(2, bench.T_FRAMES, bench.HEIGHT, bench.WIDTH, seed=1234, device=dev)
+    # ONE model and optimizer, three captured steps of it (the prepared-operand registry serves one live model)
+    model, detr = bench.build(SimpleNamespace(), dev, False, 5, "bf16")
+    model.eval()
+    opt = FusedAdamW(model.parameters(), lr=detr.lr, weight_decay=detr.weight_decay, max_norm=detr.max_norm)
     variants = {}
     for name, overlap, mode in (("plain", False, "async"), ("split-async", True, "async"), ("split-after", True, "after")):
-        model, detr = bench.build(SimpleNamespace(), dev, False, 5, "bf16")
-        model.eval()
-        opt = FusedAdamW(model.parameters(), lr=detr.lr, weight_decay=detr.weight_decay, max_norm=detr.max_norm)
         g = GraphedStep(model, opt, warmup=2, data_parallel=True)
         g.overlap, g.overlap_mode = overlap, mode
         g.broadcast_parameters()
