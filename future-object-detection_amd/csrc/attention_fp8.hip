@@ -438,8 +438,10 @@ extern "C" int fod_attn_fwd_fp8(const void* q_pack, const void* kv_pack, int par
   p.qpack = (unsigned char*)const_cast<void*>(q_pack); p.kvpack = (unsigned char*)const_cast<void*>(kv_pack);
   p.o = (__bf16*)o; p.lse2 = lse2;
   const dim3 grid(ceil_div(p.Tq, 256), p.H, p.B);
-  static const char* env_st = getenv("FOD_FP8_STAGE");           // "1": one 64-key tile per barrier (experiments)
-  const bool one = env_st && env_st[0] == '1';
+  // one 64-key tile per barrier by default: measured 42.1 us against 43.6 us with two (encoder shape, 10 frames; bf16
+  // kernel 45.5-46.2 us; profiles/r03e_fp8_attention_microbench.txt).  FOD_FP8_STAGE=2: two tiles per barrier
+  static const char* env_st = getenv("FOD_FP8_STAGE");
+  const bool one = !(env_st && env_st[0] == '2');
   if (parts == 2 && one) hipLaunchKernelGGL((attn_fwd_fp8_kernel<2, 1>), grid, dim3(512), 0, stream, p);
   else if (parts == 2) hipLaunchKernelGGL((attn_fwd_fp8_kernel<2, 2>), grid, dim3(512), 0, stream, p);
   else if (one) hipLaunchKernelGGL((attn_fwd_fp8_kernel<1, 1>), grid, dim3(512), 0, stream, p);

@@ -1,15 +1,15 @@
 #!/bin/bash
 # SQ counters of the attention kernels on the encoder shape: where the wave cycles go (issue / wait / stall).
-# usage (on the GPU box): bash tools/attn_pmc.sh <tag>
+# usage (on the GPU box): bash tools/attn_pmc.sh <tag> [attn | attn8]      (attn8: the fp8 forward beside the bf16 one)
 set -e
 tag=${1:-attn}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU \
-  --kernel-trace --output-format csv -d $out/pmc1 -- python $GRAFT_REPO_ROOT/tools/bench_ops.py attn > $out/pmc1.log 2>&1
+  --kernel-trace --output-format csv -d $out/pmc1 -- python $GRAFT_REPO_ROOT/tools/bench_ops.py ${2:-attn} > $out/pmc1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC SQ_WAVES GRBM_GUI_ACTIVE \
-  --kernel-trace --output-format csv -d $out/pmc2 -- python $GRAFT_REPO_ROOT/tools/bench_ops.py attn > $out/pmc2.log 2>&1
+  --kernel-trace --output-format csv -d $out/pmc2 -- python $GRAFT_REPO_ROOT/tools/bench_ops.py ${2:-attn} > $out/pmc2.log 2>&1
 python - <<PY
 import csv, glob, collections
 for d in ("pmc1", "pmc2"):

@@ -42,7 +42,7 @@ def snapshot(model, opt):
     ps = [p.detach().clone() for p in model.parameters()]
     ms = [(opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) if p in opt.state and "exp_avg" in opt.state[p]
           else None for p in model.parameters()]
-    return ps, ms, opt._step_no
+    return ps, ms, getattr(opt, "_step_no", 0)
 
 
 def restore(model, opt, snap):
