@@ -136,6 +136,35 @@ def _conv_fwd(x, cw, bn, dtype, relu, residual=None, cin_pad=None, out=None):
                           out=out), geom
 
 
+FUSED_BOTTLENECK = os.environ.get("FOD_FUSED_BOTTLENECK", "1") != "0"
+
+
+def _fusable(blk, x, dtype):
+    """fod_bottleneck_fused_fwd's domain: bf16, stride-1 bottleneck of width 64 with an identity (Cin 256) or 1x1
+    projection (Cin 64) shortcut -- torchvision ResNet-50's layer1."""
+    if not FUSED_BOTTLENECK or dtype != torch.bfloat16 or blk.kind == "basic":
+        return False
+    main, ds = blk.convs()
+    c1, c2, c3 = main[0][0], main[1][0], main[2][0]
+    cin = x.shape[-1]
+    if c1.weight.shape[0] != 64 or c3.weight.shape[0] != 256 or c2.stride != 1 or c1.stride != 1:
+        return False
+    if ds is None:
+        return cin == 256
+    return cin == 64 and ds[0].k == 1 and ds[0].stride == 1
+
+
+def _fused_bottleneck(blk, x, dtype, out=None):
+    main, ds = blk.convs()
+    ws, bs = [], []
+    for cw, bn in main + ([ds] if ds is not None else []):
+        scale, shift = bn.scale_shift()
+        ws.append(Fn.prep_conv(cw.weight, dtype, scale, False))
+        bs.append(shift)
+    wd, bd = (ws[3], bs[3]) if ds is not None else (None, None)
+    return ops.bottleneck_fused_fwd(x, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2], wd, bd, out=out)
+
+
 def _scale7(bn, scale):
     """The frozen-BN scale repeated per tap row ([Cout*7], the row index of the stem weight's permute job)."""
     hit = getattr(bn, "_s7", None)
@@ -154,9 +183,12 @@ class BackboneFn(Function):
         w_stem = Fn.prep_stem(body.conv1.weight, dtype, _scale7(body.bn1, scale1))
         norm = body.pixel_norm(video)
 
-        def block_fwd(blk, x, out=None):
+        def block_fwd(blk, x, out=None, frozen=False):
             """One residual block forward; returns (output, activations, geometries, downsample geometry)."""
             main, ds = blk.convs()
+            if frozen and _fusable(blk, x, dtype):
+                # a frozen 64-channel bottleneck keeps nothing for backward: one launch, intermediates stay on the CU
+                return _fused_bottleneck(blk, x, dtype, out), None, None, None
             idt, ds_geom = x, None
             if ds is not None:
                 idt, ds_geom = _conv_fwd(x, ds[0], ds[1], dtype, relu=False)
@@ -195,7 +227,7 @@ class BackboneFn(Function):
                         cout = blocks[i][1].convs()[0][-1][0].weight.shape[0]
                         x = torch.empty((l_sz * b_sz, h.shape[1], h.shape[2], cout), dtype=dtype, device=video.device)
                     dst = x[l0 * b_sz:(l0 + part.shape[1]) * b_sz]
-                h, _, _, _ = block_fwd(blocks[i][1], h, out=dst)
+                h, _, _, _ = block_fwd(blocks[i][1], h, out=dst, frozen=True)
             if steps >= l_sz:
                 x = h
             elif n_front == 0:

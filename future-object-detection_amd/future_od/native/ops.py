@@ -326,6 +326,29 @@ def conv2d_wgrad_acc(dy, x, dw, geom, row_scale=None, zeroed=False):
     return dw
 
 
+def bottleneck_fused_fwd(x, w1, b1, w2, b2, w3, b3, wd=None, bd=None, out=None):
+    """One frozen 64-channel bottleneck block (stride 1) in one launch: x NHWC [N,H,W,Cin] bf16 -> [N,H,W,256].
+    w1 [64,1,1,Cin], w2 [64,3,3,64], w3 [256,1,1,64] prepared conv weights (BN scale folded), b* f32 BN shifts;
+    wd / bd: the projection shortcut's (Cin 64), None = identity (Cin 256)."""
+    _chk(x, "x", torch.bfloat16)
+    n, h, w, cin = x.shape
+    for t, name, numel in ((w1, "w1", 64 * cin), (w2, "w2", 64 * 9 * 64), (w3, "w3", 256 * 64)):
+        _chk(t, name, torch.bfloat16); assert t.numel() == numel, (name, t.shape)
+    for t, name, numel in ((b1, "b1", 64), (b2, "b2", 64), (b3, "b3", 256)):
+        _chk(t, name, torch.float32); assert t.numel() == numel
+    if wd is not None:
+        _chk(wd, "wd", torch.bfloat16); _chk(bd, "bd", torch.float32)
+        assert wd.numel() == 256 * cin and bd.numel() == 256
+    if out is None:
+        out = torch.empty((n, h, w, 256), dtype=x.dtype, device=x.device)
+    else:
+        _chk(out, "out", x.dtype); assert tuple(out.shape) == (n, h, w, 256)
+    flops = 2.0 * n * h * w * (cin * 64 + 9 * 64 * 64 + 64 * 256 + (cin * 256 if wd is not None else 0))
+    call("fod_bottleneck_fused_fwd", dt(x), ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(w3), ptr(b3), ptr(wd),
+         ptr(bd), ptr(out), n, h, w, cin, 64, 256, stream(), work=flops, tag="fod_conv2d_fwd")
+    return out
+
+
 def maxpool3x3s2(x):
     _chk(x, "x")
     n, h, w, c = x.shape

@@ -187,6 +187,15 @@ int fod_conv2d_wgrad_acc(int dtype, const void* dy, const void* x, float* dw, co
                          const float* row_scale, int accumulate, void* ws /* optional, as fod_gemm_tn_acc */,
                          size_t ws_bytes, fod_stream_t stream);
 
+/* One FROZEN 64-channel bottleneck block in one launch (csrc/bottleneck_fused.hip; torchvision Bottleneck with
+ * FrozenBatchNorm2d, reference paper.py:94-98, for the blocks that keep nothing for backward, paper.py:102-109):
+ *   out = relu(conv3(relu(conv2_3x3(relu(conv1(x) + b1)) + b2)) + b3 + shortcut),  stride 1, bf16, NHWC
+ * w1 [64][Cin], w2 [64][3][3][64], w3 [256][64] with the BN scales folded in, b* the BN shifts (f32);
+ * shortcut = x (wd NULL, Cin 256) or wd . x + bd (wd [256][Cin], Cin 64: the stage's first block). */
+int fod_bottleneck_fused_fwd(int dtype, const void* x, const void* w1, const float* b1, const void* w2,
+                             const float* b2, const void* w3, const float* b3, const void* wd, const float* bd,
+                             void* out, int Nimg, int H, int W, int Cin, int mid, int Cout, fod_stream_t stream);
+
 /* 3x3 stride-2 pad-1 max pooling, NHWC (torchvision ResNet stem; forward only: stem is frozen). */
 int fod_maxpool3x3s2(int dtype, const void* x, void* y, int Nimg, int H, int W, int C, int Ho, int Wo,
                      fod_stream_t stream);

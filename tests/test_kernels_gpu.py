@@ -1023,3 +1023,44 @@ print("TWO_THREADS_OK")
     r = subprocess.run([sys.executable, "-c", code, root, os.path.join(root, "future-object-detection_amd")],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "TWO_THREADS_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("cin,shape", [(64, (2, 23, 41)), (256, (2, 23, 41)), (256, (1, 6, 30)), (64, (1, 7, 95)),
+                                       (256, (3, 13, 64))])
+def test_fused_frozen_bottleneck_matches_the_layer_by_layer_path(cin, shape):
+    """fod_bottleneck_fused_fwd (one launch per frozen 64-channel bottleneck block) against the
+    same block as three (four) fod_conv2d_fwd launches and against fp32 torch: ragged tiles (6 x 30 output tiles, 8 x 32
+    halos), image borders (the 3x3's zero padding applies to conv1's OUTPUT), identity and projection shortcuts.
+    Both HIP paths round the two 64-channel intermediates to bf16 at the same points; the projection shortcut is
+    rounded once more on the layer-by-layer path (it is a tensor there), hence 'within bf16 tolerance', not bit-equal."""
+    from future_od.native import backbone as BB
+    torch.manual_seed(5)
+    n, h, w = shape
+    blk = BB._Block("bottleneck", cin, 64, 1, 4).to(DEV)
+    for m in blk.modules():
+        if isinstance(m, BB.FrozenBatchNorm2d):
+            m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2); m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+    dtype = torch.bfloat16
+    x = rnd((n, h, w, cin), dtype, 9).to(DEV)
+    assert BB._fusable(blk, x, dtype)
+    fused = BB._fused_bottleneck(blk, x, dtype)
+    main, ds = blk.convs()
+    idt = x if ds is None else BB._conv_fwd(x, ds[0], ds[1], dtype, relu=False)[0]
+    hcur = x
+    for j, (cw, bn) in enumerate(main):
+        hcur, _ = BB._conv_fwd(hcur, cw, bn, dtype, relu=True, residual=idt if j == 2 else None)
+    # fp32 torch on the same bf16-rounded input
+    def bnf(t, bn):
+        sc, sh = bn.scale_shift()
+        return t * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    xt = x.float().permute(0, 3, 1, 2)
+    y = torch.relu(bnf(F.conv2d(xt, main[0][0].weight.float()), main[0][1]))
+    y = torch.relu(bnf(F.conv2d(y, main[1][0].weight.float(), padding=1), main[1][1]))
+    y = bnf(F.conv2d(y, main[2][0].weight.float()), main[2][1])
+    sc_ = xt if ds is None else bnf(F.conv2d(xt, ds[0].weight.float()), ds[1])
+    ref = torch.relu(y + sc_).permute(0, 2, 3, 1)
+    span = float(ref.abs().max())
+    e_ref = float((fused.float() - ref).abs().max()) / span
+    e_unf = float((fused.float() - hcur.float()).abs().max()) / span
+    print(f"fused bottleneck cin={cin} {shape}: vs fp32 torch {e_ref:.3e}, vs layer-by-layer HIP {e_unf:.3e} of max|ref|")
+    assert e_ref <= 2e-2 and e_unf <= 1.6e-2, (e_ref, e_unf)
