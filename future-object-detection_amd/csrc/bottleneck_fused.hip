@@ -208,9 +208,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
       }                                                                                               \
     } while (0)
     FOD_BNK_REQUEST_SC(0, res0, res1, xb);
-    for (int it = 0; it < 2 * nrows; ++it) {
-      const int r = it >> 1, t = it & 1;
-      const int yy = y0 + r;
+    for (int r = 0; r < nrows; ++r) {
+     const int yy = y0 + r;
+#pragma unroll
+     for (int t = 0; t < 2; ++t) {                  // (compile-time t: a3 / ad indexed by a runtime value would go to scratch)
+      const int it = 2 * r + t;
       FOD_BNK_REQUEST_SC(it + 1, res0n, res1n, xbn);
       f32x16 acc;
 #pragma unroll
@@ -219,11 +221,11 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
       for (int ks = 0; ks < 4; ++ks) {
         Frag<__bf16> bfr;
         bfr.v = *reinterpret_cast<const bf16x8_t*>(R + r * ROWB + at(fr, 2 * ks + fh));
-        mma16(t ? a3[1][ks] : a3[0][ks], bfr, acc);
+        mma16(a3[t][ks], bfr, acc);
       }
       if (p.wd) {                                   // projection shortcut (the stage's first block): Wd . X on the same pixels
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) mma16(t ? ad[1][ks] : ad[0][ks], xb[ks], acc);
+        for (int ks = 0; ks < 4; ++ks) mma16(ad[t][ks], xb[ks], acc);
       }
       const int cbase = 64 * wave + 32 * t;
 #pragma unroll
@@ -255,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParam
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) xb[ks] = xbn[ks];
       }
+     }
     }
   }
 }

@@ -101,14 +101,21 @@ class GraphedStep:
         # rollback_warmup the parameters, moments and step counts are put back afterwards, so that a training loop
         # sees exactly one update per batch (the Trainer asks for this; the benchmark does not care)
         self.rollback_warmup = bool(rollback_warmup)
-        # data parallel, opt-in (FOD_GRAPH_OVERLAP=1): split the captured backward at the backbone's output and average the
-        # transformer gradients while the backbone's backward runs.  Off by default: measured with a one-rank RCCL group
-        # on one GPU the third graph launch and the concurrent collective cost 0.95 ms per step (24.43 vs 23.48 ms),
-        # about what the overlap could hide at 8 GPUs, and a two-rank gloo rehearsal with full-size gradients stalled in
-        # the asynchronous collective (6.7 s per step) -- not something to leave on for a scaling run that cannot be
-        # rehearsed on RCCL here.
+        # data parallel: split the captured backward at the backbone's output and average the transformer gradients
+        # (120 MB) on RCCL's stream while the backbone's backward graph replays (north_star: "all-reduce ... overlapped
+        # with backward on a side HIP stream").  What one rank can measure (tools/ddp_overlap_probe.py, one-rank RCCL
+        # group, same process, interleaved): the split itself is free (A1 + A2 + B without communication = A + B: 20.92
+        # vs 20.96 ms), the same collectives issued AFTER A2 cost what the unsplit step's do (21.35 vs 21.34), running the
+        # transformer's collective BESIDE A2 costs +0.6 ms (21.96) whatever NCCL_MAX_NCHANNELS is -- but a one-rank
+        # "all-reduce" is a full-chip element-wise kernel (oneRankReduce, 16384 x 512 threads, 0.3 ms) fighting the
+        # backbone's kernels for every CU, where a ring step of a real group runs on a few channels.  So: on for
+        # world > 1 with RCCL (FOD_GRAPH_OVERLAP=0 turns it off), off at one rank and for gloo (a two-rank gloo
+        # rehearsal with full-size gradients stalled in the asynchronous collective, 6.7 s per step, round 2).
         import os
-        self.overlap = os.environ.get("FOD_GRAPH_OVERLAP", "0") == "1"
+        env = os.environ.get("FOD_GRAPH_OVERLAP")
+        # default (round 3): ON for a real multi-rank RCCL group, off for one rank and for gloo -- see the comment above
+        # and profiles/r03e_ddp_overlap_probe_1rank.txt
+        self.overlap = (env == "1") if env is not None else (self.ddp and self.world > 1 and self._native_avg())
         self.overlap_mode = os.environ.get("FOD_GRAPH_OVERLAP_MODE", "async")     # "after": experiment, see __call__
         self.grad_bf16 = os.environ.get("FOD_GRAD_BF16", "0") == "1"
         self._bf16_bufs = {}

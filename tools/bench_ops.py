@@ -147,3 +147,26 @@ if which in ("attn8",):
             res["fp8"].append(timeit(fwd8, iters=10))
         m = {k_: min(v_) * 1e6 for k_, v_ in res.items()}
         print(f"{str((B, H, Tq, S, parts)):28s}   {m['bf16']:8.1f} | {m['quant+deq']:8.1f} / {m['quant']:8.1f} | {m['fp8']:8.1f}")
+
+if which in ("bnk",):
+    # the fused frozen bottleneck block against the layer-by-layer launches, layer1 of ResNet-50 at FR x 900 x 1600
+    from future_od.native import backbone as BB
+    torch.manual_seed(0)
+    h, w = 225, 400
+    print(f"layer1 bottleneck at {FR} x {h} x {w}: fused us | layer by layer us | GB/s of (x + out) for the fused launch   (min of 4 rounds)")
+    for cin in (64, 256):
+        blk = BB._Block("bottleneck", cin, 64, 1, 4).to(DEV)
+        x = torch.randn(FR, h, w, cin, device=DEV).to(dtype)
+        def unfused():
+            main, ds = blk.convs()
+            idt = x if ds is None else BB._conv_fwd(x, ds[0], ds[1], dtype, relu=False)[0]
+            hc = x
+            for j, (cw, bn) in enumerate(main):
+                hc, _ = BB._conv_fwd(hc, cw, bn, dtype, relu=True, residual=idt if j == 2 else None)
+            return hc
+        tf, tu = [], []
+        for _ in range(4):
+            tf.append(timeit(lambda: BB._fused_bottleneck(blk, x, dtype), iters=10))
+            tu.append(timeit(unfused, iters=10))
+        byt = FR * h * w * (cin + 256) * 2
+        print(f"Cin {cin:3d}: {min(tf) * 1e6:8.1f} | {min(tu) * 1e6:8.1f} | {byt / min(tf) / 1e9:7.0f}")

@@ -119,6 +119,26 @@ def main():
     data = batches[s_step % len(batches)]
     one = {k: (v[:1].contiguous() if isinstance(v, torch.Tensor) else v) for k, v in data.items() if k != "_host_annotations"}
 
+    # ---- 1b. the same steps again from the snapshot, launched eagerly (bf16): which gradient tensors go non-finite first?
+    restore(model, opt, snap)
+    opt.disable_device_step() if hasattr(opt, "disable_device_step") else None
+    for k in range(14):
+        data_k = batches[(s_step + k) % len(batches)]
+        opt.zero_grad()
+        _, _, loss_k, _, _ = model(data=data_k, distributed=False)
+        loss_k.backward()
+        torch.cuda.synchronize()
+        named = [(n_, p_.grad) for n_, p_ in model.named_parameters() if p_.grad is not None]
+        norms = torch.stack(torch._foreach_norm([g_ for _, g_ in named])).float().cpu()
+        bad = [named[i][0] for i in range(len(named)) if not bool(torch.isfinite(norms[i]))]
+        fin = norms.nan_to_num(0.0, 0.0, 0.0)
+        top = int(fin.argmax())
+        print(f"   eager bf16 step {s_step + k}: loss {float(loss_k):.4f}, gradient norm {float((fin ** 2).sum() ** 0.5):.4e} (finite part), "
+              f"largest {float(fin[top]):.3e} at {named[top][0]}; {len(bad)} non-finite tensors{': ' + ', '.join(bad[:5]) if bad else ''}", flush=True)
+        if bad:
+            break
+        opt.step()
+
     # ---- 2. gradients at the snapshot: bf16 kernels, fp32 kernels, CPU oracle
     restore(model, opt, snap)
     l16, g16 = gradients(model, one)
@@ -144,26 +164,27 @@ def main():
     print(f"oracle forward + backward: {time.perf_counter() - t0:.1f} s; loss oracle {float(lo):.6f}, fp32 kernels {l32:.6f}, "
           f"bf16 kernels {l16:.6f}")
     go = {k: v.grad for k, v in osd.items() if getattr(v, "grad", None) is not None}
-    worst32, worst16, n = ("", 0.0), ("", 1.0), 0
-    tot = {"o": 0.0, "32": 0.0, "16": 0.0}
+    rows, tot = [], {"o": 0.0, "e32": 0.0, "e16": 0.0, "32": 0.0, "16": 0.0}
     for name, r in go.items():
         if name not in g32:
             continue
-        n += 1
-        rn = float(r.norm())
+        rn, e32, e16 = float(r.norm()), float((g32[name] - r).norm()), float((g16[name] - r).norm())
+        rows.append((name, rn, e32, e16))
         tot["o"] += rn ** 2
+        tot["e32"] += e32 ** 2
+        tot["e16"] += e16 ** 2
         tot["32"] += float(g32[name].norm()) ** 2
         tot["16"] += float(g16[name].norm()) ** 2
-        e32 = float((g32[name] - r).norm()) / max(rn, 1e-20)
-        cos16 = float((g16[name].flatten() @ r.flatten()) / max(float(g16[name].norm()) * rn, 1e-30))
-        if e32 > worst32[1] and rn > 1e-8:
-            worst32 = (name, e32)
-        if cos16 < worst16[1] and rn > 1e-8:
-            worst16 = (name, cos16)
-    print(f"{n} gradient tensors compared.  global gradient norm: oracle {tot['o'] ** 0.5:.4e}, fp32 kernels {tot['32'] ** 0.5:.4e}, "
+    gl = tot["o"] ** 0.5
+    print(f"{len(rows)} gradient tensors compared.  global gradient norm: oracle {gl:.4e}, fp32 kernels {tot['32'] ** 0.5:.4e}, "
           f"bf16 kernels {tot['16'] ** 0.5:.4e}")
-    print(f"fp32 kernels vs oracle: largest ||g - g_ref|| / ||g_ref|| over tensors = {worst32[1]:.3e} ({worst32[0]})")
-    print(f"bf16 kernels vs oracle: smallest cosine over tensors = {worst16[1]:.4f} ({worst16[0]})")
+    print(f"whole gradient: ||g_fp32 - g_oracle|| / ||g_oracle|| = {tot['e32'] ** 0.5 / gl:.3e};  ||g_bf16 - g_oracle|| / ||g_oracle|| = {tot['e16'] ** 0.5 / gl:.3e}")
+    print("largest absolute deviations of the fp32 kernels (tensor, ||g_ref||, ||g32 - g_ref||, ||g16 - g_ref||):")
+    for name, rn, e32, e16 in sorted(rows, key=lambda t: -t[2])[:8]:
+        print(f"   {name:70s} {rn:.3e} {e32:.3e} {e16:.3e}")
+    print("largest absolute deviations of the bf16 kernels:")
+    for name, rn, e32, e16 in sorted(rows, key=lambda t: -t[3])[:8]:
+        print(f"   {name:70s} {rn:.3e} {e32:.3e} {e16:.3e}")
 
     # ---- 3. continue from the snapshot in the fp32 parity mode
     restore(m32, o32, snap)
