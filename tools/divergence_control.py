@@ -75,6 +75,24 @@ def run_until_takeoff(model, opt, batches, steps, every=5):
         traj.append((i, loss, gn))
         base = statistics.median(t[2] for t in traj[:20]) if len(traj) >= 10 else None
         if loss != loss or abs(loss) == float("inf") or gn != gn or (base and gn > 30.0 * base):
+            # the gradients of THIS replay are still in place: which tensors are non-finite, and where inside them?
+            rep = []
+            for n_, p_ in model.named_parameters():
+                if p_.grad is None:
+                    continue
+                g_ = p_.grad.detach()
+                bad_ = ~torch.isfinite(g_)
+                nb = int(bad_.sum())
+                if nb:
+                    idx = bad_.reshape(-1).nonzero().flatten()
+                    rep.append((n_, nb, g_.numel(), tuple(g_.shape), idx[:6].tolist(), idx[-3:].tolist(),
+                                float(g_[torch.isfinite(g_)].abs().max()) if nb < g_.numel() else float("nan")))
+            big = sorted(((float(p_.grad.detach().float().abs().nan_to_num(0, 0, 0).max()), n_) for n_, p_ in model.named_parameters()
+                          if p_.grad is not None), reverse=True)[:5]
+            print(f"   at the flagged replay: {len(rep)} gradient tensors hold non-finite values")
+            for r_ in rep[:12]:
+                print(f"      {r_[0]} {r_[3]}: {r_[1]} of {r_[2]} non-finite, first flat indices {r_[4]}, last {r_[5]}, largest finite |g| {r_[6]:.3e}")
+            print("   largest finite |g| entries:", [(f"{v:.3e}", n_) for v, n_ in big], flush=True)
             return True, traj, snaps
     return False, traj, snaps
 
