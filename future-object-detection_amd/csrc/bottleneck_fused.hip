@@ -5,20 +5,26 @@
 // and re-read 460 MB each at 10 x 900 x 1600); fused, a block reads its input once (plus the 3x3's halo) and writes its
 // output once: 1.84 GB -> ~1.1 GB per block.
 //
-// Tiling: a workgroup of 8 waves owns TH x TW = 6 x 30 output pixels of one image; the 3x3 needs the 1x1's output on
+// Tiling: a workgroup of 4 waves owns TH x TW = 6 x 30 output pixels of one image; the 3x3 needs the 1x1's output on
 // the 8 x 32 halo, and one halo ROW of 32 pixels is exactly one 32-wide MFMA tile.  Everything is computed transposed
 // (C^T[channel, pixel] = W[channel, k] . ACT^T[k, pixel]: weights are the A operand straight from L2, activations the
 // B operand from LDS, the pixel sits on the lane), so every activation image in LDS is "32 pixels x 64 channels" with
 // 128-byte pixel rows whose 16-byte chunks are XOR-swizzled by (pixel >> 1) & 7 (a 16-lane ds_read_b128 group then
 // covers 16 different (parity, chunk) bank slots).
 //   stage 1  Y1[8 x 32 px, 64] = relu(W1 . X + b1), zero outside the image (the 3x3's padding applies to Y1);
-//            X arrives in 64-channel chunks: full 128-byte lines -> registers -> LDS, TWO chunks in flight
+//            X arrives in 64-channel chunks: full 128-byte lines -> registers -> LDS, next chunk in flight
 //   stage 2  Y2[6 x 32 px, 64] = relu(sum_taps W2[tap] . Y1[shifted] + b2)            (LDS -> LDS)
-//   stage 3  OUT[6 x 30 px, 256] = relu(W3 . Y2 + b3 + shortcut) straight from the accumulators: a lane holds groups of
-//            four consecutive channels of its pixel (8-byte accesses; the shortcut's pieces are requested a row ahead)
-// LDS: Y1 32 KB | X chunk 32 KB (later Y2 24 KB) = 64 KB -> two workgroups = 16 waves per CU; every weight fragment is
-// requested one step before the MFMAs that use it (the first version, without that and with 4 waves, was latency-bound
-// at 770 us per block against 434 us for the three separate launches).
+//   stage 3  OUT[6 x 30 px, 256] = relu(W3 . Y2 + b3 + shortcut): per 32-channel tile the f32 result goes through a
+//            wave-private slab so that the shortcut is read and the output written as 64-byte row segments
+// LDS: Y1 32 KB | X chunk 32 KB (later Y2 24 KB; the output slabs reuse Y1's space) = 64 KB -> two workgroups per CU.
+//
+// Measured (tools/bench_ops.py bnk, 10 x 225 x 400, one MI355X; profiles/r03i_fused_bottleneck.txt):
+//   v1: nothing requested ahead, a select on freshly loaded values          ~770 us per block (three launches: 434)
+//   v2 (THIS file): weight fragments / shortcut operands one step ahead     450 us (Cin 256), 453 us (Cin 64; 533 unfused)
+//   v3: 8 waves, two x chunks in flight, 8-byte epilogue from the registers  596 / 508 us -- the scattered 8-byte stores
+//       and loads of the epilogue cost more than the slab round trip they replaced; dropped
+// i.e. the fused block is latency-bound at one wave per SIMD and workgroup (MFMA time is ~3 us of a 43 us block), not
+// HBM-bound: it ties the layer-by-layer launches on the identity blocks and beats them by 15 % on the projection block.
 #include "common.h"
 
 namespace {
@@ -37,12 +43,8 @@ struct BnkParams {
 FOD_DEVINL int at(int px, int c16) { return px * 128 + (((c16 ^ (px >> 1)) & 7) << 4); }
 
 FOD_DEVINL bf16x8_t ld8(const __bf16* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
-FOD_DEVINL bf16x4_t ld4(const __bf16* p) { return *reinterpret_cast<const bf16x4_t*>(p); }
 
-// PROJ: the projection shortcut (Cin 64, one chunk); otherwise the identity shortcut (Cin 256).  A template parameter so
-// that each variant's registers hold only its own operands (the kernel sits at the 128-register line: 2 x 8 waves per CU)
-template <bool PROJ>
-__global__ __launch_bounds__(512, 4) void bottleneck_fused_kernel(const BnkParams p) {
+__global__ __launch_bounds__(256, 2) void bottleneck_fused_kernel(const BnkParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HR * ROWB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
@@ -54,58 +56,59 @@ __global__ __launch_bounds__(512, 4) void bottleneck_fused_kernel(const BnkParam
 
   // ---------------------------------------------------------------- stage 1: Y1 = relu(W1 . X + b1) on the halo
   {
-    const int ct = wave & 1, rq = wave >> 1;        // this wave: channels 32 ct .., halo rows 2 rq, 2 rq + 1
-    f32x16 acc[2];
+    const int ct = wave & 1, rh = wave >> 1;        // this wave: channels 32 ct .., halo rows 4 rh .. 4 rh + 3
+    f32x16 acc[4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    // staging role: thread -> pixel (tid >> 3) & 31, 16-byte chunk tid & 7, of halo rows (tid >> 8) + 2 i (i = 0..3)
-    const int spx = (tid >> 3) & 31, sc = tid & 7, sr0 = tid >> 8;
+    // staging role: thread -> pixel (tid >> 3) & 31, 16-byte chunk tid & 7, of halo row i (i = 0..7)
+    const int spx = (tid >> 3) & 31, sc = tid & 7;
     const int sxx = x0 - 1 + spx;
     const bool sx_ok = sxx >= 0 && sxx < p.W;
-    // every load is unconditional (clamped address) and its result is not touched before the commit two chunks later:
+    // every load is unconditional (clamped address) and its result is not touched before the commit one chunk later:
     // a select on a freshly loaded value would make the wave wait for it at once
+    uint4 pre[8];
     unsigned okm = 0;
-    unsigned soff[4];                                // element offsets inside the image (< 2^31: checked by the host)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int yr = y0 - 1 + sr0 + 2 * i;
-      okm |= (sx_ok && yr >= 0 && yr < p.H) ? (1u << i) : 0u;
-      const int yy = min(max(yr, 0), p.H - 1), xc = min(max(sxx, 0), p.W - 1);
-      soff[i] = (unsigned)((yy * p.W + xc) * Cin + sc * 8);
+    for (int i = 0; i < 8; ++i) {
+      const int yy = y0 - 1 + i;
+      okm |= (sx_ok && yy >= 0 && yy < p.H) ? (1u << i) : 0u;
     }
-    // (named variables indexed by unrolled constants only: an array handed to a lambda by pointer lands in scratch memory)
-    uint4 preA[4], preB[4];                          // chunks kc + 1 and kc + 2 in flight while chunk kc is multiplied
+    long soff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int yy = min(max(y0 - 1 + i, 0), p.H - 1), xc = min(max(sxx, 0), p.W - 1);
+      soff[i] = ((long)yy * p.W + xc) * Cin + sc * 8;
+    }
+    auto request = [&](int kc) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pre[i] = *reinterpret_cast<const uint4*>(ximg + soff[i] + kc * 64);
+    };
+    // (named arrays indexed by unrolled constants only: an array handed to a lambda by pointer lands in scratch memory)
     Frag<__bf16> a1[4], a1n[4];
     const __bf16* w1row = p.w1 + (long)(32 * ct + fr) * Cin + 8 * fh;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) preA[i] = *reinterpret_cast<const uint4*>(ximg + soff[i]);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) preB[i] = *reinterpret_cast<const uint4*>(ximg + soff[i] + min(1, nch - 1) * 64);
+    request(0);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) a1[ks].v = ld8(w1row + ks * 16);
     for (int kc = 0; kc < nch; ++kc) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        uint4 v = preA[i];
+      for (int i = 0; i < 8; ++i) {
+        uint4 v = pre[i];
         if (!((okm >> i) & 1u)) v = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(R + (sr0 + 2 * i) * ROWB + at(spx, sc)) = v;
+        *reinterpret_cast<uint4*>(R + i * ROWB + at(spx, sc)) = v;
       }
       __syncthreads();
-      const int k1 = min(kc + 1, nch - 1), k2 = min(kc + 2, nch - 1);   // (past the end: the last chunk again, unused)
+      const int kn = min(kc + 1, nch - 1);          // (the last trip re-requests its own chunk: no branch around a load)
+      request(kn);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) preA[i] = preB[i];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) preB[i] = *reinterpret_cast<const uint4*>(ximg + soff[i] + k2 * 64);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) a1n[ks].v = ld8(w1row + k1 * 64 + ks * 16);
+      for (int ks = 0; ks < 4; ++ks) a1n[ks].v = ld8(w1row + kn * 64 + ks * 16);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < 4; ++t) {
           Frag<__bf16> bfr;
-          bfr.v = *reinterpret_cast<const bf16x8_t*>(R + (2 * rq + t) * ROWB + at(fr, 2 * ks + fh));
+          bfr.v = *reinterpret_cast<const bf16x8_t*>(R + (4 * rh + t) * ROWB + at(fr, 2 * ks + fh));
           mma16(a1[ks], bfr, acc[t]);
         }
       }
@@ -114,8 +117,8 @@ __global__ __launch_bounds__(512, 4) void bottleneck_fused_kernel(const BnkParam
       __syncthreads();
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int hr = 2 * rq + t;
+    for (int t = 0; t < 4; ++t) {
+      const int hr = 4 * rh + t;
       const int yy = y0 - 1 + hr, xx = x0 - 1 + fr;
       const bool inside = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
 #pragma unroll
@@ -132,11 +135,11 @@ __global__ __launch_bounds__(512, 4) void bottleneck_fused_kernel(const BnkParam
   __syncthreads();
 
   // ---------------------------------------------------------------- stage 2: Y2 = relu(3x3(Y1) + b2)
-  if (wave < 6) {                                   // 6 output rows x 2 channel tiles = 12 tiles: waves 0..5 take two rows each
-    const int ct = wave & 1, rp = wave >> 1;        // channels 32 ct .., output rows 2 rp, 2 rp + 1 (sharing the weights)
-    f32x16 acc[2];
+  {
+    const int ct = wave & 1, rh = wave >> 1;        // channels 32 ct .., output rows 3 rh .. 3 rh + 2
+    f32x16 acc[3];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     Frag<__bf16> a2[4], a2n[4];
@@ -152,9 +155,9 @@ __global__ __launch_bounds__(512, 4) void bottleneck_fused_kernel(const BnkParam
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < 3; ++t) {
           Frag<__bf16> bfr;
-          bfr.v = *reinterpret_cast<const bf16x8_t*>(Y1 + (2 * rp + t + dy) * ROWB + at(px, 2 * ks + fh));
+          bfr.v = *reinterpret_cast<const bf16x8_t*>(Y1 + (3 * rh + t + dy) * ROWB + at(px, 2 * ks + fh));
           mma16(a2[ks], bfr, acc[t]);
         }
       }
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(512, 4) void bottleneck_fused_kernel(const BnkParam
       for (int ks = 0; ks < 4; ++ks) a2[ks] = a2n[ks];
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < 3; ++t) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int c = 32 * ct + 8 * g + 4 * fh;
@@ -170,57 +173,55 @@ __global__ __launch_bounds__(512, 4) void bottleneck_fused_kernel(const BnkParam
         bf16x4_t o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaxf(acc[t][4 * g + e] + sh[e], 0.f);
-        *reinterpret_cast<bf16x4_t*>(R + (2 * rp + t) * ROWB + at(fr, 4 * ct + g) + 8 * fh) = o;
+        *reinterpret_cast<bf16x4_t*>(R + (3 * rh + t) * ROWB + at(fr, 4 * ct + g) + 8 * fh) = o;
       }
     }
   }
-  __syncthreads();                                  // Y2 complete
+  __syncthreads();                                  // Y2 complete, Y1 dead: its space now holds the output slabs
 
   // ---------------------------------------------------------------- stage 3: OUT = relu(W3 . Y2 + b3 + shortcut)
   {
-    // this wave: output channels 32 wave .. 32 wave + 31 of every row; its weights stay in registers
-    Frag<__bf16> a3[4], ad[4];
+    unsigned char* OS = Y1 + wave * ROWB;           // wave-private f32 [32 px][32 ch] slab
+    Frag<__bf16> a3[2][4], ad[2][4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      a3[ks].v = ld8(p.w3 + (long)(32 * wave + fr) * 64 + ks * 16 + 8 * fh);
-      if (PROJ) ad[ks].v = ld8(p.wd + (long)(32 * wave + fr) * 64 + ks * 16 + 8 * fh);          // Cin == 64
-    }
-    f32x4 sh[4];
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      sh[g] = *reinterpret_cast<const f32x4*>(p.b3 + 32 * wave + 8 * g + 4 * fh);
-      if (PROJ) sh[g] += *reinterpret_cast<const f32x4*>(p.bd + 32 * wave + 8 * g + 4 * fh);
-    }
+      for (int ks = 0; ks < 4; ++ks) {
+        a3[t][ks].v = ld8(p.w3 + (long)(64 * wave + 32 * t + fr) * 64 + ks * 16 + 8 * fh);
+        if (p.wd) ad[t][ks].v = ld8(p.wd + (long)(64 * wave + 32 * t + fr) * 64 + ks * 16 + 8 * fh);   // Cin == 64
+      }
+    const int cpx = lane >> 1, chh = lane & 1;      // coalesced pass: pixel, 16-channel half of the 32-channel tile
     const int nrows = min(TH, p.H - y0);
-    const int pxx = min(x0 + fr, p.W - 1);
-    const bool store_ok = fr < TW && x0 + fr < p.W;
-    // the shortcut's operands of row r + 1 are requested while row r is computed and stored: identity -> the four 8-byte
-    // pieces of x this lane adds; projection -> the four B fragments of the row's pixels.  Past the end: the last row
-    // again (loaded, unused) -- no branch around a load.
-    bf16x4_t res[4], resn[4];
+    // the shortcut's operands are requested one (row, channel tile) step ahead: identity -> the 32 bytes of x each lane
+    // adds in the coalesced pass; projection -> the four B fragments of the row's pixels (shared by both channel tiles)
+    const int cxx = min(x0 + cpx, p.W - 1), fxx = min(x0 + fr, p.W - 1);
+    bf16x8_t res0, res1, res0n, res1n;
     Frag<__bf16> xb[4], xbn[4];
-    {
-      const __bf16* q = ximg + ((long)y0 * p.W + pxx) * Cin;
-      if (!PROJ) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) res[g] = ld4(q + 32 * wave + 8 * g + 4 * fh);
-      } else {
+    for (int e = 0; e < 8; ++e) { res0[e] = res1[e] = res0n[e] = res1n[e] = (__bf16)0.f; }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) xb[ks].v = ld8(q + ks * 16 + 8 * fh);
-      }
-    }
+    for (int ks = 0; ks < 4; ++ks) { frag_zero(xb[ks]); frag_zero(xbn[ks]); }
+    // step `it` = (row it >> 1, channel tile it & 1); past the end: the last row again (loaded, unused)
+#define FOD_BNK_REQUEST_SC(IT, R0, R1, XF)                                                            \
+    do {                                                                                              \
+      const int r__ = min((IT) >> 1, nrows - 1), t__ = (IT) & 1;                                      \
+      const long rowoff__ = (long)(y0 + r__) * p.W;                                                   \
+      if (!p.wd) {                                                                                    \
+        const __bf16* q__ = ximg + (rowoff__ + cxx) * Cin + 64 * wave + 32 * t__ + 16 * chh;          \
+        R0 = ld8(q__);                                                                                \
+        R1 = ld8(q__ + 8);                                                                            \
+      } else {                                                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                              \
+            XF[ks].v = ld8(ximg + (rowoff__ + fxx) * Cin + ks * 16 + 8 * fh);                         \
+      }                                                                                               \
+    } while (0)
+    FOD_BNK_REQUEST_SC(0, res0, res1, xb);
     for (int r = 0; r < nrows; ++r) {
-      const int yy = y0 + r;
-      {
-        const __bf16* q = ximg + ((long)(y0 + min(r + 1, nrows - 1)) * p.W + pxx) * Cin;
-        if (!PROJ) {
+     const int yy = y0 + r;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) resn[g] = ld4(q + 32 * wave + 8 * g + 4 * fh);
-        } else {
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) xbn[ks].v = ld8(q + ks * 16 + 8 * fh);
-        }
-      }
+     for (int t = 0; t < 2; ++t) {                  // (compile-time t: a3 / ad indexed by a runtime value would go to scratch)
+      const int it = 2 * r + t;
+      FOD_BNK_REQUEST_SC(it + 1, res0n, res1n, xbn);
       f32x16 acc;
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -228,29 +229,43 @@ __global__ __launch_bounds__(512, 4) void bottleneck_fused_kernel(const BnkParam
       for (int ks = 0; ks < 4; ++ks) {
         Frag<__bf16> bfr;
         bfr.v = *reinterpret_cast<const bf16x8_t*>(R + r * ROWB + at(fr, 2 * ks + fh));
-        mma16(a3[ks], bfr, acc);
+        mma16(a3[t][ks], bfr, acc);
       }
-      if (PROJ) {                                   // projection shortcut (the stage's first block): Wd . X on the same pixels
+      if (p.wd) {                                   // projection shortcut (the stage's first block): Wd . X on the same pixels
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) mma16(ad[ks], xb[ks], acc);
+        for (int ks = 0; ks < 4; ++ks) mma16(ad[t][ks], xb[ks], acc);
       }
-      if (store_ok) {
-        __bf16* dst = p.out + ((long)n * p.H * p.W + (long)yy * p.W + x0 + fr) * 256 + 32 * wave + 4 * fh;
+      const int cbase = 64 * wave + 32 * t;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          bf16x4_t o;
+      for (int g = 0; g < 4; ++g) {
+        const int c = cbase + 8 * g + 4 * fh;
+        f32x4 sh = *reinterpret_cast<const f32x4*>(p.b3 + c);
+        if (p.wd) sh += *reinterpret_cast<const f32x4*>(p.bd + c);
+        *reinterpret_cast<f32x4*>(OS + at(fr, 2 * g + fh)) =
+            f32x4{acc[4 * g] + sh[0], acc[4 * g + 1] + sh[1], acc[4 * g + 2] + sh[2], acc[4 * g + 3] + sh[3]};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // wave-private slab: LDS operations of a wave are in order
+      f32x4 v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaxf(acc[4 * g + e] + sh[g][e] + (PROJ ? 0.f : (float)res[g][e]), 0.f);
-          *reinterpret_cast<bf16x4_t*>(dst + 8 * g) = o;
+      for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(OS + at(cpx, 4 * chh + q));
+      if (cpx < TW && x0 + cpx < p.W) {
+        bf16x8_t o0, o1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o0[e] = (__bf16)fmaxf(v[e >> 2][e & 3] + (float)res0[e], 0.f);          // (projection: res stays zero)
+          o1[e] = (__bf16)fmaxf(v[2 + (e >> 2)][e & 3] + (float)res1[e], 0.f);
         }
+        __bf16* dst = p.out + ((long)n * p.H * p.W + (long)yy * p.W + x0 + cpx) * 256 + cbase + 16 * chh;
+        *reinterpret_cast<bf16x8_t*>(dst) = o0;
+        *reinterpret_cast<bf16x8_t*>(dst + 8) = o1;
       }
-      if (!PROJ) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) res[g] = resn[g];
-      } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!p.wd) { res0 = res0n; res1 = res1n; }
+      else if (t == 1) {                            // the projection's B fragments belong to a row: refresh after its second tile
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) xb[ks] = xbn[ks];
       }
+     }
     }
   }
 }
@@ -275,9 +290,7 @@ extern "C" int fod_bottleneck_fused_fwd(int dtype, const void* x, const void* w1
   p.N = Nimg; p.H = H; p.W = W; p.Cin = Cin;
   const dim3 grid(ceil_div(W, TW), ceil_div(H, TH), Nimg);
   FOD_REQUIRE(grid.y <= 65535, "bottleneck_fused: image too tall");
-  FOD_REQUIRE((long)H * W * Cin < (1L << 31), "bottleneck_fused: image larger than 2^31 elements");
-  if (wd) hipLaunchKernelGGL(bottleneck_fused_kernel<true>, grid, dim3(512), 0, stream, p);
-  else hipLaunchKernelGGL(bottleneck_fused_kernel<false>, grid, dim3(512), 0, stream, p);
+  hipLaunchKernelGGL(bottleneck_fused_kernel, grid, dim3(256), 0, stream, p);
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }

@@ -136,13 +136,18 @@ def _conv_fwd(x, cw, bn, dtype, relu, residual=None, cin_pad=None, out=None):
                           out=out), geom
 
 
-FUSED_BOTTLENECK = os.environ.get("FOD_FUSED_BOTTLENECK", "1") != "0"
+# "1" (default): the frozen stage's FIRST block (projection shortcut) runs as one launch -- measured 453 vs 533 us for its
+# four separate launches at 10 x 225 x 400; the identity blocks tie (450 vs 434 us) and stay layer by layer.
+# "2": every frozen 64-channel bottleneck fused; "0": none.  profiles/r03i_fused_bottleneck.txt
+FUSED_BOTTLENECK = os.environ.get("FOD_FUSED_BOTTLENECK", "1")
 
 
-def _fusable(blk, x, dtype):
+def _fusable(blk, x, dtype, force=False):
     """fod_bottleneck_fused_fwd's domain: bf16, stride-1 bottleneck of width 64 with an identity (Cin 256) or 1x1
-    projection (Cin 64) shortcut -- torchvision ResNet-50's layer1."""
-    if not FUSED_BOTTLENECK or dtype != torch.bfloat16 or blk.kind == "basic":
+    projection (Cin 64) shortcut -- torchvision ResNet-50's layer1.  `force`: the domain only, not the policy."""
+    if (FUSED_BOTTLENECK == "0" and not force) or dtype != torch.bfloat16 or blk.kind == "basic":
+        return False
+    if FUSED_BOTTLENECK == "1" and not force and blk.downsample is None:
         return False
     main, ds = blk.convs()
     c1, c2, c3 = main[0][0], main[1][0], main[2][0]

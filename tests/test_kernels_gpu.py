@@ -1042,7 +1042,7 @@ def test_fused_frozen_bottleneck_matches_the_layer_by_layer_path(cin, shape):
             m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2); m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
     dtype = torch.bfloat16
     x = rnd((n, h, w, cin), dtype, 9).to(DEV)
-    assert BB._fusable(blk, x, dtype)
+    assert BB._fusable(blk, x, dtype, force=True)
     fused = BB._fused_bottleneck(blk, x, dtype)
     main, ds = blk.convs()
     idt = x if ds is None else BB._conv_fwd(x, ds[0], ds[1], dtype, relu=False)[0]
