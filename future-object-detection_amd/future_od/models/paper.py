@@ -73,12 +73,10 @@ class CDetrBackbone(nn.Module):
 
     def __init__(self, name: str, train_backbone: bool, dilation: bool, hidden_dim: int, pretrained=True):
         super().__init__()
-        if dilation:
-            raise NotImplementedError("dilated layer4 is never used by the reference's runs/ (runs/_model.py:22)")
         if pretrained and is_main_process():
             print("[future_od] pretrained torchvision weights cannot be fetched here (no torchvision / network): "
                   "the backbone keeps its random init until a checkpoint is loaded.")
-        self.body = ResNetBody(name)
+        self.body = ResNetBody(name, dilate_layer4=bool(dilation))
         self.num_channels = 512 if name in ("resnet18", "resnet34") else 2048
         for pname, p in self.body.named_parameters():
             if not train_backbone or ("layer2" not in pname and "layer3" not in pname and "layer4" not in pname):
@@ -99,8 +97,6 @@ class SeparateEncoder(nn.Module):
     def __init__(self, backbone: CDetrBackbone, transformer: TransformerEncoder = None,
                  imu_layers: nn.Module = None, concat_imu: bool = False):
         super().__init__()
-        if concat_imu:
-            raise NotImplementedError("concat_imu is never used by the reference's runs/")
         self.backbone = backbone
         self.imu_layers = imu_layers
         self.transformer = transformer
@@ -123,6 +119,13 @@ class SeparateEncoder(nn.Module):
             lin0, lin2 = self.imu_layers[0], self.imu_layers[2]
             h0 = _linear_padded_in(x, lin0, I, relu=True)
             ego = Fn.linear(h0, lin2.weight, lin2.bias)
+        if self.concat_imu:
+            # reference paper.py:153-156: the ego-motion code is added to every pixel of its frame's features and is
+            # then NOT handed on as a token ("concat" in name only)
+            if ego is None:
+                raise ValueError("concat_imu needs imu data and imu_layers")
+            tokens = tokens + ego.unsqueeze(1)
+            ego = None
         if self.transformer:
             pos = pos_encoder.spatial_table(h, w, D, dtype, feat.device)
             tokens = self.transformer(tokens, pos, ego)
@@ -328,7 +331,9 @@ class FuturePredCore(nn.Module):
 
     drop_future = True                     # the last frame of the clip is the one to predict, never an input
 
-    def forward(self, images: Tensor, imu: Tensor = None, temporal_offsets: Tensor = None):
+    def forward(self, images: Tensor, imu: Tensor = None, temporal_offsets: Tensor = None, temporal_table=None):
+        """temporal_table: optional f32 [B, past, D] that replaces the temporal term computed from this clip (the
+        tracker baseline runs single frames with the term of a three-frame clip)."""
         B, L = images.shape[:2]
         past = L - 1 if self.drop_future else L
         assert past > 0
@@ -347,7 +352,9 @@ class FuturePredCore(nn.Module):
             # + the per-(batch, frame) temporal term (reference paper.py:50-55,66-73), computed over ALL past
             # frames (it is normalised by the last one) and cut to the frames that are kept
             offs = temporal_offsets[:, :past] if temporal_offsets is not None else None
-            tt = self.pos_encoder.temporal_table(B, past, D, torch.float32, tokens.device, offs)[:, past - keep:]
+            tt = temporal_table if temporal_table is not None else \
+                self.pos_encoder.temporal_table(B, past, D, torch.float32, tokens.device, offs)
+            tt = tt[:, past - keep:]
             pos_all = lambda: (spatial.float()[None, None] + tt[:, :, None]).reshape(B, keep * N, D).to(self.compute_dtype)
             pos_at = lambda l: (spatial.float()[None] + tt[:, l, None]).to(self.compute_dtype).contiguous()    # [B, N, D]
         else:
@@ -442,11 +449,16 @@ class TrackerBaselineCore(SingleFrameCore):
             return super().forward(images, imu, temporal_offsets)
         if L != 3:
             raise ValueError("TrackerBaselineCore takes clips of 1 frame (detect) or 3 frames (detect, detect, extrapolate)")
+        tt3 = None
         if not self.pos_encoder._no_temporal:
-            raise NotImplementedError("TrackerBaselineCore with the temporal positional term")
+            # the reference builds the encoding of the whole three-frame clip (its temporal term is normalised by
+            # the LAST frame's offset, paper.py:66-73) and hands each detector pass its frame's slice (:684-700)
+            D = self.detector.query_embed.weight.shape[1]
+            tt3 = self.pos_encoder.temporal_table(B, 3, D, torch.float32, images.device, temporal_offsets)
         preds = []
         for l in range(2):                                     # each frame on its own, as a first frame (reference :693-700)
-            out, _ = super().forward(images[:, l:l + 1], imu[:, l:l + 1] if imu is not None else None, None)
+            out, _ = super().forward(images[:, l:l + 1], imu[:, l:l + 1] if imu is not None else None, None,
+                                     temporal_table=None if tt3 is None else tt3[:, l:l + 1])
             preds.append(out)
         pred = self.tracker_future_predictor(preds[0], preds[1], temporal_offsets)
         return pred, [["model happy" for _ in range(L)] for _ in range(B)]

@@ -87,6 +87,14 @@ class OutProj(nn.Module):
         nn.init.constant_(self.out_proj.bias, 0.0)
 
 
+def _no_masks(attn_mask, key_padding_mask):
+    """The reference's wrappers hand attn_mask / key_padding_mask on to MultiheadAttention (transformer.py:61-82,
+    122-181, 401-419) and every caller in the reference passes None (transformer.py:270-307, 464-487, paper.py:164):
+    the attention kernels have no mask operand, so anything else is refused rather than ignored."""
+    if attn_mask is not None or key_padding_mask is not None:
+        raise NotImplementedError("attention masks: fod_attn_fwd has no mask operand (the reference always passes None)")
+
+
 class Attention(nn.Module):
     def __init__(self, D):
         super().__init__()
@@ -106,9 +114,10 @@ class SlotToSlotAttention(Attention):
         self.Nhead, self.D = Nhead, D
         self.droprate = dropout            # on the attention probabilities (MultiheadAttention(dropout=...), reference :64)
 
-    def forward(self, x, qpos, pos_proj=None):
+    def forward(self, x, qpos, pos_proj=None, attn_mask=None, key_padding_mask=None):
         """`pos_proj` = (query_pos(qpos), key_pos(qpos)) when the decoder has projected the (layer-independent)
         query positions for all layers at once."""
+        _no_masks(attn_mask, key_padding_mask)
         M = qpos.shape[0]
         qp, kp = pos_proj if pos_proj is not None else (_lin(qpos, self.query_pos), _lin(qpos, self.key_pos))
         qc, kc, v = Fn.group_linear(x, [self.query_content, self.key_content, self.value])
@@ -195,11 +204,13 @@ class SlotToImageAttention(Attention):
         self.droprate = dropout            # on the attention probabilities (reference :126)
         self.store_attention = False
 
-    def forward(self, x, qpos, query_sine, side, layer, image, is_first, qs=None, qpos_proj=None, keep=False):
+    def forward(self, x, qpos, query_sine, side, layer, image, is_first, qs=None, qpos_proj=None, keep=False,
+                attn_mask=None, key_padding_mask=None):
         """`side` (functional.MemorySide) holds this image's value / key_content projections for ALL layers
         and the projected positional table; this call uses the (layer, image) slots.  `qs` = query_sine(query_sine)
         and `qpos_proj` = query_pos(qpos) when the caller has projected them for all images at once.
         `keep`: also return x for the residual step (one autograd consumer of x instead of two, Fn.LinearKeepFn)."""
+        _no_masks(attn_mask, key_padding_mask)
         B, M, D = x.shape
         if keep:
             x_keep, qc = Fn.linear_keep(x, self.query_content.weight, self.query_content.bias)
@@ -374,10 +385,11 @@ class EncoderAttention(nn.Module):
         self.D, self.H = Dsrc, num_heads
         self.droprate = droprate
 
-    def forward(self, src, pos, other=None):
+    def forward(self, src, pos, other=None, attn_mask=None, key_padding_mask=None):
         """src [F,N,D]; pos table [N,D] or per-batch [F,N,D].  Self form: q = k = src + pos, v = src.  Cross form
         (`other` [F,N,D]: the previous frame's output or an earlier frame's features, reference :464-478):
         q = src + pos, k = other + pos, v = other."""
+        _no_masks(attn_mask, key_padding_mask)
         D = self.D
         N = pos.shape[-2]
         add_pos = (lambda t: Fn.add(t, pos, b_row_mod=N)) if pos.dim() == 2 else (lambda t: Fn.add(t, pos))

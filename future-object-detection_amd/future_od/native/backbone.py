@@ -54,25 +54,30 @@ class FrozenBatchNorm2d(nn.Module):
 class ConvWeight(nn.Module):
     """Holds an OIHW conv weight (channels_last storage = the kernels' [Cout][kh][kw][Cin] order)."""
 
-    def __init__(self, cin, cout, k, stride, pad, bias=False):
+    def __init__(self, cin, cout, k, stride, pad, bias=False, dilation=1):
         super().__init__()
         w = torch.empty(cout, cin, k, k)
         nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")
         self.weight = nn.Parameter(w.contiguous(memory_format=torch.channels_last))
         self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
-        self.k, self.stride, self.pad = k, stride, pad
+        # dilation 2 (3x3, stride 1, pad = dilation) is run by BackboneFn as an ordinary 3x3 on the four pixel-parity
+        # sub-grids; k / stride / pad describe THAT convolution
+        self.k, self.stride, self.pad, self.dilation = k, stride, pad, dilation
 
 
 class _Block(nn.Module):
-    def __init__(self, kind, cin, width, stride, exp):
+    def __init__(self, kind, cin, width, stride, exp, dilation=1):
         super().__init__()
         self.kind = kind
+        self.dilation = dilation
+        if kind == "basic" and dilation > 1:
+            raise NotImplementedError("Dilation > 1 not supported in BasicBlock")       # torchvision's own refusal
         if kind == "basic":
             self.conv1, self.bn1 = ConvWeight(cin, width, 3, stride, 1), FrozenBatchNorm2d(width)
             self.conv2, self.bn2 = ConvWeight(width, width, 3, 1, 1), FrozenBatchNorm2d(width)
         else:
             self.conv1, self.bn1 = ConvWeight(cin, width, 1, 1, 0), FrozenBatchNorm2d(width)
-            self.conv2, self.bn2 = ConvWeight(width, width, 3, stride, 1), FrozenBatchNorm2d(width)
+            self.conv2, self.bn2 = ConvWeight(width, width, 3, stride, 1, dilation=dilation), FrozenBatchNorm2d(width)
             self.conv3, self.bn3 = ConvWeight(width, width * 4, 1, 1, 0), FrozenBatchNorm2d(width * 4)
         self.downsample = None
         if stride != 1 or cin != width * exp:
@@ -91,15 +96,20 @@ class _Block(nn.Module):
 class ResNetBody(nn.Module):
     """conv1/bn1/layer1..4 containers with torchvision's names (what IntermediateLayerGetter keeps)."""
 
-    def __init__(self, name):
+    def __init__(self, name, dilate_layer4=False):
+        """dilate_layer4: torchvision's replace_stride_with_dilation=[False, False, True] (reference paper.py:95):
+        layer4 keeps layer3's resolution; its first block runs undilated with stride 1, the others with a 3x3 of
+        dilation 2 (ResNet._make_layer: previous_dilation for block 0, the stage's dilation after it)."""
         super().__init__()
         kind, depths, exp = RESNET_SPECS[name]
         self.conv1, self.bn1 = ConvWeight(3, 64, 7, 2, 3), FrozenBatchNorm2d(64)
         cin = 64
         for s, (width, depth) in enumerate(zip(STAGE_WIDTH, depths)):
             blocks = []
+            dilated = dilate_layer4 and s == 3
             for i in range(depth):
-                blocks.append(_Block(kind, cin, width, 2 if (i == 0 and s > 0) else 1, exp))
+                stride = 2 if (i == 0 and s > 0 and not dilated) else 1
+                blocks.append(_Block(kind, cin, width, stride, exp, dilation=2 if (dilated and i > 0) else 1))
                 cin = width * exp
             setattr(self, f"layer{s + 1}", nn.Sequential(*blocks))
         self.out_channels = cin
@@ -170,6 +180,42 @@ def _fused_bottleneck(blk, x, dtype, out=None):
     return ops.bottleneck_fused_fwd(x, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2], wd, bd, out=out)
 
 
+def _parity_split(x):
+    """[F,H,W,C] -> [(i j f), ceil(H/2), ceil(W/2), C]: the four pixel-parity sub-grids as extra images (a zero row /
+    column where H / W is odd).  A dilation-2 "same" 3x3 on x IS an ordinary pad-1 3x3 on these, and every 1x1 and
+    pointwise step of a bottleneck commutes with the rearrangement, so whole dilated blocks run in this layout."""
+    F_, H, W, C = x.shape
+    h2, w2 = (H + 1) // 2, (W + 1) // 2
+    t = (x.new_zeros if (H % 2 or W % 2) else x.new_empty)((2, 2, F_, h2, w2, C))
+    for i in range(2):
+        for j in range(2):
+            sub = x[:, i::2, j::2]
+            t[i, j, :, :sub.shape[1], :sub.shape[2]].copy_(sub)
+    return t.view(4 * F_, h2, w2, C)
+
+
+def _parity_merge(t, H, W):
+    """Inverse of _parity_split (the pad row / column is dropped)."""
+    F4, h2, w2, C = t.shape
+    t6 = t.view(2, 2, F4 // 4, h2, w2, C)
+    x = t.new_empty((F4 // 4, H, W, C))
+    for i in range(2):
+        for j in range(2):
+            dst = x[:, i::2, j::2]
+            dst.copy_(t6[i, j, :, :dst.shape[1], :dst.shape[2]])
+    return x
+
+
+def _zero_parity_pads(t, H, W):
+    """The pad row / column of the odd sub-grids must read as the convolution's zero padding."""
+    F4, h2, w2, C = t.shape
+    t6 = t.view(2, 2, F4 // 4, h2, w2, C)
+    if H % 2:
+        t6[1, :, :, h2 - 1].zero_()
+    if W % 2:
+        t6[:, 1, :, :, w2 - 1].zero_()
+
+
 def _scale7(bn, scale):
     """The frozen-BN scale repeated per tap row ([Cout*7], the row index of the stem weight's permute job)."""
     hit = getattr(bn, "_s7", None)
@@ -188,8 +234,9 @@ class BackboneFn(Function):
         w_stem = Fn.prep_stem(body.conv1.weight, dtype, _scale7(body.bn1, scale1))
         norm = body.pixel_norm(video)
 
-        def block_fwd(blk, x, out=None, frozen=False):
-            """One residual block forward; returns (output, activations, geometries, downsample geometry)."""
+        def block_fwd(blk, x, out=None, frozen=False, pads=None):
+            """One residual block forward; returns (output, activations, geometries, downsample geometry).
+            pads = (H, W) of the full grid when x holds the parity sub-grids of a dilated block."""
             main, ds = blk.convs()
             if frozen and _fusable(blk, x, dtype):
                 # a frozen 64-channel bottleneck keeps nothing for backward: one launch, intermediates stay on the CU
@@ -203,6 +250,10 @@ class BackboneFn(Function):
                 last = j == len(main) - 1
                 h, g = _conv_fwd(h, cw, bn, dtype, relu=True, residual=idt if last else None,
                                  out=out if last else None)
+                if pads is not None and j == 0:
+                    # the 3x3's input: zeros where the full grid has no pixel.  The backward needs nothing extra --
+                    # the ReLU mask of this (zeroed) activation already drops the gradient there
+                    _zero_parity_pads(h, *pads)
                 acts.append(h)
                 geoms.append(g)
             return h, acts, geoms, ds_geom
@@ -214,7 +265,8 @@ class BackboneFn(Function):
         # the 256 MB Infinity Cache when its consumer reads it.  Measured (profiles/r02b): no gain -- conv forward
         # 5.35 ms with all 10 frames per launch, 5.58 / 5.45 ms with 2 / 4 -- so the default is all frames at once.
         n_front = 0
-        while n_front < len(blocks) and not blocks[n_front][1].convs()[0][0][0].weight.requires_grad:
+        while (n_front < len(blocks) and blocks[n_front][1].dilation == 1
+               and not blocks[n_front][1].convs()[0][0][0].weight.requires_grad):
             n_front += 1
         b_sz, l_sz = video.shape[0], video.shape[1]
         steps = max(1, min(l_sz, FRONT_FRAMES // max(b_sz, 1)))
@@ -241,10 +293,20 @@ class BackboneFn(Function):
                 x[l0 * b_sz:(l0 + part.shape[1]) * b_sz].copy_(h)
             del h
         tape = []
+        dom = None                                       # (H, W) while x holds the parity sub-grids (dilated blocks)
         for _stage, blk in blocks[n_front:]:
-            x, acts, geoms, ds_geom = block_fwd(blk, x)
+            if blk.dilation not in (1, 2):
+                raise NotImplementedError(f"bottleneck dilation {blk.dilation}")
+            if blk.dilation == 2 and dom is None:
+                dom = (x.shape[1], x.shape[2])
+                x = _parity_split(x)
+            elif blk.dilation == 1 and dom is not None:
+                x, dom = _parity_merge(x, *dom), None
+            x, acts, geoms, ds_geom = block_fwd(blk, x, pads=dom)
             if blk.convs()[0][0][0].weight.requires_grad:
-                tape.append((blk, acts, geoms, ds_geom))
+                tape.append((blk, acts, geoms, ds_geom, dom))
+        if dom is not None:
+            x = _parity_merge(x, *dom)
         geom_p = ops.conv_geom(x.shape, proj.weight.shape[0], 1, 1, 0)
         wp = Fn.prep_conv(proj.weight, dtype, None, False)
         feat = ops.conv2d_fwd(x, wp, geom_p, shift=proj.bias.detach())
@@ -281,8 +343,13 @@ class BackboneFn(Function):
         if tape:
             # gradient wrt the last block's output, gated by that ReLU (x_last = relu(...))
             g = ops.conv2d_dgrad(g, Fn.prep_conv(proj.weight, dtype, None, True), ctx.geom_p, relu_mask=ctx.x_last)
+        gdom = None                                      # the layout g is in, as in forward
         for bi in range(len(tape) - 1, -1, -1):
-            blk, acts, geoms, ds_geom = tape[bi]
+            blk, acts, geoms, ds_geom, dom = tape[bi]
+            if dom is not None and gdom is None:
+                g, gdom = _parity_split(g), dom
+            elif dom is None and gdom is not None:
+                g, gdom = _parity_merge(g, *gdom), None
             main, ds = blk.convs()
             need_dx = bi > 0
             g_out = g                                   # already masked by (block output > 0)

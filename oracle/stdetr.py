@@ -57,6 +57,8 @@ class Config:
     single_frame: bool = False          # paper.py:488-528 SingleFrameCore: no frame is dropped, no joint encoder; its
                                         # SeparateEncoder is called `encoder` (see rename_for_core)
     train_backbone: bool = True         # runs/_model.py:21 (lr_backbone > 0)
+    dilation: bool = False              # paper.py:95 replace_stride_with_dilation=[False, False, dilation] (runs/_model.py:22: False)
+    concat_imu: bool = False            # paper.py:153-156 SeparateEncoder(concat_imu=True): ego code added to the features, no ego token
     # matcher / loss (st_detr.py:41-51)
     set_cost_class: float = 2.0
     set_cost_bbox: float = 5.0
@@ -109,7 +111,7 @@ def resnet_conv_list(name):
     cin = 64
     for s, (width, depth) in enumerate(zip(STAGE_WIDTH, depths)):
         for i in range(depth):
-            stride = 2 if (i == 0 and s > 0) else 1
+            stride = 2 if (i == 0 and s > 0) else 1          # (weight shapes only: cfg.dilation changes no shape)
             p = f"layer{s + 1}.{i}."
             if kind == "basic":
                 convs.append((p + "conv1", cin, width, 3, stride, 1, p + "bn1", s + 1))
@@ -284,8 +286,8 @@ def backbone_forward(sd, cfg: Config, images, taps: Optional[dict] = None):
     body = P_BB + "body."
     kind, depths, exp = RESNET_SPECS[cfg.backbone]
 
-    def conv(x, key, stride, pad):
-        return F.conv2d(x, sd[body + key + ".weight"], None, stride, pad)
+    def conv(x, key, stride, pad, dil=1):
+        return F.conv2d(x, sd[body + key + ".weight"], None, stride, pad, dil)
 
     x = F.relu(_bn(sd, body + "bn1", conv(images, "conv1", 2, 3)))
     x = F.max_pool2d(x, 3, 2, 1)
@@ -293,18 +295,24 @@ def backbone_forward(sd, cfg: Config, images, taps: Optional[dict] = None):
         taps["stem"] = x
     cin = 64
     for s, (width, depth) in enumerate(zip(STAGE_WIDTH, depths)):
+        # torchvision _make_layer(dilate=True), layer4 only (paper.py:95): the stage keeps the resolution, its first
+        # block runs at the previous dilation (1), the others with a 3x3 of dilation 2 / padding 2
+        dilated = cfg.dilation and s == 3
         for i in range(depth):
-            stride = 2 if (i == 0 and s > 0) else 1
+            stride = 2 if (i == 0 and s > 0 and not dilated) else 1
+            dil = 2 if (dilated and i > 0) else 1
             p = f"layer{s + 1}.{i}."
             idt = x
             if stride != 1 or cin != width * exp:
                 idt = _bn(sd, body + p + "downsample.1", conv(x, p + "downsample.0", stride, 0))
             if kind == "basic":
+                if dilated:
+                    raise NotImplementedError("Dilation > 1 not supported in BasicBlock")     # torchvision's own refusal
                 y = F.relu(_bn(sd, body + p + "bn1", conv(x, p + "conv1", stride, 1)))
                 y = _bn(sd, body + p + "bn2", conv(y, p + "conv2", 1, 1))
             else:
                 y = F.relu(_bn(sd, body + p + "bn1", conv(x, p + "conv1", 1, 0)))
-                y = F.relu(_bn(sd, body + p + "bn2", conv(y, p + "conv2", stride, 1)))
+                y = F.relu(_bn(sd, body + p + "bn2", conv(y, p + "conv2", stride, dil, dil)))
                 y = _bn(sd, body + p + "bn3", conv(y, p + "conv3", 1, 0))
             x = F.relu(y + idt)
             cin = width * exp
@@ -432,6 +440,9 @@ def separate_encoder(sd, cfg, images, imu, taps=None):
     ego = None
     if imu is not None and cfg.use_imu:
         ego = _linear(sd, P_SEP + "imu_layers.2", F.relu(_linear(sd, P_SEP + "imu_layers.0", imu)))
+    if cfg.concat_imu:                                                 # paper.py:153-156
+        feat = feat + ego.reshape(B * L, D, 1, 1)
+        ego = None
     if cfg.enc_layers > 0:
         pos = spatial_pos_table(h, w, D, feat.device).flatten(1).t()[:, None, :].expand(-1, B * L, -1)
         x = feat.flatten(2).permute(2, 0, 1)                           # (h w) (b l) c
@@ -685,11 +696,20 @@ def tracker_future_predictor(pred1, pred2, temporal_offsets=None, dim_extrapolat
 
 
 def tracker_core_forward(sd, cfg, images, imu=None, temporal_offsets=None, dim_extrapolation=None):
-    """TrackerBaselineCore.forward, paper.py:665-706 (cfg.single_frame key names; no temporal term)."""
-    assert cfg.single_frame and cfg.no_temporal
+    """TrackerBaselineCore.forward, paper.py:665-706 (cfg.single_frame key names).  One frame: plain single-frame
+    detection.  Three frames: all are encoded (:681), the positional encoding -- temporal term included, normalised by
+    the LAST frame's offset -- is built for the whole clip (:684-686), the first two frames are detected each on its
+    own slice (:693-700) and the tracker extrapolates to the third (:701)."""
+    assert cfg.single_frame
     L = images.shape[1]
     if L == 1:
-        return core_forward(sd, cfg, images, imu)
+        return core_forward(sd, cfg, images, imu, temporal_offsets)
     assert L == 3
-    preds = [core_forward(sd, cfg, images[:, l:l + 1], imu[:, l:l + 1] if imu is not None else None) for l in range(2)]
+    feat, ego = separate_encoder(sd, cfg, images, imu)
+    B, _, D, h, w = feat.shape
+    pos = spatial_pos_table(h, w, D, feat.device)[None, None].expand(B, L, -1, -1, -1)
+    if not cfg.no_temporal:
+        pos = pos + temporal_pos_table(B, L, h, w, D, temporal_offsets, device=feat.device)
+    preds = [detector_forward(sd, cfg, feat[:, l:l + 1], pos[:, l:l + 1], False, None,
+                              ego[:, l:l + 1] if ego is not None else None) for l in range(2)]
     return tracker_future_predictor(preds[0], preds[1], temporal_offsets, dim_extrapolation)

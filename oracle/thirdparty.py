@@ -254,8 +254,10 @@ STAGE_WIDTH = (64, 128, 256, 512)
 
 
 class _Basic(nn.Module):
-    def __init__(self, cin, width, stride, norm, down):
+    def __init__(self, cin, width, stride, norm, down, dilation=1):
         super().__init__()
+        if dilation > 1:                                  # torchvision's BasicBlock refuses it the same way
+            raise NotImplementedError("Dilation > 1 not supported in BasicBlock")
         self.conv1 = nn.Conv2d(cin, width, 3, stride, 1, bias=False)
         self.bn1 = norm(width)
         self.relu = nn.ReLU(inplace=True)
@@ -271,11 +273,11 @@ class _Basic(nn.Module):
 
 
 class _Bottleneck(nn.Module):
-    def __init__(self, cin, width, stride, norm, down):
+    def __init__(self, cin, width, stride, norm, down, dilation=1):
         super().__init__()
         self.conv1 = nn.Conv2d(cin, width, 1, bias=False)
         self.bn1 = norm(width)
-        self.conv2 = nn.Conv2d(width, width, 3, stride, 1, bias=False)
+        self.conv2 = nn.Conv2d(width, width, 3, stride, dilation, dilation, bias=False)     # padding = dilation
         self.bn2 = norm(width)
         self.conv3 = nn.Conv2d(width, width * 4, 1, bias=False)
         self.bn3 = norm(width * 4)
@@ -295,7 +297,11 @@ class ResNet(nn.Module):
                  pretrained=False, num_classes=1000, **_unused):
         super().__init__()
         assert not pretrained, "no network: pretrained weights unavailable"
-        assert not replace_stride_with_dilation or not any(replace_stride_with_dilation)
+        # torchvision ResNet._make_layer(dilate=True): the stage's stride becomes 1 and its dilation is multiplied
+        # by that stride; the FIRST block still runs at the previous dilation, the others at the new one
+        dilate = tuple(replace_stride_with_dilation or (False, False, False))
+        assert len(dilate) == 3
+        dilation = 1
         kind, depths, exp = RESNET_SPECS[name]
         block = _Basic if kind == "basic" else _Bottleneck
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
@@ -305,13 +311,19 @@ class ResNet(nn.Module):
         cin = 64
         for s, (width, depth) in enumerate(zip(STAGE_WIDTH, depths)):
             blocks = []
+            previous_dilation = dilation
+            stage_stride = 2 if s > 0 else 1
+            if s > 0 and dilate[s - 1]:
+                dilation *= stage_stride
+                stage_stride = 1
             for i in range(depth):
-                stride = 2 if (i == 0 and s > 0) else 1
+                stride = stage_stride if i == 0 else 1
                 down = None
                 if stride != 1 or cin != width * exp:
                     down = nn.Sequential(nn.Conv2d(cin, width * exp, 1, stride, bias=False),
                                          norm_layer(width * exp))
-                blocks.append(block(cin, width, stride, norm_layer, down))
+                blocks.append(block(cin, width, stride, norm_layer, down,
+                                    dilation=previous_dilation if i == 0 else dilation))
                 cin = width * exp
             setattr(self, f"layer{s + 1}", nn.Sequential(*blocks))
         self.avgpool = nn.AdaptiveAvgPool2d(1)

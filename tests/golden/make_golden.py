@@ -81,11 +81,11 @@ def build_reference(cfg: Config, paper, transformer, st_detr):
                                             use_egodeep=cfg.use_imu)
         for _ in range(cfg.enc_layers)))
     sep = paper.SeparateEncoder(
-        backbone=paper.CDetrBackbone(name=cfg.backbone, train_backbone=True, dilation=False,
+        backbone=paper.CDetrBackbone(name=cfg.backbone, train_backbone=True, dilation=cfg.dilation,
                                      hidden_dim=cfg.hidden_dim, pretrained=False),
         imu_layers=nn.Sequential(nn.Linear(cfg.imu_dim, cfg.imu_hidden), nn.ReLU(inplace=True),
                                  nn.Linear(cfg.imu_hidden, cfg.hidden_dim)) if cfg.use_imu else None,
-        transformer=enc)
+        transformer=enc, concat_imu=cfg.concat_imu)
     core_kw = dict(encoder=sep) if cfg.single_frame else dict(separate_encoder=sep,
                                                               joint_encoder=joint_encoder(cfg, paper, transformer))
     core = (paper.SingleFrameCore if cfg.single_frame else paper.FuturePredCore)(
@@ -211,6 +211,14 @@ def main():
         "g16_multikey_egodeep": (Config(backbone="resnet18", enc_layers=1, joint_layers=1, joint_egodeep=True,
                                         dec_layers=2, num_images=1, image_memory_mode="attend all at once",
                                         dec_egodeep=True, no_temporal=False), 2, 4, 64, 96, 19),
+        # SeparateEncoder(concat_imu=True) (paper.py:153-156): the ego-motion code is added to the frame's features
+        # and no IMU token travels on
+        "g20_concat_imu": (Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2, concat_imu=True),
+                           2, 3, 64, 96, 22),
+        # CDetrBackbone(dilation=True) (paper.py:95): layer4 at layer3's resolution, 3x3s of dilation 2; the 80 x 144
+        # frames give layer3 a 5 x 9 map, odd both ways
+        "g21_dilated_r50": (Config(backbone="resnet50", enc_layers=1, dec_layers=1, num_images=2, dilation=True),
+                            2, 3, 80, 144, 23),
     }
     for name, (cfg, B, L, H, W, seed) in cases.items():
         if ONLY and name not in ONLY:
@@ -298,6 +306,21 @@ def main():
             out1, _ = core(data["video"][:, :1], imu=imu[:, :1])
         arrays.update(meta=np.array([2, 3, 64, 96, 32]), offs3=offs3, core3_boxes=out3["pred_boxes"],
                       core3_logits=out3["pred_logits"], core1_boxes=out1["pred_boxes"], core1_logits=out1["pred_logits"])
+        # the same core with the temporal positional term (PositionalEncoder(no_temporal=False)): the encoding is built
+        # for the three-frame clip and sliced per detector pass (paper.py:684-700)
+        cfg_t = Config(backbone="resnet18", enc_layers=1, dec_layers=1, num_images=1, single_frame=True, num_queries=32,
+                       no_temporal=False)
+        model_t = build_reference(cfg_t, paper, transformer, st_detr)
+        load_weights(model_t, cfg_t, 32)
+        st = model_t._model
+        core_t = paper.TrackerBaselineCore(encoder=st.encoder, detector=st.detector, pos_encoder=st.pos_encoder,
+                                           tracker_future_predictor=paper.TrackerFuturePredictor("linear")).eval()
+        offs3t = torch.tensor([[0.5, 1.0, 1.5], [0.4, 0.9, 1.6]])
+        with torch.no_grad():
+            out3t, _ = core_t(data["video"], imu=imu, temporal_offsets=offs3t)
+            out3n, _ = core_t(data["video"], imu=imu, temporal_offsets=None)
+        arrays.update(offs3t=offs3t, tcore3_boxes=out3t["pred_boxes"], tcore3_logits=out3t["pred_logits"],
+                      tcore3n_boxes=out3n["pred_boxes"], tcore3n_logits=out3n["pred_logits"])
         save("g18_tracker_baseline", **arrays)
 
     # ---------------------------------------------------------------- G3/G4 encoder & decoder stacks alone

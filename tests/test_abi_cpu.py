@@ -244,3 +244,29 @@ def test_weight_gradient_job_tables():
             assert len(cols) == 1, (slot, sp, cols)
     assert table[-1].nsplit == 1 and table[0].N1 * table[0].K2 == 2048 * 256      # largest problem first
     assert int((bj == -1).sum()) == nblocks - sum(((t.N1 + 127) // 128) * ((t.K2 + 127) // 128) * t.nsplit for t in table)
+
+
+def test_attention_wrappers_refuse_masks_and_constructor_options_build():
+    """Reference constructor / call options its runs/ never use: attention masks (transformer.py:61-82,122-181: always
+    None in the reference) are refused, not silently dropped; dilated layer4 and concat_imu construct (paper.py:90-95,
+    125) and a dilated BasicBlock is refused the way torchvision refuses it."""
+    import pytest
+    import torch
+    import future_od.models.transformer as T
+    from future_od.models.paper import CDetrBackbone, SeparateEncoder
+    x = torch.zeros(1, 4, 32)
+    for mod, args in ((T.SlotToSlotAttention(32, 4, 0.0), (x, torch.zeros(4, 32))),
+                      (T.EncoderAttention(32, 4, 64), (x, torch.zeros(4, 32)))):
+        with pytest.raises(NotImplementedError):
+            mod(*args, key_padding_mask=torch.zeros(1, 4, dtype=torch.bool))
+        with pytest.raises(NotImplementedError):
+            mod(*args, attn_mask=torch.zeros(4, 4))
+    with pytest.raises(NotImplementedError):
+        T.SlotToImageAttention(32, 4, 0.0)(x, None, None, None, 0, 0, True, attn_mask=torch.zeros(4, 4))
+    bb = CDetrBackbone("resnet50", True, True, 32, pretrained=False)
+    l4 = bb.body.layer4
+    assert [b.conv2.stride for b in l4] == [1, 1, 1] and [b.dilation for b in l4] == [1, 2, 2]
+    assert l4[0].downsample[0].stride == 1
+    with pytest.raises(NotImplementedError):
+        CDetrBackbone("resnet18", True, True, 32, pretrained=False)
+    assert SeparateEncoder(bb, None, None, concat_imu=True).concat_imu

@@ -12,6 +12,8 @@ from types import SimpleNamespace
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+# placeholder bounds, replaced by 3 x the measured deviations
+LOGIT_BOUND, BOX_BOUND = 0.05, 2e-2
 
 CONFIGS = {"cfg2": (4, 800, 1333, 2, 2), "nusc500-stage1": (3, 448, 800, 4, 2), "nusc500-stage2": (3, 896, 1600, 2, 2),
            "t8": (8, 900, 1600, 1, 7)}
@@ -49,14 +51,17 @@ def test_config_at_real_extent(name):
     if B > 1:
         one = {k: (v[:1] if isinstance(v, torch.Tensor) else v) for k, v in data.items() if k != "_host_annotations"}
         l1, b1 = _core(model, one)
-        assert float((l1[0] - la[0]).abs().max()) <= 0.05 * float(la[0].abs().max())
-        assert float((b1[0] - ba[0]).abs().max()) <= 2e-2
+        dl, db = float((l1[0] - la[0]).abs().max()) / float(la[0].abs().max()), float((b1[0] - ba[0]).abs().max())
+        print(f"{name}: batch independence: logits {dl:.3e} of max|logit|, boxes {db:.3e}")
+        assert dl <= LOGIT_BOUND and db <= BOX_BOUND, (dl, db)
     # past frames that cannot reach the output are skipped: same result with them computed
     if T - 1 > K:
         model._model.skip_dead_frames = False
         lf, bf = _core(model, data)
         model._model.skip_dead_frames = True
-        assert float((la - lf).abs().max()) <= 0.05 * float(lf.abs().max()) and float((ba - bf).abs().max()) <= 2e-2
+        dl, db = float((la - lf).abs().max()) / float(lf.abs().max()), float((ba - bf).abs().max())
+        print(f"{name}: dead-frame skipping: logits {dl:.3e} of max|logit|, boxes {db:.3e}")
+        assert dl <= LOGIT_BOUND and db <= BOX_BOUND, (dl, db)
     # the device-side matcher on this configuration's outputs = scipy on the same cost matrix, index for index
     packed = ops.pack_targets_dev(data["boxes"].float().contiguous(), data["classes"].contiguous(),
                                   data["active"].contiguous(), H, W)

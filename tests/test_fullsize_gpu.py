@@ -8,6 +8,8 @@ from types import SimpleNamespace
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+# placeholder bounds, replaced by 3 x the measured deviations
+LOGIT_BOUND, BOX_BOUND = 0.05, 2e-2
 T, H, W = 6, 900, 1600
 
 
@@ -40,8 +42,9 @@ def test_full_size_samples_are_independent_and_runs_repeat():
         one = {k: (v[i:i + 1] if isinstance(v, torch.Tensor) else v) for k, v in data.items() if k != "_host_annotations"}
         l1, b1 = _core(model, one)
         # tile shapes / split choices may differ with the row count, so equality is up to bf16 rounding of the activations
-        assert float((l1[0] - l2[i]).abs().max()) <= 0.05 * float(l2[i].abs().max()), i
-        assert float((b1[0] - b2[i]).abs().max()) <= 2e-2, i
+        dl, db = float((l1[0] - l2[i]).abs().max()) / float(l2[i].abs().max()), float((b1[0] - b2[i]).abs().max())
+        print(f"batch independence, sample {i}: logits {dl:.3e} of max|logit|, boxes {db:.3e}")
+        assert dl <= LOGIT_BOUND and db <= BOX_BOUND, (i, dl, db)
     assert torch.isfinite(l2).all() and (b2 >= 0).all() and (b2 <= 1).all()
 
 
@@ -61,7 +64,9 @@ def test_full_size_dead_frame_skipping_and_matching_properties():
     model._model.skip_dead_frames = False
     lb, bb = _core(model, data)
     model._model.skip_dead_frames = True
-    assert float((la - lb).abs().max()) <= 0.05 * float(lb.abs().max()) and float((ba - bb).abs().max()) <= 2e-2
+    dl, db = float((la - lb).abs().max()) / float(lb.abs().max()), float((ba - bb).abs().max())
+    print(f"dead-frame skipping: logits {dl:.3e} of max|logit|, boxes {db:.3e}")
+    assert dl <= LOGIT_BOUND and db <= BOX_BOUND, (dl, db)
     # matcher: cost on the device, assignment by the product solver vs scipy on the same matrix
     host = data["_host_annotations"]
     targets = to_detr_targets(H, W, host["active"], host["boxes"], host["classes"])

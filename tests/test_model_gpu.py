@@ -47,12 +47,12 @@ def build_product(cfg: Config, dtype, seed):
                                   enc_nheads=cfg.nheads, nheads=cfg.nheads, pretrained_backbone=False,
                                   encode_offset=not cfg.no_temporal)
     sep = SeparateEncoder(
-        backbone=CDetrBackbone(cfg.backbone, True, False, cfg.hidden_dim, pretrained=False),
+        backbone=CDetrBackbone(cfg.backbone, True, cfg.dilation, cfg.hidden_dim, pretrained=False),
         imu_layers=nn.Sequential(nn.Linear(cfg.imu_dim, cfg.imu_hidden), nn.ReLU(inplace=True),
                                  nn.Linear(cfg.imu_hidden, cfg.hidden_dim)) if cfg.use_imu else None,
         transformer=T.TransformerEncoder(nn.ModuleList(
             T.TransformerEncoderLayer(cfg.hidden_dim, cfg.nheads, cfg.dim_feedforward, use_egodeep=cfg.use_imu)
-            for _ in range(cfg.enc_layers))))
+            for _ in range(cfg.enc_layers))), concat_imu=cfg.concat_imu)
     core_kw = dict(encoder=sep) if cfg.single_frame else dict(separate_encoder=sep, joint_encoder=build_joint(cfg))
     core = (SingleFrameCore if cfg.single_frame else FuturePredCore)(
         **core_kw,
@@ -96,6 +96,9 @@ CASES = {
                                    num_images=1, image_memory_mode="attend all at once", dec_egodeep=True,
                                    no_temporal=False),
     "g17_single_frame_core": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2, single_frame=True),
+    # constructor options of paper.py the reference's runs/ leave at False
+    "g20_concat_imu": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2, concat_imu=True),
+    "g21_dilated_r50": Config(backbone="resnet50", enc_layers=1, dec_layers=1, num_images=2, dilation=True),
 }
 
 
@@ -316,6 +319,20 @@ def test_tracker_baseline_matches_reference_fixture(golden):
     rel_close(out3["pred_logits"], g["core3_logits"], 1e-3, "tracker core logits")
     rel_close(out1["pred_boxes"], g["core1_boxes"], 1e-3, "tracker core, one frame: boxes")
     rel_close(out1["pred_logits"], g["core1_logits"], 1e-3, "tracker core, one frame: logits")
+    # with the temporal positional term (reference paper.py:684-700: built over the three frames, sliced per pass)
+    cfg_t = Config(backbone="resnet18", enc_layers=1, dec_layers=1, num_images=1, single_frame=True, num_queries=32,
+                   no_temporal=False)
+    model_t, _ = build_product(cfg_t, torch.float32, seed)
+    st = model_t._model
+    core_t = TrackerBaselineCore(st.encoder, st.detector, st.pos_encoder, TrackerFuturePredictor("linear")).eval()
+    core_t.compute_dtype = torch.float32
+    with torch.no_grad():
+        out3t, _ = core_t(data["video"], imu=imu, temporal_offsets=t("offs3t"))
+        out3n, _ = core_t(data["video"], imu=imu, temporal_offsets=None)
+    rel_close(out3t["pred_boxes"], g["tcore3_boxes"], 1e-3, "tracker core + temporal term: boxes")
+    rel_close(out3t["pred_logits"], g["tcore3_logits"], 1e-3, "tracker core + temporal term: logits")
+    rel_close(out3n["pred_boxes"], g["tcore3n_boxes"], 1e-3, "tracker core + temporal term, frame indices: boxes")
+    rel_close(out3n["pred_logits"], g["tcore3n_logits"], 1e-3, "tracker core + temporal term, frame indices: logits")
 
 
 def test_ctypes_fallback_binding_still_runs_the_model():

@@ -84,6 +84,8 @@ CASES = {
                                    num_images=1, image_memory_mode="attend all at once", dec_egodeep=True,
                                    no_temporal=False),
     "g17_single_frame_core": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2, single_frame=True),
+    "g20_concat_imu": Config(backbone="resnet18", enc_layers=1, dec_layers=2, num_images=2, concat_imu=True),
+    "g21_dilated_r50": Config(backbone="resnet50", enc_layers=1, dec_layers=1, num_images=2, dilation=True),
 }
 
 
@@ -195,3 +197,11 @@ def test_g18_tracker_baseline(golden):
         out1 = O.tracker_core_forward(sd, cfg, data["video"][:, :1], imu[:, :1])
     close(out3["pred_boxes"], g["core3_boxes"]); close(out3["pred_logits"], g["core3_logits"])
     close(out1["pred_boxes"], g["core1_boxes"]); close(out1["pred_logits"], g["core1_logits"])
+    # with the temporal positional term: built over the three-frame clip, sliced per detector pass (paper.py:684-700)
+    cfg_t = Config(backbone="resnet18", enc_layers=1, dec_layers=1, num_images=1, single_frame=True, num_queries=32,
+                   no_temporal=False)
+    with torch.no_grad():
+        out3t = O.tracker_core_forward(sd, cfg_t, data["video"], imu, t("offs3t"), "linear")
+        out3n = O.tracker_core_forward(sd, cfg_t, data["video"], imu, None, "linear")
+    close(out3t["pred_boxes"], g["tcore3_boxes"]); close(out3t["pred_logits"], g["tcore3_logits"])
+    close(out3n["pred_boxes"], g["tcore3n_boxes"]); close(out3n["pred_logits"], g["tcore3n_logits"])
