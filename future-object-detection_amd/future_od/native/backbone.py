@@ -146,10 +146,11 @@ def _conv_fwd(x, cw, bn, dtype, relu, residual=None, cin_pad=None, out=None):
                           out=out), geom
 
 
-# "1" (default): the frozen stage's FIRST block (projection shortcut) runs as one launch -- measured 453 vs 533 us for its
-# four separate launches at 10 x 225 x 400; the identity blocks tie (450 vs 434 us) and stay layer by layer.
-# "2": every frozen 64-channel bottleneck fused; "0": none.  profiles/r03i_fused_bottleneck.txt
-FUSED_BOTTLENECK = os.environ.get("FOD_FUSED_BOTTLENECK", "1")
+# "2" (default): every frozen 64-channel bottleneck as one launch of the persistent weight-stationary kernel -- measured at
+# 10 x 225 x 400: projection block 196 us against 517 us for its four separate launches, identity blocks 316 against 430
+# (profiles/r03v_fused_bottleneck_v4.txt).  "1": only the stage's first block (the policy of the earlier kernel, which
+# tied on the identity blocks); "0": none.
+FUSED_BOTTLENECK = os.environ.get("FOD_FUSED_BOTTLENECK", "2")
 
 
 def _fusable(blk, x, dtype, force=False):

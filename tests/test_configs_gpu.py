@@ -12,8 +12,11 @@ from types import SimpleNamespace
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-# placeholder bounds, replaced by 3 x the measured deviations
-LOGIT_BOUND, BOX_BOUND = 0.05, 2e-2
+# bf16 mode, same sample in a different batch / with the dead frames computed: tile shapes and split choices change with
+# the row count, so activations round differently.  Measured on MI355X (round 3, all four workloads): logits <= 2.1e-3
+# of max|logit|, boxes identical.  Bounds = two bf16 ulps of the logit range (2 x 2^-8) and one bf16 ulp of a box
+# coordinate near 1 (2^-8); the round-2 bounds were 5e-2 / 2e-2.
+LOGIT_BOUND, BOX_BOUND = 8e-3, 4e-3
 
 CONFIGS = {"cfg2": (4, 800, 1333, 2, 2), "nusc500-stage1": (3, 448, 800, 4, 2), "nusc500-stage2": (3, 896, 1600, 2, 2),
            "t8": (8, 900, 1600, 1, 7)}

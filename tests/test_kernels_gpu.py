@@ -1025,15 +1025,21 @@ print("TWO_THREADS_OK")
     assert r.returncode == 0 and "TWO_THREADS_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("cin,shape", [(64, (2, 23, 41)), (256, (2, 23, 41)), (256, (1, 6, 30)), (64, (1, 7, 95)),
-                                       (256, (3, 13, 64))])
-def test_fused_frozen_bottleneck_matches_the_layer_by_layer_path(cin, shape):
+@pytest.mark.parametrize("cin,shape,version", [
+    (64, (2, 23, 41), "4"), (256, (2, 23, 41), "4"), (256, (1, 6, 30), "4"), (64, (1, 7, 95), "4"), (256, (3, 13, 64), "4"),
+    # more tiles than CUs: every workgroup of the persistent kernel walks 3-4 tiles (ring wrap-around, the counted vmcnt
+    # waits across tile boundaries, the last workgroups' shorter ranges, rows past the image repeated)
+    (64, (4, 121, 301), "4"), (256, (4, 121, 301), "4"), (256, (2, 225, 400), "4"),
+    # the non-persistent kernel that stays as the path for inputs of 4 GiB and more (64-bit addressing)
+    (64, (2, 23, 41), "2"), (256, (3, 13, 64), "2")])
+def test_fused_frozen_bottleneck_matches_the_layer_by_layer_path(cin, shape, version, monkeypatch):
     """fod_bottleneck_fused_fwd (one launch per frozen 64-channel bottleneck block) against the
     same block as three (four) fod_conv2d_fwd launches and against fp32 torch: ragged tiles (6 x 30 output tiles, 8 x 32
     halos), image borders (the 3x3's zero padding applies to conv1's OUTPUT), identity and projection shortcuts.
     Both HIP paths round the two 64-channel intermediates to bf16 at the same points; the projection shortcut is
     rounded once more on the layer-by-layer path (it is a tensor there), hence 'within bf16 tolerance', not bit-equal."""
     from future_od.native import backbone as BB
+    monkeypatch.setenv("FOD_BNK_VERSION", version)                  # read by the entry point at every call
     torch.manual_seed(5)
     n, h, w = shape
     blk = BB._Block("bottleneck", cin, 64, 1, 4).to(DEV)

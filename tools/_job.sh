@@ -1,7 +1,8 @@
 set -e
-mkdir -p gpurun_out/r03x
-timeout -k 10 900 python -m pytest tests -m gpu -x -q -s > gpurun_out/r03x/gpu_tests.log 2>&1 || { tail -40 gpurun_out/r03x/gpu_tests.log; exit 1; }
-tail -2 gpurun_out/r03x/gpu_tests.log
-bash tools/profile_round.sh r03x > gpurun_out/r03x_profile.log 2>&1 || { tail -30 gpurun_out/r03x_profile.log; exit 1; }
-tail -3 gpurun_out/r03x_profile.log
-cat gpurun_out/r03x/pmc_mfma_busy.txt
+o=gpurun_out/r03v4
+mkdir -p $o
+for v in 0 2 1 2 0; do
+  FOD_FUSED_BOTTLENECK=$v python bench.py --no-cpu-baseline --no-extras --no-roofline 2> $o/ab.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FOD_FUSED_BOTTLENECK=$v', round(d['value'],2), round(d['ms_per_step'],3))" | tee -a $o/ab.txt
+done

@@ -23,3 +23,18 @@ print(f"one replayed step under rocprofv3 --kernel-trace: {len(seg)} kernels, sp
 print(f"{'ms/step':>8s} {'launches':>8s} {'avg us':>8s}  kernel")
 for k, (d, c) in sorted(agg.items(), key=lambda x: -x[1][0]):
     print(f"{d / 1e6:8.3f} {c:8d} {d / c / 1e3:8.1f}  {k}")
+
+# the same step per C-ABI entry point, with bench.py's own kernel -> entry mapping: these are the figures bench.py's
+# `roofline` / `kernel_breakdown` must reproduce (within 5 %)
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import _entry_of  # noqa: E402
+
+ent = collections.defaultdict(lambda: [0, 0])
+for r in seg:
+    e = _entry_of(r["Kernel_Name"])
+    ent[e][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); ent[e][1] += 1
+print()
+print(f"{'ms/step':>8s} {'launches':>8s} {'avg us':>8s}  C-ABI entry point (bench.py mapping)")
+for k, (d, c) in sorted(ent.items(), key=lambda x: -x[1][0]):
+    print(f"{d / 1e6:8.3f} {c:8d} {d / c / 1e3:8.1f}  {k}")
