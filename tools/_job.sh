@@ -1,12 +1,4 @@
 set -e
-o=gpurun_out/r03bits
-mkdir -p $o
-for rep in 1 2; do
-for tag in old new; do
-  if [ $tag = old ]; then d=_ab_old; else d=.; fi
-  (cd $d && FOD_RELU_BITS=0 python bench.py --no-cpu-baseline --no-extras 2> /dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); kb=d['kernel_breakdown']
-print('$tag', round(d['ms_per_step'],3), {k: round(kb[k]['ms_per_step'],3) for k in ('fod_conv2d_fwd','fod_conv2d_dgrad','fod_conv2d_wgrad_acc','fod_gemm_nt')})") | tee -a $o/oldnew.txt
-done
-done
+mkdir -p gpurun_out/r03s
+timeout -k 10 200 python tools/probe_write_bw.py > gpurun_out/r03s/wbw.txt 2>&1 || { tail -20 gpurun_out/r03s/wbw.txt; exit 1; }
+cat gpurun_out/r03s/wbw.txt
