@@ -1030,6 +1030,8 @@ print("TWO_THREADS_OK")
     # more tiles than CUs: every workgroup of the persistent kernel walks 3-4 tiles (ring wrap-around, the counted vmcnt
     # waits across tile boundaries, the last workgroups' shorter ranges, rows past the image repeated)
     (64, (4, 121, 301), "4"), (256, (4, 121, 301), "4"), (256, (2, 225, 400), "4"),
+    # images smaller than one tile / one halo row, single pixels
+    (64, (2, 3, 5), "4"), (256, (3, 1, 1), "4"), (256, (1, 2, 33), "4"), (64, (1, 13, 2), "4"),
     # the non-persistent kernel that stays as the path for inputs of 4 GiB and more (64-bit addressing)
     (64, (2, 23, 41), "2"), (256, (3, 13, 64), "2")])
 def test_fused_frozen_bottleneck_matches_the_layer_by_layer_path(cin, shape, version, monkeypatch):

@@ -1,4 +1,4 @@
 set -e
-mkdir -p gpurun_out/r03s
-timeout -k 10 200 python tools/probe_write_bw.py > gpurun_out/r03s/wbw.txt 2>&1 || { tail -20 gpurun_out/r03s/wbw.txt; exit 1; }
-cat gpurun_out/r03s/wbw.txt
+mkdir -p gpurun_out/r03t
+timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "bottleneck" > gpurun_out/r03t/test.log 2>&1 || { tail -40 gpurun_out/r03t/test.log; exit 1; }
+tail -2 gpurun_out/r03t/test.log
