@@ -69,7 +69,7 @@ def pmc_traffic_per_launch(entry):
 
 # device kernel name (as the tracer reports it, demangled or not) -> C-ABI entry point whose launches it serves
 _KERNEL_ENTRY = [
-    (r"conv2d_fwd_kernel|conv_stem_fwd_kernel|nt_big_kernel(<|ILi)1|bottleneck_fused", "fod_conv2d_fwd"),
+    (r"conv2d_fwd_kernel|conv_stem_fwd_kernel|stem_pool_kernel|nt_big_kernel(<|ILi)1|bottleneck_fused", "fod_conv2d_fwd"),
     (r"conv2d_dgrad|nt_big_kernel(<|ILi)[23]", "fod_conv2d_dgrad"),
     (r"tn_big_kernel|tn_reduce_kernel", "fod_conv2d_wgrad_acc"),
     (r"gemm_nt_small_kernel|gemm_nt_kernel|gemm_nt_grouped|nt_big_kernel(<|ILi)0", "fod_gemm_nt"),

@@ -134,6 +134,9 @@ class ResNetBody(nn.Module):
         return c
 
 
+# the frozen stem and its max-pool as one launch (csrc/stem_pool.hip); "0": two launches
+FUSED_STEM_POOL = os.environ.get("FOD_FUSED_STEM_POOL", "1") != "0"
+
 # frames per pass of the frozen front (stem .. last frozen block); 0 (default) = all frames at once
 FRONT_FRAMES = int(os.environ.get("FOD_FRONT_FRAMES", "0")) or (1 << 30)
 
@@ -275,9 +278,15 @@ class BackboneFn(Function):
         for l0 in range(0, l_sz, steps):
             part = video[:, l0:l0 + steps]
             xp = ops.clip_to_stem_layout(part, dtype, *norm)
-            h = ops.conv_stem_fwd(xp, w_stem, video.shape[-2], video.shape[-1], shift=shift1, relu=True)
-            del xp
-            h = ops.maxpool3x3s2(h)
+            if FUSED_STEM_POOL and dtype == torch.bfloat16 and w_stem.shape[0] == 64:
+                # the stem is frozen (reference paper.py:102-109): conv + BN + ReLU + max-pool in one launch, the
+                # full-resolution map stays in LDS
+                h = ops.stem_pool_fwd(xp, w_stem, video.shape[-2], video.shape[-1], shift=shift1)
+                del xp
+            else:
+                h = ops.conv_stem_fwd(xp, w_stem, video.shape[-2], video.shape[-1], shift=shift1, relu=True)
+                del xp
+                h = ops.maxpool3x3s2(h)
             for i in range(n_front):
                 dst = None
                 if i == n_front - 1 and steps < l_sz:

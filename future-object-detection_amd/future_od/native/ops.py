@@ -293,6 +293,23 @@ def conv_stem_fwd(xp, w, h, wd, *, shift=None, relu=True):
     return y
 
 
+def stem_pool_fwd(xp, w, h, wd, *, shift=None):
+    """The frozen stem and its max-pool in one launch (bf16): xp / w as conv_stem_fwd ->
+    maxpool3x3s2(relu(stem(xp) + shift)) NHWC [F, Po, Qo, 64]."""
+    _chk(xp, "xp", torch.bfloat16); _chk(w, "w", torch.bfloat16)
+    f, hp, wp, c4 = xp.shape
+    ho, wo, hp_need, wp_need = stem_geom(h, wd)
+    cout = w.shape[0]
+    assert c4 == 4 and (hp, wp) == (hp_need, wp_need) and tuple(w.shape[1:]) == (7, 8, 4) and cout == 64, (xp.shape, w.shape)
+    if shift is not None:
+        _chk(shift, "shift", torch.float32); assert shift.numel() == cout
+    po, qo = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
+    y = torch.empty((f, po, qo, cout), dtype=xp.dtype, device=xp.device)
+    call("fod_stem_pool_fwd", dt(xp), ptr(xp), ptr(w), ptr(shift), ptr(y), f, hp, wp, ho, wo, cout, stream(),
+         work=2.0 * f * ho * wo * cout * 147, tag="fod_conv2d_fwd")
+    return y
+
+
 def conv2d_dgrad(dy, w_t, geom, *, residual=None, relu_mask=None, out=None):
     """dy NHWC [N,Ho,Wo,Cout], w_t [Cin, kh, kw, Cout] -> dx NHWC [N,H,W,Cin] (+residual, *mask>0).
     `out is residual`: accumulate in place (dx = mask(dx + dgrad(dy))); pixels that no tap reaches (three of the four

@@ -179,6 +179,11 @@ int fod_conv2d_fwd(int dtype, const void* x, const void* w, void* y, const fod_c
  * y: NHWC [Nimg][Ho][Wo][Cout].  Contracts over 7 x 32 = 224 instead of 7 x 7 x 8 = 392 padded taps. */
 int fod_conv_stem_fwd(int dtype, const void* xp, const void* w, void* y, int Nimg, int Hp, int Wp, int Ho, int Wo,
                       int Cout, const fod_epilogue* epi, fod_stream_t stream);
+/* The same stem followed by its 3x3 stride-2 pad-1 max-pool, in one launch (csrc/stem_pool.hip; bf16, Cout = 64):
+ *   y [Nimg][(Ho-1)/2+1][(Wo-1)/2+1][64] = maxpool(relu(conv_stem(xp, w) + shift)),  xp / w as for fod_conv_stem_fwd.
+ * For a FROZEN stem (the reference's, paper.py:102-109): the full-resolution 64-channel map is never materialised. */
+int fod_stem_pool_fwd(int dtype, const void* xp, const void* w, const float* shift, void* y, int Nimg, int Hp, int Wp,
+                      int Ho, int Wo, int Cout, fod_stream_t stream);
 /* dx = epi(conv2d_input_grad(dy, w)).  w_t is the weight re-laid as [Cin][kh][kw][Cout]. */
 int fod_conv2d_dgrad(int dtype, const void* dy, const void* w_t, void* dx, const fod_conv_geom* g,
                      const fod_epilogue* epi, fod_stream_t stream);

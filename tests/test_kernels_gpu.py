@@ -227,6 +227,34 @@ def test_conv2d_real_layer_shapes(dtype, case):
           f"conv wgrad {case}")
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 900, 1600), (3, 37, 61), (1, 14, 18), (2, 225, 31), (1, 7, 7), (5, 130, 250)])
+def test_fused_stem_and_maxpool_equal_the_two_launches(shape):
+    """fod_stem_pool_fwd (csrc/stem_pool.hip): the frozen stem's convolution + frozen BN + ReLU and the 3x3 stride-2 max-pool
+    in one launch against fod_conv_stem_fwd followed by fod_maxpool3x3s2 -- the same products in the same k order, so the
+    results are compared for EQUALITY; odd and tiny extents (tiles of 8 x 15 pooled pixels that hang over every border,
+    images smaller than one tile, several tiles per workgroup at 900 x 1600)."""
+    from future_od.native import backbone as BB
+    from future_od.native import functional as Fn
+    n, h, w = shape
+    dtype = torch.bfloat16
+    torch.manual_seed(3)
+    body = BB.ResNetBody("resnet18").to(DEV)
+    with torch.no_grad():
+        body.bn1.weight.uniform_(0.5, 1.5); body.bn1.bias.normal_(0, 0.3)
+        body.bn1.running_mean.normal_(0, 0.2); body.bn1.running_var.uniform_(0.5, 1.5)
+    scale1, shift1 = body.bn1.scale_shift()
+    w_stem = Fn.prep_stem(body.conv1.weight, dtype, BB._scale7(body.bn1, scale1))
+    video = torch.randn(1, n, 3, h, w, device=DEV)
+    xp = ops.clip_to_stem_layout(video, dtype)
+    two = ops.maxpool3x3s2(ops.conv_stem_fwd(xp, w_stem, h, w, shift=shift1, relu=True))
+    one = ops.stem_pool_fwd(xp, w_stem, h, w, shift=shift1)
+    assert one.shape == two.shape
+    assert torch.equal(one, two), float((one.float() - two.float()).abs().max())
+    ref = F.max_pool2d(torch.relu(F.conv2d(video[0], body.conv1.weight, None, 2, 3) * scale1.view(1, -1, 1, 1)
+                                  + shift1.view(1, -1, 1, 1)), 3, 2, 1).permute(0, 2, 3, 1)
+    check(one, ref.cpu(), dtype, 4, f"stem + pool {shape}")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_layout_helpers(dtype):
     v = torch.randn(3, 3, 10, 13)
