@@ -8,7 +8,7 @@ pids=()
 # attention: MFMA results stay in VGPRs (no AGPR round trip): the softmax reads every accumulator element, and
 # v_accvgpr_read was a fifth of the loop's vector instructions; the kernels also fit one more wave per SIMD.
 declare -A EXTRA=([attention]="-mllvm -amdgpu-mfma-vgpr-form=1" [attention_fp8]="-mllvm -amdgpu-mfma-vgpr-form=1" [gemm_nt_big]="-Wno-inline-asm" [gemm_tn_big]="-Wno-inline-asm" [bottleneck_fused]="-Wno-inline-asm")
-for f in gemm_nt gemm_nt_big stem_pool gemm_tn gemm_tn_big attention attention_fp8 bottleneck_fused elementwise loss optim lap_dev; do
+for f in gemm_nt gemm_nt_big stem_pool linear_norm gemm_tn gemm_tn_big attention attention_fp8 bottleneck_fused elementwise loss optim lap_dev; do
   hipcc $FLAGS ${EXTRA[$f]} -c csrc/$f.hip -o build/$f.o &
   pids+=($!)
 done

@@ -867,6 +867,11 @@ def layer_norm(x, gamma, beta, residual=None, res_row_div=0):
                              res_row_div)
 
 
+# "0": the output projection and the post-norm of the decoder's attention blocks as two launches (fod_gemm_nt +
+# fod_layernorm_fwd) instead of fod_linear_add_norm_fwd
+FUSED_LINEAR_NORM = os.environ.get("FOD_FUSED_LINEAR_NORM", "1") != "0"
+
+
 class LinearAddNormFn(Function):
     """y = LayerNorm(x + (a W^T + b)): a sub-layer's output projection, the residual add and the post-norm as ONE
     autograd node -- the same two kernels forward and four backward as LinearFn + LayerNormFn, but one Function
@@ -881,8 +886,14 @@ class LinearAddNormFn(Function):
         N = weight.shape[0]
         w = prep_linear(weight, a.dtype, False)
         assert w.shape[0] == N, "linear_add_norm: out_features must be a multiple of the vector width"
-        o = ops.gemm_nt(a, w, shift=bias).view(x.shape)
-        y, s, mean, rstd = ops.layernorm_fwd(x, gamma, beta, residual=o)
+        rows = a.numel() // a.shape[-1]
+        if (FUSED_LINEAR_NORM and a.dtype == torch.bfloat16 and N == 256 and weight.shape[1] == 256 and w.shape[1] == 256
+                and rows <= 1024):
+            # the decoder's query side: projection + residual add + norm as ONE launch (csrc/linear_norm.hip)
+            y, s, mean, rstd = ops.linear_add_norm_fwd(a, w, bias, x, gamma, beta)
+        else:
+            o = ops.gemm_nt(a, w, shift=bias).view(x.shape)
+            y, s, mean, rstd = ops.layernorm_fwd(x, gamma, beta, residual=o)
         ctx.save_for_backward(a, s, mean, rstd, gamma)
         ctx.weight, ctx.bias, ctx.has_bias, ctx.a_relu = weight, bias, bias is not None, bool(a_relu)
         return y

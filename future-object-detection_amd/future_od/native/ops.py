@@ -593,6 +593,25 @@ def layernorm_fwd(x, gamma, beta, residual=None, res_row_div=0, res_row_mod=0, w
     return y, (s if want_sum else x), mean, rstd
 
 
+def linear_add_norm_fwd(a, w, bias, x, gamma, beta, eps=1e-5):
+    """LayerNorm(x + (a w^T + bias)) in one launch (bf16, 256 x 256 projection): returns (y, sum, mean, rstd) as
+    layernorm_fwd(x, ..., residual=gemm_nt(a, w, shift=bias)) does."""
+    _chk(a, "a", torch.bfloat16); _chk(w, "w", torch.bfloat16); _chk(x, "x", torch.bfloat16)
+    _chk(gamma, "gamma", torch.float32); _chk(beta, "beta", torch.float32)
+    N, K = w.shape
+    M = a.numel() // K
+    assert a.shape[-1] == K and x.numel() == M * N and gamma.numel() == N and beta.numel() == N, (a.shape, w.shape, x.shape)
+    if bias is not None:
+        _chk(bias, "bias", torch.float32); assert bias.numel() == N
+    y = torch.empty_like(x)
+    s = torch.empty_like(x)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    call("fod_linear_add_norm_fwd", dt(a), ptr(a), K, ptr(w), ptr(bias), ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(s),
+         ptr(mean), ptr(rstd), M, N, K, eps, stream(), work=2.0 * M * N * K, tag="fod_gemm_nt")
+    return y, s, mean, rstd
+
+
 def layernorm_bwd(dy, xsum, mean, rstd, gamma, dgamma, dbeta):
     _chk(dy, "dy"); _chk(xsum, "xsum", dy.dtype)
     D = dy.shape[-1]

@@ -298,6 +298,13 @@ int fod_attn_fwd_fp8(const void* q_pack, const void* kv_pack, int parts, void* o
  * sum_out (optional) receives x + residual; mean/rstd f32 [rows] are saved for the backward.
  * Replaces the `x = norm(x + dropout(new))` pattern, transformer.py:117-118,271-272,285-286,
  * 310-311,417-418,485-486 (dropout = identity in eval). */
+/* y = LayerNorm(x + (a W^T + bias)) * gamma + beta in ONE launch for the decoder's query side (csrc/linear_norm.hip;
+ * bf16, N = K = 256, a [M, K] with row stride lda, W [N, K], x / y / sum_out [M, N]): an attention block's output
+ * projection, residual add and post-norm (reference transformer.py:117-118,271-272,285-286,310-311).  sum_out (optional)
+ * receives x + (a W^T + bias) as fod_layernorm_fwd's does; mean / rstd f32 [M] for fod_layernorm_bwd. */
+int fod_linear_add_norm_fwd(int dtype, const void* a, long lda, const void* w, const float* bias, const void* x,
+                            const float* gamma, const float* beta, void* y, void* sum_out, float* mean, float* rstd,
+                            int M, int N, int K, float eps, fod_stream_t stream);
 int fod_layernorm_fwd(int dtype, const void* x, const void* residual, int res_row_div, int res_row_mod,
                       const float* gamma, const float* beta, void* y, void* sum_out, float* mean,
                       float* rstd, int rows, int D, float eps, fod_stream_t stream);

@@ -255,6 +255,33 @@ def test_fused_stem_and_maxpool_equal_the_two_launches(shape):
     check(one, ref.cpu(), dtype, 4, f"stem + pool {shape}")
 
 
+@pytest.mark.parametrize("M", [256, 100, 16, 1, 515])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_fused_linear_add_norm_forward(M, with_bias):
+    """fod_linear_add_norm_fwd (csrc/linear_norm.hip: the decoder's output projection + residual add + post-norm in one
+    launch) against the two launches it replaces, fod_gemm_nt + fod_layernorm_fwd: the bf16-rounded sum that the backward
+    pass reads within one bf16 ulp (the two kernels add the 256 products in different orders), y within 2 ulp of its
+    range, mean / rstd to 1e-3; and against float64 torch.  Ragged row counts (the last workgroup has 16 rows)."""
+    dtype = torch.bfloat16
+    a = rnd((M, 256), dtype, 41).to(DEV)
+    w = rnd((256, 256), dtype, 42, scale=1.0 / 16).to(DEV)
+    x = rnd((M, 256), dtype, 43).to(DEV)
+    bias = (torch.randn(256) * 0.3).to(DEV) if with_bias else None
+    gamma, beta = (torch.rand(256) + 0.5).to(DEV), (torch.randn(256) * 0.2).to(DEV)
+    y, s, mean, rstd = ops.linear_add_norm_fwd(a, w, bias, x, gamma, beta)
+    o = ops.gemm_nt(a, w, shift=bias)
+    y2, s2, mean2, rstd2 = ops.layernorm_fwd(x, gamma, beta, residual=o)
+    ds = (s.float() - s2.float()).abs()
+    assert float(ds.max()) <= 2.0 ** -7 * float(s2.float().abs().max()), float(ds.max())
+    assert float((y.float() - y2.float()).abs().max()) <= 2.0 ** -6 * float(y2.float().abs().max())
+    assert torch.allclose(mean, mean2, rtol=1e-3, atol=2e-3) and torch.allclose(rstd, rstd2, rtol=2e-3)
+    pre = x.double() + (a.double() @ w.double().t() + (bias.double() if with_bias else 0))
+    ref = F.layer_norm(pre, (256,), gamma.double(), beta.double(), 1e-5)
+    check(y, ref.float().cpu(), dtype, 4, f"linear_add_norm M={M}")
+    # statistics describe the STORED sum (what fod_layernorm_bwd pairs them with)
+    assert torch.allclose(mean, s.float().mean(-1), atol=1e-4) and torch.allclose(rstd, (s.float().var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_layout_helpers(dtype):
     v = torch.randn(3, 3, 10, 13)
