@@ -116,6 +116,126 @@ __global__ __launch_bounds__(256) void linear_add_norm_kernel(const LanParams p)
   }
 }
 
+
+// ---- the backward counterpart: dsum = LayerNorm'(dy) (the gradient of x + o, which feeds the residual branch and the
+// weight-gradient queue) and da = dsum . W in ONE launch.  A workgroup owns 16 rows; every wave loads those rows of dy and
+// of the stored sum in MFMA B-operand layout (lane = row, 8 consecutive columns per k-step), so the two row reductions of
+// the layer-norm gradient stay inside a wave (lanes c, c + 16, c + 32, c + 48) and its result IS the operand of the
+// product: no trip through memory between the two.  Wave w multiplies by the 64 rows 64 w .. of W^T (32 fragments, all
+// requested up front), writes columns 64 w .. of dsum, and leaves dy * xhat and dy of those columns in LDS for the column
+// sums (dgamma, dbeta: one atomic pair per column and workgroup, as ln_bwd_kernel).
+struct LanBwdParams {
+  const __bf16* dy;
+  const __bf16* xs;
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  const __bf16* wt;        // W^T as [K][N] (the operand the input-gradient GEMM reads)
+  __bf16* dsum;
+  __bf16* da;
+  float* dgamma;
+  float* dbeta;
+  int M;
+};
+
+__global__ __launch_bounds__(256) void linear_add_norm_bwd_kernel(const LanBwdParams p) {
+  constexpr int D = 256, KS = D / 32;
+  __shared__ __attribute__((aligned(16))) float sgam[D];
+  __shared__ __attribute__((aligned(16))) float cg[16][D + 4];      // dy * xhat per (row, column); + 4: rows on different banks
+  __shared__ __attribute__((aligned(16))) float cb[16][D + 4];      // dy
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * 16;
+  const int m = min(m0 + c, p.M - 1);
+  const bool live = m0 + c < p.M;
+  sgam[tid] = p.gamma[tid];
+
+  bf16x8_t fd[KS], fx[KS], fw[4][KS];
+  const __bf16* dp = p.dy + (long)m * D + 8 * g;
+  const __bf16* xp = p.xs + (long)m * D + 8 * g;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    fd[ks] = *reinterpret_cast<const bf16x8_t*>(dp + 32 * ks);
+    fx[ks] = *reinterpret_cast<const bf16x8_t*>(xp + 32 * ks);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const __bf16* wp = p.wt + (long)(64 * wave + 16 * t + c) * D + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) fw[t][ks] = *reinterpret_cast<const bf16x8_t*>(wp + 32 * ks);
+  }
+  const float mu = p.mean[m], rs = p.rstd[m];
+  __syncthreads();                                        // gamma in LDS
+
+  // ---- layer-norm gradient of this lane's 64 (row, column) pairs
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const f32x4v g0 = *reinterpret_cast<const f32x4v*>(sgam + 32 * ks + 8 * g);
+    const f32x4v g1 = *reinterpret_cast<const f32x4v*>(sgam + 32 * ks + 8 * g + 4);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = live ? (float)fd[ks][j] : 0.f;
+      const float xh = ((float)fx[ks][j] - mu) * rs;
+      const float gy = d * (j < 4 ? g0[j] : g1[j - 4]);
+      s1 += gy;
+      s2 += gy * xh;
+    }
+  }
+  s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+  s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+  s1 *= 1.f / D;
+  s2 *= 1.f / D;
+  bf16x8_t fg[KS];                                         // dsum in operand layout
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const f32x4v g0 = *reinterpret_cast<const f32x4v*>(sgam + 32 * ks + 8 * g);
+    const f32x4v g1 = *reinterpret_cast<const f32x4v*>(sgam + 32 * ks + 8 * g + 4);
+    f32x4v t0, t1, u0, u1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = live ? (float)fd[ks][j] : 0.f;
+      const float xh = ((float)fx[ks][j] - mu) * rs;
+      const float gy = d * (j < 4 ? g0[j] : g1[j - 4]);
+      fg[ks][j] = (__bf16)(rs * (gy - s1 - xh * s2));
+      if (j < 4) { t0[j] = d * xh; u0[j] = d; } else { t1[j - 4] = d * xh; u1[j - 4] = d; }
+    }
+    if ((ks >> 1) == wave) {                               // this wave's 64 columns: store dsum, leave the column terms in LDS
+      if (live) *reinterpret_cast<bf16x8_t*>(p.dsum + (long)m * D + 32 * ks + 8 * g) = fg[ks];
+      *reinterpret_cast<f32x4v*>(&cg[c][32 * ks + 8 * g]) = t0;
+      *reinterpret_cast<f32x4v*>(&cg[c][32 * ks + 8 * g + 4]) = t1;
+      *reinterpret_cast<f32x4v*>(&cb[c][32 * ks + 8 * g]) = u0;
+      *reinterpret_cast<f32x4v*>(&cb[c][32 * ks + 8 * g + 4]) = u1;
+    }
+  }
+
+  // ---- da^T[k, m] = sum_n W^T[k, n] dsum[m, n]
+  if (p.da) {
+    f32x4v acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[t][ks], fg[ks], acc[t], 0, 0, 0);
+    if (live) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        *reinterpret_cast<bf16x4_t*>(p.da + (long)m * D + 64 * wave + 16 * t + 4 * g) =
+            bf16x4_t{(__bf16)acc[t][0], (__bf16)acc[t][1], (__bf16)acc[t][2], (__bf16)acc[t][3]};
+    }
+  }
+  __syncthreads();
+  float ag = 0.f, ab = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    ag += cg[r][tid];
+    ab += cb[r][tid];
+  }
+  atomicAdd(p.dgamma + tid, ag);
+  atomicAdd(p.dbeta + tid, ab);
+}
+
 }  // namespace
 
 extern "C" int fod_linear_add_norm_fwd(int dtype, const void* a, long lda, const void* w, const float* bias, const void* x,
@@ -132,6 +252,25 @@ extern "C" int fod_linear_add_norm_fwd(int dtype, const void* a, long lda, const
   p.a = (const __bf16*)a; p.w = (const __bf16*)w; p.bias = bias; p.x = (const __bf16*)x; p.gamma = gamma; p.beta = beta;
   p.y = (__bf16*)y; p.sum_out = (__bf16*)sum_out; p.mean = mean; p.rstd = rstd; p.lda = lda; p.M = M; p.eps = eps;
   hipLaunchKernelGGL(linear_add_norm_kernel, dim3(ceil_div(M, 16)), dim3(256), 0, stream, p);
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
+}
+
+extern "C" int fod_linear_add_norm_bwd(int dtype, const void* dy, const void* xsum, const float* mean, const float* rstd,
+                                       const float* gamma, const void* w_t, void* dsum, void* da, float* dgamma,
+                                       float* dbeta, int M, int N, int K, hipStream_t stream) {
+  FOD_REQUIRE(dtype == FOD_BF16, "linear_add_norm_bwd: bf16 only (dtype %d)", dtype);
+  FOD_REQUIRE(dy && xsum && mean && rstd && gamma && dsum && dgamma && dbeta && M > 0, "linear_add_norm_bwd: bad args");
+  FOD_REQUIRE((da == nullptr) || w_t, "linear_add_norm_bwd: da needs w_t");
+  FOD_REQUIRE(N == 256 && K == 256, "linear_add_norm_bwd: built for 256 x 256 projections (N %d, K %d)", N, K);
+  auto al = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
+  FOD_REQUIRE(al(dy) && al(xsum) && al(gamma) && al(dsum) && (!da || (al(da) && al(w_t))),
+              "linear_add_norm_bwd: operands must be 16-byte aligned");
+  LanBwdParams p{};
+  p.dy = (const __bf16*)dy; p.xs = (const __bf16*)xsum; p.mean = mean; p.rstd = rstd; p.gamma = gamma;
+  p.wt = (const __bf16*)(w_t ? w_t : dy); p.dsum = (__bf16*)dsum; p.da = (__bf16*)da; p.dgamma = dgamma; p.dbeta = dbeta;
+  p.M = M;
+  hipLaunchKernelGGL(linear_add_norm_bwd_kernel, dim3(ceil_div(M, 16)), dim3(256), 0, stream, p);
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }

@@ -905,12 +905,22 @@ class LinearAddNormFn(Function):
         N, K = weight.shape
         dev = dy.device
         dg, dbeta = zeros_f32((N,), dev), zeros_f32((N,), dev)
-        dsum = ops.layernorm_bwd(dy.contiguous(), s, mean, rstd, gamma, dg, dbeta)     # d(x + o): feeds both branches
-        g = dsum.view(-1, N)
         da = None
-        if ctx.needs_input_grad[0]:
-            da = ops.gemm_nt(g, prep_linear(weight, a.dtype, True),
-                             relu_mask=a.view(-1, K) if ctx.a_relu else None).view(a.shape)
+        rows = dy.numel() // N
+        if (FUSED_LINEAR_NORM and dy.dtype == torch.bfloat16 and N == 256 and K == 256 and rows <= 1024
+                and ctx.needs_input_grad[0] and not ctx.a_relu):
+            # the decoder's query side: layer-norm gradient and the projection's input gradient as ONE launch
+            wt = prep_linear(weight, a.dtype, True)
+            assert tuple(wt.shape) == (K, N)
+            dsum, da = ops.linear_add_norm_bwd(dy.contiguous(), s, mean, rstd, gamma, wt, dg, dbeta)
+            dsum, da = dsum.view(dy.shape), da.view(a.shape)
+            g = dsum.view(-1, N)
+        else:
+            dsum = ops.layernorm_bwd(dy.contiguous(), s, mean, rstd, gamma, dg, dbeta)     # d(x + o): feeds both branches
+            g = dsum.view(-1, N)
+            if ctx.needs_input_grad[0]:
+                da = ops.gemm_nt(g, prep_linear(weight, a.dtype, True),
+                                 relu_mask=a.view(-1, K) if ctx.a_relu else None).view(a.shape)
         dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[3]
         if want_db:

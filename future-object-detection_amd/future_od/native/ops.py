@@ -612,6 +612,21 @@ def linear_add_norm_fwd(a, w, bias, x, gamma, beta, eps=1e-5):
     return y, s, mean, rstd
 
 
+def linear_add_norm_bwd(dy, xsum, mean, rstd, gamma, w_t, dgamma, dbeta, want_da=True):
+    """Backward of linear_add_norm_fwd in one launch: (dsum, da) with dsum = layernorm_bwd(dy, ...) and da = dsum . W
+    (w_t = W^T as [K, N], the operand gemm_nt would take); dgamma / dbeta (f32, accumulated)."""
+    _chk(dy, "dy", torch.bfloat16); _chk(xsum, "xsum", torch.bfloat16); _chk(w_t, "w_t", torch.bfloat16)
+    K, N = w_t.shape
+    M = dy.numel() // N
+    assert xsum.numel() == dy.numel() and mean.numel() == M and rstd.numel() == M and gamma.numel() == N
+    _chk(dgamma, "dgamma", torch.float32); _chk(dbeta, "dbeta", torch.float32)
+    dsum = torch.empty_like(dy)
+    da = torch.empty((M, K), dtype=dy.dtype, device=dy.device) if want_da else None
+    call("fod_linear_add_norm_bwd", dt(dy), ptr(dy), ptr(xsum), ptr(mean), ptr(rstd), ptr(gamma), ptr(w_t), ptr(dsum),
+         ptr(da), ptr(dgamma), ptr(dbeta), M, N, K, stream(), work=2.0 * M * N * K if want_da else 0.0, tag="fod_gemm_nt")
+    return dsum, da
+
+
 def layernorm_bwd(dy, xsum, mean, rstd, gamma, dgamma, dbeta):
     _chk(dy, "dy"); _chk(xsum, "xsum", dy.dtype)
     D = dy.shape[-1]

@@ -305,6 +305,11 @@ int fod_attn_fwd_fp8(const void* q_pack, const void* kv_pack, int parts, void* o
 int fod_linear_add_norm_fwd(int dtype, const void* a, long lda, const void* w, const float* bias, const void* x,
                             const float* gamma, const float* beta, void* y, void* sum_out, float* mean, float* rstd,
                             int M, int N, int K, float eps, fod_stream_t stream);
+/* Its backward counterpart in one launch: dsum = fod_layernorm_bwd(dy, xsum, mean, rstd, gamma) (the gradient of
+ * x + o; dgamma / dbeta accumulated), and -- when da is not NULL -- da [M, K] = dsum . W, with w_t = W^T as [K][N]. */
+int fod_linear_add_norm_bwd(int dtype, const void* dy, const void* xsum, const float* mean, const float* rstd,
+                            const float* gamma, const void* w_t, void* dsum, void* da, float* dgamma, float* dbeta,
+                            int M, int N, int K, fod_stream_t stream);
 int fod_layernorm_fwd(int dtype, const void* x, const void* residual, int res_row_div, int res_row_mod,
                       const float* gamma, const float* beta, void* y, void* sum_out, float* mean,
                       float* rstd, int rows, int D, float eps, fod_stream_t stream);

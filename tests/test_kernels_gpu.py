@@ -282,6 +282,51 @@ def test_fused_linear_add_norm_forward(M, with_bias):
     assert torch.allclose(mean, s.float().mean(-1), atol=1e-4) and torch.allclose(rstd, (s.float().var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4)
 
 
+@pytest.mark.parametrize("M", [256, 100, 16, 1, 515])
+def test_fused_linear_add_norm_backward(M):
+    """fod_linear_add_norm_bwd (layer-norm gradient + the projection's input gradient in one launch) against
+    fod_layernorm_bwd followed by fod_gemm_nt: dsum and da within one bf16 ulp (the same formulas; the row sums and the
+    256 products are added in a different order), dgamma / dbeta within f32 accumulation noise; and the whole
+    autograd node against float64 torch."""
+    from future_od.native import functional as Fn
+    dtype = torch.bfloat16
+    dy = rnd((M, 256), dtype, 51).to(DEV)
+    s = rnd((M, 256), dtype, 52).to(DEV)
+    gamma = (torch.rand(256) + 0.5).to(DEV)
+    mean = s.float().mean(-1).contiguous()
+    rstd = (s.float().var(-1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    wt = rnd((256, 256), dtype, 53, scale=1.0 / 16).to(DEV)                 # W^T as [K, N]
+    dg1, db1 = torch.zeros(256, device=DEV), torch.zeros(256, device=DEV)
+    dg2, db2 = torch.zeros(256, device=DEV), torch.zeros(256, device=DEV)
+    dsum, da = ops.linear_add_norm_bwd(dy, s, mean, rstd, gamma, wt, dg1, db1)
+    dsum2 = ops.layernorm_bwd(dy, s, mean, rstd, gamma, dg2, db2)
+    da2 = ops.gemm_nt(dsum2.view(-1, 256), wt)
+    dd = (dsum.float() - dsum2.float().view_as(dsum)).abs()           # (the row sums are added in a different order)
+    assert float(dd.max()) <= 2.0 ** -7 * float(dsum2.float().abs().max()) and float((dd > 0).float().mean()) < 0.05, float(dd.max())
+    assert float((da.float() - da2.float()).abs().max()) <= 2.0 ** -7 * max(float(da2.float().abs().max()), 1e-3)
+    assert torch.allclose(dg1, dg2, rtol=1e-4, atol=1e-3) and torch.allclose(db1, db2, rtol=1e-4, atol=1e-3)
+    # through autograd: fused node vs float64
+    a = rnd((M, 256), dtype, 54).to(DEV).requires_grad_(True)
+    x = rnd((M, 256), dtype, 55).to(DEV).requires_grad_(True)
+    lin = torch.nn.Linear(256, 256).to(DEV)
+    ln = torch.nn.LayerNorm(256).to(DEV)
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.normal_(0, 0.2)
+    Fn.PREP.clear()
+    y = Fn.linear_add_norm(a, x, lin.weight, lin.bias, ln.weight, ln.bias)
+    gy = rnd((M, 256), dtype, 56).to(DEV)
+    y.backward(gy)
+    a64, x64 = a.detach().double().requires_grad_(True), x.detach().double().requires_grad_(True)
+    w64, b64 = lin.weight.detach().double().requires_grad_(True), lin.bias.detach().double().requires_grad_(True)
+    g64, be64 = ln.weight.detach().double().requires_grad_(True), ln.bias.detach().double().requires_grad_(True)
+    y64 = F.layer_norm(x64 + a64 @ w64.t() + b64, (256,), g64, be64, 1e-5)
+    y64.backward(gy.double())
+    for name, got, ref in (("y", y, y64), ("da", a.grad, a64.grad), ("dx", x.grad, x64.grad), ("dW", lin.weight.grad, w64.grad),
+                           ("db", lin.bias.grad, b64.grad), ("dgamma", ln.weight.grad, g64.grad), ("dbeta", ln.bias.grad, be64.grad)):
+        err = float((got.double() - ref.detach()).norm() / ref.detach().norm().clamp_min(1e-9))
+        assert err <= 2e-2, (name, err)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_layout_helpers(dtype):
     v = torch.randn(3, 3, 10, 13)
