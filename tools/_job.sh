@@ -1,9 +1,15 @@
 set -e
-mkdir -p gpurun_out/r03z
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r03z_gpu_tests.txt 2>&1 || { tail -40 gpurun_out/r03z_gpu_tests.txt; exit 1; }
-tail -2 gpurun_out/r03z_gpu_tests.txt
-bash tools/profile_round.sh r03z > gpurun_out/r03z_profile.log 2>&1 || { tail -30 gpurun_out/r03z_profile.log; exit 1; }
-tail -3 gpurun_out/r03z_profile.log
-bash tools/trace_graph.sh r03z_trace > gpurun_out/r03z/trace.log 2>&1 || { tail -30 gpurun_out/r03z/trace.log; exit 1; }
-python tools/trace_summary_graph.py gpurun_out/r03z_trace/kernel_trace.csv > gpurun_out/r03z/graph_replay_kernel_summary.txt
-tail -24 gpurun_out/r03z/graph_replay_kernel_summary.txt
+o=gpurun_out/r03zb
+mkdir -p $o
+python bench.py --workload t8 --attn-dtype fp8 --no-cpu-baseline --no-extras --no-roofline > $o/bench_t8_fp8.json 2> $o/bench_t8_fp8.err
+for w in cfg2 nusc500-stage1 nusc500-stage2; do
+  python bench.py --workload $w --no-cpu-baseline --no-extras --no-roofline > $o/bench_$w.json 2> $o/bench_$w.err
+done
+python bench.py --train-mode --no-cpu-baseline --no-extras --no-roofline > $o/bench_trainmode_headline.json 2> $o/bench_trainmode_headline.err
+python bench.py --force-ddp --no-cpu-baseline --no-extras --no-roofline > $o/bench_force_ddp.json 2> $o/bench_force_ddp.err
+for f in $o/bench_*.json; do python - "$f" <<'PY'
+import json,sys
+d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print(sys.argv[1].split('/')[-1], round(d['value'],2), round(d['ms_per_step'],3), (d.get('vs_bf16_attention') or {}).get('throughput_ratio_fp8_over_bf16'))
+PY
+done
