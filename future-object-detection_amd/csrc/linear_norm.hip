@@ -1,5 +1,6 @@
-// y = LayerNorm(x + (a W^T + b)) * gamma + beta for the decoder's query side (a few hundred rows, D = 256, K = 256): the
-// output projection of an attention sub-layer, its residual add and the post-norm in ONE launch.  Reference:
+// y = LayerNorm(x + (a W^T + b)) * gamma + beta for 256-wide projections (D = 256, K = 256; the decoder's query side with a
+// few hundred rows, and the encoder's 14 500): the output projection of an attention sub-layer, its residual add and the
+// post-norm in ONE launch.  Reference:
 // `x = norm(x + dropout(new))` after every attention block, future_od/models/transformer.py:117-118,271-272,285-286,310-311
 // (dropout = identity in eval mode; the caller keeps the two-kernel path when it is active).
 //
@@ -36,86 +37,93 @@ __global__ __launch_bounds__(256) void linear_add_norm_kernel(const LanParams p)
   constexpr int D = 256, K = 256, KS = K / 32;
   __shared__ float red[2][4][16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = lane & 15, g = lane >> 4;               // MFMA column (= row m of the block) and lane group
-  const int m0 = blockIdx.x * 16;
-  const int m = min(m0 + c, p.M - 1);                    // rows past M shadow the last row; nothing of theirs is stored
-  const bool live = m0 + c < p.M;
+  const int c = lane & 15, g = lane >> 4;               // MFMA column (= row m of the tile) and lane group
 
-  // ---- every operand up front
-  bf16x8_t fa[KS], fw[4][KS];
-  const __bf16* ap = p.a + (long)m * p.lda + 8 * g;
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) fa[ks] = *reinterpret_cast<const bf16x8_t*>(ap + 32 * ks);
+  // ---- stationary for the whole launch: this wave's 64 rows of W (32 fragments), gamma, beta, bias of its columns
+  bf16x8_t fw[4][KS];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const __bf16* wp = p.w + (long)(64 * wave + 16 * t + c) * K + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) fw[t][ks] = *reinterpret_cast<const bf16x8_t*>(wp + 32 * ks);
   }
-  bf16x4_t xr[4];
   f32x4v ga[4], be[4], bi[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int n = 64 * wave + 16 * t + 4 * g;            // this lane's 4 consecutive columns of tile t
-    xr[t] = *reinterpret_cast<const bf16x4_t*>(p.x + (long)m * D + n);
     ga[t] = *reinterpret_cast<const f32x4v*>(p.gamma + n);
     be[t] = *reinterpret_cast<const f32x4v*>(p.beta + n);
     bi[t] = p.bias ? *reinterpret_cast<const f32x4v*>(p.bias + n) : f32x4v{0.f, 0.f, 0.f, 0.f};
   }
 
-  f32x4v acc[4];
+  // ---- 16-row tiles, grid-strided (a few hundred rows: one tile per workgroup; the encoder's 14 500 rows: ~2 per
+  // workgroup with two workgroups per CU, the weights never re-read)
+  const int ntiles = (p.M + 15) / 16;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * 16;
+    const int m = min(m0 + c, p.M - 1);                  // rows past M shadow the last row; nothing of theirs is stored
+    const bool live = m0 + c < p.M;
+    bf16x8_t fa[KS];
+    const __bf16* ap = p.a + (long)m * p.lda + 8 * g;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < KS; ++ks) fa[ks] = *reinterpret_cast<const bf16x8_t*>(ap + 32 * ks);
+    bf16x4_t xr[4];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[t][ks], fa[ks], acc[t], 0, 0, 0);
+    for (int t = 0; t < 4; ++t) xr[t] = *reinterpret_cast<const bf16x4_t*>(p.x + (long)m * D + 64 * wave + 16 * t + 4 * g);
 
-  // ---- s = bf16(x + bf16(a W^T + b)) (the roundings of the two-launch path), statistics on the stored value
-  float v[4][4];
-  bf16x4_t sb[4];
-  float part = 0.f;
+    f32x4v acc[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const __bf16 o = (__bf16)(acc[t][r] + bi[t][r]);
-      sb[t][r] = (__bf16)((float)xr[t][r] + (float)o);
-      v[t][r] = (float)sb[t][r];
-      part += v[t][r];
-    }
-  part += __shfl_xor(part, 16);
-  part += __shfl_xor(part, 32);
-  if (g == 0) red[0][wave][c] = part;
-  __syncthreads();
-  const float mu = (red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]) * (1.f / D);
-  float q = 0.f;
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[t][ks], fa[ks], acc[t], 0, 0, 0);
+
+    // ---- s = bf16(x + bf16(a W^T + b)) (the roundings of the two-launch path), statistics on the stored value
+    float v[4][4];
+    bf16x4_t sb[4];
+    float part = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) q += (v[t][r] - mu) * (v[t][r] - mu);
-  q += __shfl_xor(q, 16);
-  q += __shfl_xor(q, 32);
-  if (g == 0) red[1][wave][c] = q;
-  __syncthreads();
-  const float rs = rsqrtf((red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]) * (1.f / D) + p.eps);
-  if (live) {
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int n = 64 * wave + 16 * t + 4 * g;
-      bf16x4_t o;
+      for (int r = 0; r < 4; ++r) {
+        const __bf16 o = (__bf16)(acc[t][r] + bi[t][r]);
+        sb[t][r] = (__bf16)((float)xr[t][r] + (float)o);
+        v[t][r] = (float)sb[t][r];
+        part += v[t][r];
+      }
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    if (g == 0) red[0][wave][c] = part;
+    __syncthreads();
+    const float mu = (red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]) * (1.f / D);
+    float q = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] = (__bf16)((v[t][r] - mu) * rs * ga[t][r] + be[t][r]);
-      *reinterpret_cast<bf16x4_t*>(p.y + (long)m * D + n) = o;
-      if (p.sum_out) *reinterpret_cast<bf16x4_t*>(p.sum_out + (long)m * D + n) = sb[t];
-    }
-    if (wave == 0 && g == 0) {
-      p.mean[m] = mu;
-      p.rstd[m] = rs;
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q += (v[t][r] - mu) * (v[t][r] - mu);
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    if (g == 0) red[1][wave][c] = q;
+    __syncthreads();
+    const float rs = rsqrtf((red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]) * (1.f / D) + p.eps);
+    if (live) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int n = 64 * wave + 16 * t + 4 * g;
+        bf16x4_t o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (__bf16)((v[t][r] - mu) * rs * ga[t][r] + be[t][r]);
+        *reinterpret_cast<bf16x4_t*>(p.y + (long)m * D + n) = o;
+        if (p.sum_out) *reinterpret_cast<bf16x4_t*>(p.sum_out + (long)m * D + n) = sb[t];
+      }
+      if (wave == 0 && g == 0) {
+        p.mean[m] = mu;
+        p.rstd[m] = rs;
+      }
     }
   }
 }
-
 
 // ---- the backward counterpart: dsum = LayerNorm'(dy) (the gradient of x + o, which feeds the residual branch and the
 // weight-gradient queue) and da = dsum . W in ONE launch.  A workgroup owns 16 rows; every wave loads those rows of dy and
@@ -145,95 +153,111 @@ __global__ __launch_bounds__(256) void linear_add_norm_bwd_kernel(const LanBwdPa
   __shared__ __attribute__((aligned(16))) float cb[16][D + 4];      // dy
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * 16;
-  const int m = min(m0 + c, p.M - 1);
-  const bool live = m0 + c < p.M;
   sgam[tid] = p.gamma[tid];
 
-  bf16x8_t fd[KS], fx[KS], fw[4][KS];
-  const __bf16* dp = p.dy + (long)m * D + 8 * g;
-  const __bf16* xp = p.xs + (long)m * D + 8 * g;
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    fd[ks] = *reinterpret_cast<const bf16x8_t*>(dp + 32 * ks);
-    fx[ks] = *reinterpret_cast<const bf16x8_t*>(xp + 32 * ks);
-  }
+  // ---- stationary: this wave's 64 rows of W^T (32 fragments)
+  bf16x8_t fw[4][KS];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const __bf16* wp = p.wt + (long)(64 * wave + 16 * t + c) * D + 8 * g;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) fw[t][ks] = *reinterpret_cast<const bf16x8_t*>(wp + 32 * ks);
   }
-  const float mu = p.mean[m], rs = p.rstd[m];
+  float ag = 0.f, ab = 0.f;                               // this thread's column (tid) of dgamma / dbeta, over the workgroup's tiles
   __syncthreads();                                        // gamma in LDS
 
-  // ---- layer-norm gradient of this lane's 64 (row, column) pairs
-  float s1 = 0.f, s2 = 0.f;
+  const int ntiles = (p.M + 15) / 16;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * 16;
+    const int m = min(m0 + c, p.M - 1);
+    const bool live = m0 + c < p.M;
+    bf16x8_t fd[KS], fx[KS];
+    const __bf16* dp = p.dy + (long)m * D + 8 * g;
+    const __bf16* xp = p.xs + (long)m * D + 8 * g;
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const f32x4v g0 = *reinterpret_cast<const f32x4v*>(sgam + 32 * ks + 8 * g);
-    const f32x4v g1 = *reinterpret_cast<const f32x4v*>(sgam + 32 * ks + 8 * g + 4);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float d = live ? (float)fd[ks][j] : 0.f;
-      const float xh = ((float)fx[ks][j] - mu) * rs;
-      const float gy = d * (j < 4 ? g0[j] : g1[j - 4]);
-      s1 += gy;
-      s2 += gy * xh;
+    for (int ks = 0; ks < KS; ++ks) {
+      fd[ks] = *reinterpret_cast<const bf16x8_t*>(dp + 32 * ks);
+      fx[ks] = *reinterpret_cast<const bf16x8_t*>(xp + 32 * ks);
     }
-  }
-  s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
-  s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
-  s1 *= 1.f / D;
-  s2 *= 1.f / D;
-  bf16x8_t fg[KS];                                         // dsum in operand layout
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const f32x4v g0 = *reinterpret_cast<const f32x4v*>(sgam + 32 * ks + 8 * g);
-    const f32x4v g1 = *reinterpret_cast<const f32x4v*>(sgam + 32 * ks + 8 * g + 4);
-    f32x4v t0, t1, u0, u1;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float d = live ? (float)fd[ks][j] : 0.f;
-      const float xh = ((float)fx[ks][j] - mu) * rs;
-      const float gy = d * (j < 4 ? g0[j] : g1[j - 4]);
-      fg[ks][j] = (__bf16)(rs * (gy - s1 - xh * s2));
-      if (j < 4) { t0[j] = d * xh; u0[j] = d; } else { t1[j - 4] = d * xh; u1[j - 4] = d; }
-    }
-    if ((ks >> 1) == wave) {                               // this wave's 64 columns: store dsum, leave the column terms in LDS
-      if (live) *reinterpret_cast<bf16x8_t*>(p.dsum + (long)m * D + 32 * ks + 8 * g) = fg[ks];
-      *reinterpret_cast<f32x4v*>(&cg[c][32 * ks + 8 * g]) = t0;
-      *reinterpret_cast<f32x4v*>(&cg[c][32 * ks + 8 * g + 4]) = t1;
-      *reinterpret_cast<f32x4v*>(&cb[c][32 * ks + 8 * g]) = u0;
-      *reinterpret_cast<f32x4v*>(&cb[c][32 * ks + 8 * g + 4]) = u1;
-    }
-  }
+    const float mu = p.mean[m], rs = p.rstd[m];
 
-  // ---- da^T[k, m] = sum_n W^T[k, n] dsum[m, n]
-  if (p.da) {
-    f32x4v acc[4];
+    // ---- layer-norm gradient of this lane's 64 (row, column) pairs
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < KS; ++ks) {
+      const f32x4v g0 = *reinterpret_cast<const f32x4v*>(sgam + 32 * ks + 8 * g);
+      const f32x4v g1 = *reinterpret_cast<const f32x4v*>(sgam + 32 * ks + 8 * g + 4);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[t][ks], fg[ks], acc[t], 0, 0, 0);
-    if (live) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        *reinterpret_cast<bf16x4_t*>(p.da + (long)m * D + 64 * wave + 16 * t + 4 * g) =
-            bf16x4_t{(__bf16)acc[t][0], (__bf16)acc[t][1], (__bf16)acc[t][2], (__bf16)acc[t][3]};
+      for (int j = 0; j < 8; ++j) {
+        const float d = live ? (float)fd[ks][j] : 0.f;
+        const float xh = ((float)fx[ks][j] - mu) * rs;
+        const float gy = d * (j < 4 ? g0[j] : g1[j - 4]);
+        s1 += gy;
+        s2 += gy * xh;
+      }
     }
-  }
-  __syncthreads();
-  float ag = 0.f, ab = 0.f;
+    s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+    s1 *= 1.f / D;
+    s2 *= 1.f / D;
+    bf16x8_t fg[KS];                                       // dsum in operand layout
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    ag += cg[r][tid];
-    ab += cb[r][tid];
+    for (int ks = 0; ks < KS; ++ks) {
+      const f32x4v g0 = *reinterpret_cast<const f32x4v*>(sgam + 32 * ks + 8 * g);
+      const f32x4v g1 = *reinterpret_cast<const f32x4v*>(sgam + 32 * ks + 8 * g + 4);
+      f32x4v t0, t1, u0, u1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = live ? (float)fd[ks][j] : 0.f;
+        const float xh = ((float)fx[ks][j] - mu) * rs;
+        const float gy = d * (j < 4 ? g0[j] : g1[j - 4]);
+        fg[ks][j] = (__bf16)(rs * (gy - s1 - xh * s2));
+        if (j < 4) { t0[j] = d * xh; u0[j] = d; } else { t1[j - 4] = d * xh; u1[j - 4] = d; }
+      }
+      if ((ks >> 1) == wave) {                             // this wave's 64 columns: store dsum, leave the column terms in LDS
+        if (live) *reinterpret_cast<bf16x8_t*>(p.dsum + (long)m * D + 32 * ks + 8 * g) = fg[ks];
+        *reinterpret_cast<f32x4v*>(&cg[c][32 * ks + 8 * g]) = t0;
+        *reinterpret_cast<f32x4v*>(&cg[c][32 * ks + 8 * g + 4]) = t1;
+        *reinterpret_cast<f32x4v*>(&cb[c][32 * ks + 8 * g]) = u0;
+        *reinterpret_cast<f32x4v*>(&cb[c][32 * ks + 8 * g + 4]) = u1;
+      }
+    }
+
+    // ---- da^T[k, m] = sum_n W^T[k, n] dsum[m, n]
+    if (p.da) {
+      f32x4v acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[t][ks], fg[ks], acc[t], 0, 0, 0);
+      if (live) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          *reinterpret_cast<bf16x4_t*>(p.da + (long)m * D + 64 * wave + 16 * t + 4 * g) =
+              bf16x4_t{(__bf16)acc[t][0], (__bf16)acc[t][1], (__bf16)acc[t][2], (__bf16)acc[t][3]};
+      }
+    }
+    __syncthreads();                                       // the tile's column terms are in LDS
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      ag += cg[r][tid];
+      ab += cb[r][tid];
+    }
+    __syncthreads();                                       // ... and read, before the next tile overwrites them
   }
   atomicAdd(p.dgamma + tid, ag);
   atomicAdd(p.dbeta + tid, ab);
+}
+
+// one workgroup per 16-row tile up to one per CU (the kernels hold ~260-320 registers: one wave per SIMD); beyond that the workgroups walk the tiles (weights stay in
+// their registers)
+int lan_grid(int M) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  const int tiles = ceil_div(M, 16);
+  return tiles < cus ? tiles : cus;
 }
 
 }  // namespace
@@ -251,7 +275,7 @@ extern "C" int fod_linear_add_norm_fwd(int dtype, const void* a, long lda, const
   LanParams p{};
   p.a = (const __bf16*)a; p.w = (const __bf16*)w; p.bias = bias; p.x = (const __bf16*)x; p.gamma = gamma; p.beta = beta;
   p.y = (__bf16*)y; p.sum_out = (__bf16*)sum_out; p.mean = mean; p.rstd = rstd; p.lda = lda; p.M = M; p.eps = eps;
-  hipLaunchKernelGGL(linear_add_norm_kernel, dim3(ceil_div(M, 16)), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(linear_add_norm_kernel, dim3(lan_grid(M)), dim3(256), 0, stream, p);
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }
@@ -270,7 +294,7 @@ extern "C" int fod_linear_add_norm_bwd(int dtype, const void* dy, const void* xs
   p.dy = (const __bf16*)dy; p.xs = (const __bf16*)xsum; p.mean = mean; p.rstd = rstd; p.gamma = gamma;
   p.wt = (const __bf16*)(w_t ? w_t : dy); p.dsum = (__bf16*)dsum; p.da = (__bf16*)da; p.dgamma = dgamma; p.dbeta = dbeta;
   p.M = M;
-  hipLaunchKernelGGL(linear_add_norm_bwd_kernel, dim3(ceil_div(M, 16)), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(linear_add_norm_bwd_kernel, dim3(lan_grid(M)), dim3(256), 0, stream, p);
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }

@@ -870,6 +870,11 @@ def layer_norm(x, gamma, beta, residual=None, res_row_div=0):
 # "0": the output projection and the post-norm of the decoder's attention blocks as two launches (fod_gemm_nt +
 # fod_layernorm_fwd) instead of fod_linear_add_norm_fwd
 FUSED_LINEAR_NORM = os.environ.get("FOD_FUSED_LINEAR_NORM", "1") != "0"
+# rows up to which the fused launches are used.  The kernels walk 16-row tiles with the weights stationary, so they take any
+# row count, but at the encoder's 14 500 rows they do not pay (one wave per SIMD, every tile's loads queue behind the
+# previous tile's stores): forward 19.5 us against 21.3 for GEMM + norm, backward 26.3 against 20.9, whole step +0.1 ms
+# (profiles/r03l_fused_linear_norm.txt)
+FUSED_LINEAR_NORM_ROWS = int(os.environ.get("FOD_FUSED_LINEAR_NORM_ROWS", "1024"))
 
 
 class LinearAddNormFn(Function):
@@ -888,7 +893,7 @@ class LinearAddNormFn(Function):
         assert w.shape[0] == N, "linear_add_norm: out_features must be a multiple of the vector width"
         rows = a.numel() // a.shape[-1]
         if (FUSED_LINEAR_NORM and a.dtype == torch.bfloat16 and N == 256 and weight.shape[1] == 256 and w.shape[1] == 256
-                and rows <= 1024):
+                and rows <= FUSED_LINEAR_NORM_ROWS):
             # the decoder's query side: projection + residual add + norm as ONE launch (csrc/linear_norm.hip)
             y, s, mean, rstd = ops.linear_add_norm_fwd(a, w, bias, x, gamma, beta)
         else:
@@ -907,7 +912,7 @@ class LinearAddNormFn(Function):
         dg, dbeta = zeros_f32((N,), dev), zeros_f32((N,), dev)
         da = None
         rows = dy.numel() // N
-        if (FUSED_LINEAR_NORM and dy.dtype == torch.bfloat16 and N == 256 and K == 256 and rows <= 1024
+        if (FUSED_LINEAR_NORM and dy.dtype == torch.bfloat16 and N == 256 and K == 256 and rows <= FUSED_LINEAR_NORM_ROWS
                 and ctx.needs_input_grad[0] and not ctx.a_relu):
             # the decoder's query side: layer-norm gradient and the projection's input gradient as ONE launch
             wt = prep_linear(weight, a.dtype, True)

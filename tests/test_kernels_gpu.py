@@ -255,7 +255,7 @@ def test_fused_stem_and_maxpool_equal_the_two_launches(shape):
     check(one, ref.cpu(), dtype, 4, f"stem + pool {shape}")
 
 
-@pytest.mark.parametrize("M", [256, 100, 16, 1, 515])
+@pytest.mark.parametrize("M", [256, 100, 16, 1, 515, 14500])
 @pytest.mark.parametrize("with_bias", [True, False])
 def test_fused_linear_add_norm_forward(M, with_bias):
     """fod_linear_add_norm_fwd (csrc/linear_norm.hip: the decoder's output projection + residual add + post-norm in one
@@ -282,7 +282,7 @@ def test_fused_linear_add_norm_forward(M, with_bias):
     assert torch.allclose(mean, s.float().mean(-1), atol=1e-4) and torch.allclose(rstd, (s.float().var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4)
 
 
-@pytest.mark.parametrize("M", [256, 100, 16, 1, 515])
+@pytest.mark.parametrize("M", [256, 100, 16, 1, 515, 14500])
 def test_fused_linear_add_norm_backward(M):
     """fod_linear_add_norm_bwd (layer-norm gradient + the projection's input gradient in one launch) against
     fod_layernorm_bwd followed by fod_gemm_nt: dsum and da within one bf16 ulp (the same formulas; the row sums and the
