@@ -425,11 +425,14 @@ __global__ __launch_bounds__(256, 1) void bottleneck_fused4_kernel(const BnkPara
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
-    // This tile's first min(3, NCH) chunks were issued a whole tile ago; every tile issues the SAME number of younger
-    // operations after them (rows past the image repeat the last row's loads and stores), so a counted wait need not
-    // drain the previous tile's stores.  Projection: at least DMA(T+2) 8 + stores(T-1) 24 + DMA(T+1) 8 = 40 are younger
-    // than DMA(T); identity: stage 3's 6 x (4 loads + 4 stores) = 48 are younger than the fourth chunk (issued at its start).
-    if (PROJ) FOD_VMCNT(40); else FOD_VMCNT(48);
+    // This tile's chunks were issued a whole tile ago; every tile issues a fixed MINIMUM of younger operations after them
+    // (rows past the image repeat the last row's stores), so a counted wait need not drain the previous tile's stores.
+    // The counts are lower bounds on what the compiler must emit -- stores, which it cannot drop; the shortcut loads of
+    // the last row pair ARE dropped as dead (seen in the ISA), so loads are not counted:
+    //   projection: DMA(T+2) 8 + stores(T-1) 24 + DMA(T+1) 8 = 40 are younger than DMA(T) (and stores(T-2) too);
+    //   identity: the fourth chunk's DMA goes out at the start of stage 3, whose 24 stores follow it: waiting for all but
+    //   the youngest 16 operations leaves a margin of one row pair.
+    if (PROJ) FOD_VMCNT(40); else FOD_VMCNT(16);
     __syncthreads();
     BNK_MARK(0);
 #pragma unroll
