@@ -327,6 +327,28 @@ def test_fused_linear_add_norm_backward(M):
         assert err <= 2e-2, (name, err)
 
 
+def test_frozen_front_in_frame_chunks_equals_the_whole_clip(monkeypatch):
+    """FOD_FRONT_FRAMES (the frozen front -- fused stem + max-pool, fused layer1 blocks -- a few frames at a time, the last
+    block writing into its slice of the full tensor): the same features as all frames at once, bit for bit, and the same
+    with the fused launches switched off (bf16 tolerance: the separate launches round the projection shortcut once more)."""
+    from future_od.native import backbone as BB
+    from future_od.models.paper import CDetrBackbone
+    torch.manual_seed(8)
+    bb = CDetrBackbone("resnet50", True, False, 64, pretrained=False).to(DEV)
+    clip = torch.randn(2, 3, 3, 70, 100, device=DEV)
+    with torch.no_grad():
+        ref = bb.forward_clip(clip, torch.bfloat16)
+        monkeypatch.setattr(BB, "FRONT_FRAMES", 2)
+        chunked = bb.forward_clip(clip, torch.bfloat16)
+        monkeypatch.setattr(BB, "FRONT_FRAMES", 1 << 30)
+        monkeypatch.setattr(BB, "FUSED_BOTTLENECK", "0")
+        monkeypatch.setattr(BB, "FUSED_STEM_POOL", False)
+        plain = bb.forward_clip(clip, torch.bfloat16)
+    assert torch.equal(ref, chunked)
+    span = float(plain.float().abs().max())
+    assert float((ref.float() - plain.float()).abs().max()) <= 3e-2 * span
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_layout_helpers(dtype):
     v = torch.randn(3, 3, 10, 13)
