@@ -17,6 +17,7 @@ Dropout: the reference applies dropout(0.1) in training mode.  These modules imp
 eval-mode graph (dropout = identity) in both modes for now -- see DESIGN.md "Gaps".
 """
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -138,6 +139,15 @@ class SlotToSlotAttention(Attention):
         return _Proj(a, self.fun.out_proj)
 
 
+# TRAIN mode with active dropout and ONE IMU token per frame: the reference (transformer.py:108-119, 444, 485) draws its
+# dropout masks per TOKEN -- on the attention probability (a dropped weight zeroes that token's whole IMU contribution),
+# on the block's output and inside its MLP.  The collapsed one-key form below computes one row per frame, so its masks
+# would be per frame; by default train mode therefore runs the general form (keys = the one token) and is mask-for-mask
+# the reference's computation.  FOD_IMU_COLLAPSED_TRAIN=1 keeps the collapsed form in train mode too (faster, per-frame
+# masks).  Eval mode (the benchmark, and every parity fixture) is unaffected: without dropout the two forms are equal.
+IMU_COLLAPSED_TRAIN = os.environ.get("FOD_IMU_COLLAPSED_TRAIN", "0") == "1"
+
+
 class EgodeepAttention(nn.Module):
     """Attention to the per-frame IMU token(s) (reference transformer.py:85-119).
 
@@ -145,6 +155,10 @@ class EgodeepAttention(nn.Module):
     out_proj(value(ego)) for every query row, and the following LayerNorm/MLP act on identical
     rows: computed once per frame as [frames, D]; the caller broadcasts.  query_content /
     query_pos / key only feed the (constant) softmax: their gradient is exactly zero."""
+
+    def per_token_masks(self):
+        """True when the one-key case must run the general form: dropout is active and its masks are per token."""
+        return self.training and self.droprate > 0.0 and not IMU_COLLAPSED_TRAIN
 
     def __init__(self, D, Nhead, droprate, Dff=None):
         super().__init__()
@@ -287,6 +301,8 @@ class TransformerDecoderLayer(nn.Module):
         if self.slotstates_attend is not None and slotstates is not None:
             o = self.slotstates_attend.forward_cross(x, qpos, slotstates)
             x = _add_norm(x, o, self.norm_ssa, p, t)
+        if self.egodeep_attend is not None and egodeep is not None and egodeep.dim() == 2 and self.egodeep_attend.per_token_masks():
+            egodeep = egodeep.unsqueeze(1)             # train mode: the general form, dropout masks per token as in the reference
         if self.egodeep_attend is not None and egodeep is not None and egodeep.dim() == 3:     # [B,S,D]: several keys
             e = Fn.dropout(self.egodeep_attend.forward_keys(x, qpos, egodeep), p, t)
             x = Fn.layer_norm(x, self.norm_eda.weight, self.norm_eda.bias, residual=e)
@@ -435,6 +451,8 @@ class TransformerEncoderLayer(nn.Module):
         if memory is not None:
             for prev, attn in zip(memory, self.previmage_attn):
                 x = attn(x, pos, other=prev)
+        if egodeep is not None and self.egodeep_attend is not None and egodeep.dim() == 2 and self.egodeep_attend.per_token_masks():
+            egodeep = egodeep.unsqueeze(1)             # train mode: the general form, dropout masks per token as in the reference
         if egodeep is not None and self.egodeep_attend is not None and egodeep.dim() == 3:   # [F,S,D]: several keys
             e = self.egodeep_attend.forward_keys(x, pos, egodeep)
             e = Fn.dropout(e, self.egodeep_attend.droprate, self.training)

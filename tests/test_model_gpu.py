@@ -4,6 +4,8 @@ weights and (b) the golden fixtures captured from the reference's own files.
 fp32 mode (exact-f32 MFMA): pred_logits / pred_boxes / loss within 1e-3 relative of the fp32 CPU path
 (BASELINE.json north_star), Hungarian assignment indices bit-exact, gradients within 2e-3 of their norm.
 bf16 mode: same graph on bf16 MFMA; tolerance stated in the test (it is a precision trade, not parity)."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -226,6 +228,44 @@ def test_train_mode_dropout():
     with torch.no_grad():
         e2, _ = model._model(data["video"], imu=imu)
     assert torch.equal(e1["pred_logits"], e2["pred_logits"]) and torch.equal(e1["pred_boxes"], e2["pred_boxes"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_imu_branch_dropout_is_per_token_in_train_mode(dtype, monkeypatch):
+    """with ONE IMU token per frame the reference drops per TOKEN -- the attention probability (a
+    dropped weight removes that token's whole IMU contribution), the block's output, its MLP (transformer.py:108-119,444,
+    485).  Train mode runs the general attention form for that: the IMU update differs between the tokens of a frame and
+    about p of the tokens lose the attention output entirely; eval mode is the collapsed form (identical rows);
+    FOD_IMU_COLLAPSED_TRAIN=1 keeps per-frame masks in train mode."""
+    torch.manual_seed(4)
+    F_, N, D = 3, 640, 256
+    att = T.EgodeepAttention(D, 8, droprate=0.5, Dff=None).to(DEV)
+    x = (torch.randn(F_, N, D, device=DEV) * 0.5).to(dtype)
+    pos = torch.randn(N, D, device=DEV).to(dtype)
+    ego = torch.randn(F_, D, device=DEV).to(dtype)
+    att.eval()
+    with torch.no_grad():
+        collapsed = att.forward_single_key(ego)                                  # [F, D]
+        general = att.forward_keys(x, pos, ego.unsqueeze(1))                     # [F, N, D]
+    span = float(collapsed.float().abs().max())
+    assert float((general.float() - collapsed.float().unsqueeze(1)).abs().max()) <= (1e-4 if dtype == torch.float32 else 2e-2) * span
+    att.train()
+    assert att.per_token_masks()
+    with torch.no_grad():
+        out = att.forward_keys(x, pos, ego.unsqueeze(1)).float()                 # what the layers call in train mode
+        # the attention itself, one key: every (token, head) slice is either dropped or value / (1 - p)
+        v = (torch.randn(F_, 1, D, device=DEV)).to(dtype)
+        q = torch.randn(F_, N, D, device=DEV).to(dtype)
+        k = torch.randn(F_, 1, D, device=DEV).to(dtype)
+        a = Fn.attention(q, k, v, 1.0 / math.sqrt(32), drop_p=0.5, training=True).float().view(F_, N, 8, 32)
+    rows_differ = (out - out[:, :1]).abs().amax(-1) > 1e-3 * span                # tokens of one frame no longer share one row
+    assert float(rows_differ.float().mean()) > 0.9
+    zero = a.abs().sum(-1) == 0
+    assert 0.45 < float(zero.float().mean()) < 0.55, float(zero.float().mean())
+    want = 2.0 * v.float().view(F_, 1, 8, 32).expand(F_, N, 8, 32)
+    assert float((a - want)[~zero].abs().max()) <= 2e-2 * float(want.abs().max())
+    monkeypatch.setattr(T, "IMU_COLLAPSED_TRAIN", True)
+    assert not att.per_token_masks()
 
 
 def test_dead_frame_skipping_is_exact():
