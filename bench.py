@@ -435,6 +435,15 @@ def main():
                         "hipgraph replay (one graph per step)" if not distributed else
                         "hipgraph replay (forward + backward graph, eager gradient all-reduce, optimizer graph)"),
     }
+    # what the number rests on: the step was replayed from a captured graph (a failed capture raises
+    # in GraphedStep -- bench.py has no eager fallback), and whether the weight-gradient queues were available (they need a
+    # private torch symbol; without it ~170 extra launches run one by one)
+    from future_od.native import functional as _Fn
+    result["fast_paths"] = {"captured_graph": bool(use_graph), "wgrad_queue": bool(_Fn.WGRADS.enabled),
+                            "wgrad_queue_long": bool(_Fn.WGRADS.enabled and _Fn.WGRADS.long_enabled)}
+    if use_graph and not _Fn.WGRADS.enabled and rank == 0:
+        sys.stderr.write("bench: the weight-gradient queue is OFF (torch._C._current_graph_task_id missing or FOD_WGRAD_QUEUE=0): "
+                         "every Linear weight gradient is its own launch\n")
     if ddp_info:
         result["ddp"] = ddp_info
     fl = live_flops_per_sequence(a.num_images)
