@@ -31,11 +31,21 @@ struct LanParams {
   long lda;
   int M;
   float eps;
+  // THEN form: the next sub-layer's 256 -> 256 projection of y in the same launch, out2 = y W2^T + b2
+  const __bf16* w2;
+  const float* b2;
+  __bf16* out2;
 };
 
+// THEN: also out2 = y . W2^T + b2 (the query-content projection of the NEXT cross-attention block reads exactly this
+// launch's output): y goes through LDS once to change from the accumulator layout (lane = row, 4 columns per tile) to the
+// operand layout (lane = row, 8 consecutive columns per k-step); the second weight matrix is requested right behind the
+// first product's MFMAs, so its latency hides under the norm's two reductions.
+template <bool THEN>
 __global__ __launch_bounds__(256) void linear_add_norm_kernel(const LanParams p) {
   constexpr int D = 256, K = 256, KS = K / 32;
   __shared__ float red[2][4][16];
+  __shared__ __attribute__((aligned(16))) __bf16 ybuf[THEN ? 16 : 1][D + 8];      // + 8: rows 16 bytes apart in the banks
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & 15, g = lane >> 4;               // MFMA column (= row m of the tile) and lane group
 
@@ -78,6 +88,17 @@ __global__ __launch_bounds__(256) void linear_add_norm_kernel(const LanParams p)
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[t][ks], fa[ks], acc[t], 0, 0, 0);
+    bf16x8_t fw2[THEN ? 4 : 1][THEN ? KS : 1];
+    f32x4v bi2[THEN ? 4 : 1];
+    if (THEN) {                                            // requested now, needed after the norm
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const __bf16* wp = p.w2 + (long)(64 * wave + 16 * t + c) * K + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) fw2[t][ks] = *reinterpret_cast<const bf16x8_t*>(wp + 32 * ks);
+        bi2[t] = p.b2 ? *reinterpret_cast<const f32x4v*>(p.b2 + 64 * wave + 16 * t + 4 * g) : f32x4v{0.f, 0.f, 0.f, 0.f};
+      }
+    }
 
     // ---- s = bf16(x + bf16(a W^T + b)) (the roundings of the two-launch path), statistics on the stored value
     float v[4][4];
@@ -107,20 +128,41 @@ __global__ __launch_bounds__(256) void linear_add_norm_kernel(const LanParams p)
     if (g == 0) red[1][wave][c] = q;
     __syncthreads();
     const float rs = rsqrtf((red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]) * (1.f / D) + p.eps);
-    if (live) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int n = 64 * wave + 16 * t + 4 * g;
-        bf16x4_t o;
+    for (int t = 0; t < 4; ++t) {
+      const int n = 64 * wave + 16 * t + 4 * g;
+      bf16x4_t o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (__bf16)((v[t][r] - mu) * rs * ga[t][r] + be[t][r]);
+      for (int r = 0; r < 4; ++r) o[r] = (__bf16)((v[t][r] - mu) * rs * ga[t][r] + be[t][r]);
+      if (live) {
         *reinterpret_cast<bf16x4_t*>(p.y + (long)m * D + n) = o;
         if (p.sum_out) *reinterpret_cast<bf16x4_t*>(p.sum_out + (long)m * D + n) = sb[t];
       }
-      if (wave == 0 && g == 0) {
-        p.mean[m] = mu;
-        p.rstd[m] = rs;
+      if (THEN) *reinterpret_cast<bf16x4_t*>(&ybuf[c][n]) = o;
+    }
+    if (live && wave == 0 && g == 0) {
+      p.mean[m] = mu;
+      p.rstd[m] = rs;
+    }
+    if (THEN) {
+      __syncthreads();                                     // the 16 x 256 tile of y (as stored: bf16) is in LDS
+      f32x4v acc2[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc2[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t fy = *reinterpret_cast<const bf16x8_t*>(&ybuf[c][32 * ks + 8 * g]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[t][ks], fy, acc2[t], 0, 0, 0);
       }
+      if (live) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          *reinterpret_cast<bf16x4_t*>(p.out2 + (long)m * D + 64 * wave + 16 * t + 4 * g) =
+              bf16x4_t{(__bf16)(acc2[t][0] + bi2[t][0]), (__bf16)(acc2[t][1] + bi2[t][1]), (__bf16)(acc2[t][2] + bi2[t][2]),
+                       (__bf16)(acc2[t][3] + bi2[t][3])};
+      }
+      __syncthreads();                                     // (a further tile of this workgroup overwrites ybuf)
     }
   }
 }
@@ -264,7 +306,8 @@ int lan_grid(int M) {
 
 extern "C" int fod_linear_add_norm_fwd(int dtype, const void* a, long lda, const void* w, const float* bias, const void* x,
                                        const float* gamma, const float* beta, void* y, void* sum_out, float* mean,
-                                       float* rstd, int M, int N, int K, float eps, hipStream_t stream) {
+                                       float* rstd, int M, int N, int K, float eps, const void* then_w,
+                                       const float* then_bias, void* then_out, hipStream_t stream) {
   FOD_REQUIRE(dtype == FOD_BF16, "linear_add_norm: bf16 only (dtype %d)", dtype);
   FOD_REQUIRE(a && w && x && gamma && beta && y && mean && rstd && M > 0, "linear_add_norm: bad args");
   FOD_REQUIRE(N == 256 && K == 256, "linear_add_norm: built for 256 x 256 projections (N %d, K %d)", N, K);
@@ -275,7 +318,14 @@ extern "C" int fod_linear_add_norm_fwd(int dtype, const void* a, long lda, const
   LanParams p{};
   p.a = (const __bf16*)a; p.w = (const __bf16*)w; p.bias = bias; p.x = (const __bf16*)x; p.gamma = gamma; p.beta = beta;
   p.y = (__bf16*)y; p.sum_out = (__bf16*)sum_out; p.mean = mean; p.rstd = rstd; p.lda = lda; p.M = M; p.eps = eps;
-  hipLaunchKernelGGL(linear_add_norm_kernel, dim3(lan_grid(M)), dim3(256), 0, stream, p);
+  FOD_REQUIRE((then_w == nullptr) == (then_out == nullptr), "linear_add_norm: then_w and then_out come together");
+  if (then_w) {
+    FOD_REQUIRE(al(then_w) && al(then_out) && (!then_bias || al(then_bias)), "linear_add_norm: then operands must be 16-byte aligned");
+    p.w2 = (const __bf16*)then_w; p.b2 = then_bias; p.out2 = (__bf16*)then_out;
+    hipLaunchKernelGGL(linear_add_norm_kernel<true>, dim3(lan_grid(M)), dim3(256), 0, stream, p);
+  } else {
+    hipLaunchKernelGGL(linear_add_norm_kernel<false>, dim3(lan_grid(M)), dim3(256), 0, stream, p);
+  }
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }

@@ -45,16 +45,24 @@ class _Proj:
         self.a, self.lin, self.a_relu = a, lin, a_relu      # a_relu: see Fn.LinearAddNormFn / _fused_tail
 
 
-def _add_norm(x, new, norm: nn.LayerNorm, p, training):
+def _add_norm(x, new, norm: nn.LayerNorm, p, training, then: nn.Linear = None):
     """norm(x + dropout(new)) -- the post-norm residual step of every sub-layer (reference transformer.py:271-272,
-    285-286, 310-311, 417-418); `new` is a tensor or a pending `_Proj`."""
+    285-286, 310-311, 417-418); `new` is a tensor or a pending `_Proj`.  `then`: the Linear the NEXT block applies to this
+    result first (a cross-attention block's query_content): where the fused launch can, it computes that projection too
+    and the return value is (y, then(y)) -- else (y, None)."""
     if isinstance(new, _Proj):
         vec_ok = new.lin.weight.shape[0] % 8 == 0
         if vec_ok and not (training and p > 0.0):
+            if then is not None:
+                if not new.a_relu and Fn.linear_add_norm_then_fits(new.a, new.lin.weight, then.weight):
+                    return Fn.linear_add_norm_then(new.a, x, new.lin.weight, new.lin.bias, norm.weight, norm.bias,
+                                                   then.weight, then.bias)
+                return Fn.linear_add_norm(new.a, x, new.lin.weight, new.lin.bias, norm.weight, norm.bias, new.a_relu), None
             return Fn.linear_add_norm(new.a, x, new.lin.weight, new.lin.bias, norm.weight, norm.bias, new.a_relu)
         assert not new.a_relu, "a ReLU that left its gradient mask to a fused tail needs that tail (see _fused_tail)"
         new = _lin(new.a, new.lin)
-    return Fn.layer_norm(x, norm.weight, norm.bias, residual=Fn.dropout(new, p, training))
+    y = Fn.layer_norm(x, norm.weight, norm.bias, residual=Fn.dropout(new, p, training))
+    return (y, None) if then is not None else y
 
 
 def _fused_tail(lin: nn.Linear, p, training):
@@ -219,7 +227,7 @@ class SlotToImageAttention(Attention):
         self.store_attention = False
 
     def forward(self, x, qpos, query_sine, side, layer, image, is_first, qs=None, qpos_proj=None, keep=False,
-                attn_mask=None, key_padding_mask=None):
+                attn_mask=None, key_padding_mask=None, qc_pre=None):
         """`side` (functional.MemorySide) holds this image's value / key_content projections for ALL layers
         and the projected positional table; this call uses the (layer, image) slots.  `qs` = query_sine(query_sine)
         and `qpos_proj` = query_pos(qpos) when the caller has projected them for all images at once.
@@ -227,8 +235,10 @@ class SlotToImageAttention(Attention):
         _no_masks(attn_mask, key_padding_mask)
         B, M, D = x.shape
         if keep:
-            x_keep, qc = Fn.linear_keep(x, self.query_content.weight, self.query_content.bias)
+            # qc_pre: query_content(x) as the launch that produced x already computed it (_add_norm(then=...))
+            x_keep, qc = Fn.linear_keep(x, self.query_content.weight, self.query_content.bias, precomputed=qc_pre)
         else:
+            assert qc_pre is None
             qc = _lin(x, self.query_content)
         if is_first:
             qc = Fn.add(qc, qpos_proj if qpos_proj is not None else _lin(qpos, self.query_pos), b_row_mod=M)
@@ -291,13 +301,21 @@ class TransformerDecoderLayer(nn.Module):
         slotstates [B,M,D] or None; egodeep [B,D] (ONE IMU token per sample) or None."""
         t, p = self.training, self.droprate
         o = self.self_attend(x, qpos, pos_proj["sa"] if pos_proj else None)
-        x = _add_norm(x, o, self.norm_sa, p, t)
+        # each post-norm launch also forms the NEXT cross-attention block's query_content projection of its output
+        if side.K > 0:
+            x, qc_pre = _add_norm(x, o, self.norm_sa, p, t, then=self.image_attend[0].query_content)
+        else:
+            x, qc_pre = _add_norm(x, o, self.norm_sa, p, t), None
         # the sine embedding is the same for every image of the layer: all their query_sine projections at once
         qs_all = Fn.group_linear(query_sine, [self.image_attend[i].query_sine for i in range(side.K)])
         for i in range(side.K):
             o, x = self.image_attend[i](x, qpos, query_sine, side, layer, i, is_first, qs=qs_all[i],
-                                        qpos_proj=pos_proj["ca"][i] if (pos_proj and is_first) else None, keep=True)
-            x = _add_norm(x, o, self.norm_ia[i], p, t)
+                                        qpos_proj=pos_proj["ca"][i] if (pos_proj and is_first) else None, keep=True,
+                                        qc_pre=qc_pre)
+            if i + 1 < side.K:
+                x, qc_pre = _add_norm(x, o, self.norm_ia[i], p, t, then=self.image_attend[i + 1].query_content)
+            else:
+                x, qc_pre = _add_norm(x, o, self.norm_ia[i], p, t), None
         if self.slotstates_attend is not None and slotstates is not None:
             o = self.slotstates_attend.forward_cross(x, qpos, slotstates)
             x = _add_norm(x, o, self.norm_ssa, p, t)

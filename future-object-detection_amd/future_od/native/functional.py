@@ -696,13 +696,17 @@ class LinearKeepFn(Function):
     step); here the residual path's gradient enters the projection's input-gradient GEMM as its epilogue operand."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, grad_masked=False):
+    def forward(ctx, x, weight, bias, relu, grad_masked=False, precomputed=None):
         """`grad_masked` (with relu): the consumer of y applies the (y > 0) mask to the gradient it sends back
-        (LinearAddNormFn(a_relu=True)); this node then skips its own masking pass."""
+        (LinearAddNormFn(a_relu=True)); this node then skips its own masking pass.  `precomputed`: act(x W^T + b) as the
+        launch that produced x already computed it (LinearAddNormFn(then=...)): no launch here, the same backward."""
         dtype = x.dtype
-        w = prep_linear(weight, dtype, False)
         N = weight.shape[0]
-        y = ops.gemm_nt(x, w[:N] if w.shape[0] != N else w, shift=bias, relu=relu).view(*x.shape[:-1], N)
+        if precomputed is not None:
+            y = precomputed.view(*x.shape[:-1], N)
+        else:
+            w = prep_linear(weight, dtype, False)
+            y = ops.gemm_nt(x, w[:N] if w.shape[0] != N else w, shift=bias, relu=relu).view(*x.shape[:-1], N)
         ctx.relu, ctx.weight, ctx.bias, ctx.has_bias = relu, weight, bias, bias is not None
         ctx.mask_here = relu and not grad_masked
         ctx.save_for_backward(x, y if ctx.mask_here else None)
@@ -733,18 +737,19 @@ class LinearKeepFn(Function):
             WGRADS.tn(WGRADS.site((weight, ctx.bias)), g, x.view(-1, K), dw, dbp)
         elif want_db:
             ops.colsum_acc(g, dbp)
-        return dx, dw, dbp, None, None
+        return dx, dw, dbp, None, None, None
 
 
 _LINEAR_KEEP = __import__("os").environ.get("FOD_LINEAR_KEEP", "1") != "0"       # "0": two autograd consumers (experiments)
 
 
-def linear_keep(x, weight, bias=None, relu=False, grad_masked=False):
+def linear_keep(x, weight, bias=None, relu=False, grad_masked=False, precomputed=None):
     """-> (x for the residual path, act(x W^T + b)); see LinearKeepFn.  Falls back to two consumers when the output
     width does not fit the vector epilogue (that path masks its own gradient: a second mask upstream is harmless)."""
     if weight.shape[0] % _VEC[x.dtype] != 0 or not _LINEAR_KEEP:
+        assert precomputed is None
         return x, linear(x, weight, bias, relu=relu)
-    return LinearKeepFn.apply(x.contiguous(), weight, bias, relu, grad_masked)
+    return LinearKeepFn.apply(x.contiguous(), weight, bias, relu, grad_masked, precomputed)
 
 
 class AddFn(Function):
@@ -870,6 +875,8 @@ def layer_norm(x, gamma, beta, residual=None, res_row_div=0):
 # "0": the output projection and the post-norm of the decoder's attention blocks as two launches (fod_gemm_nt +
 # fod_layernorm_fwd) instead of fod_linear_add_norm_fwd
 FUSED_LINEAR_NORM = os.environ.get("FOD_FUSED_LINEAR_NORM", "1") != "0"
+# the next cross-attention block's query-content projection from the same launch (fod_linear_add_norm_fwd then_*); "0": its own GEMM
+FUSED_LINEAR_THEN = os.environ.get("FOD_FUSED_LINEAR_THEN", "1") != "0"
 # rows up to which the fused launches are used.  The kernels walk 16-row tiles with the weights stationary, so they take any
 # row count, but at the encoder's 14 500 rows they do not pay (one wave per SIMD, every tile's loads queue behind the
 # previous tile's stores): forward 19.5 us against 21.3 for GEMM + norm, backward 26.3 against 20.9, whole step +0.1 ms
@@ -884,7 +891,7 @@ class LinearAddNormFn(Function):
     Used where no dropout sits between the projection and the add (eval mode or p = 0)."""
 
     @staticmethod
-    def forward(ctx, a, x, weight, bias, gamma, beta, a_relu=False):
+    def forward(ctx, a, x, weight, bias, gamma, beta, a_relu=False, then_weight=None, then_bias=None):
         """`a_relu`: `a` is the output of a ReLU whose producer leaves the masking of its incoming gradient to THIS
         node (LinearKeepFn(grad_masked=True)): the (a > 0) mask is applied in the epilogue of the GEMM that forms da --
         one pass over a [rows, 2048] gradient less per feed-forward block."""
@@ -895,16 +902,27 @@ class LinearAddNormFn(Function):
         if (FUSED_LINEAR_NORM and a.dtype == torch.bfloat16 and N == 256 and weight.shape[1] == 256 and w.shape[1] == 256
                 and rows <= FUSED_LINEAR_NORM_ROWS):
             # the decoder's query side: projection + residual add + norm as ONE launch (csrc/linear_norm.hip)
-            y, s, mean, rstd = ops.linear_add_norm_fwd(a, w, bias, x, gamma, beta)
+            if then_weight is not None:
+                # ... and the next block's 256 -> 256 projection of y from the same launch: a CONSTANT second output
+                # that LinearKeepFn(precomputed=...) adopts as its result (its backward is the usual one)
+                y, s, mean, rstd, nxt = ops.linear_add_norm_fwd(a, w, bias, x, gamma, beta,
+                                                                then_w=prep_linear(then_weight, a.dtype, False),
+                                                                then_bias=then_bias)
+            else:
+                y, s, mean, rstd = ops.linear_add_norm_fwd(a, w, bias, x, gamma, beta)
         else:
+            assert then_weight is None, "linear_add_norm(then=...) outside the fused launch's domain (the caller checks)"
             o = ops.gemm_nt(a, w, shift=bias).view(x.shape)
             y, s, mean, rstd = ops.layernorm_fwd(x, gamma, beta, residual=o)
         ctx.save_for_backward(a, s, mean, rstd, gamma)
         ctx.weight, ctx.bias, ctx.has_bias, ctx.a_relu = weight, bias, bias is not None, bool(a_relu)
+        if then_weight is not None:
+            ctx.mark_non_differentiable(nxt)
+            return y, nxt
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dnxt=None):
         a, s, mean, rstd, gamma = ctx.saved_tensors
         weight = ctx.weight
         N, K = weight.shape
@@ -935,11 +953,24 @@ class LinearAddNormFn(Function):
             WGRADS.tn(WGRADS.site((weight, ctx.bias)), g, a.view(-1, K), dw, db)
         elif want_db:
             ops.colsum_acc(g, db)
-        return da, (dsum if ctx.needs_input_grad[1] else None), dw, db, dg, dbeta, None
+        return da, (dsum if ctx.needs_input_grad[1] else None), dw, db, dg, dbeta, None, None, None
 
 
 def linear_add_norm(a, x, weight, bias, gamma, beta, a_relu=False):
-    return LinearAddNormFn.apply(a.contiguous(), x.contiguous(), weight, bias, gamma, beta, a_relu)
+    return LinearAddNormFn.apply(a.contiguous(), x.contiguous(), weight, bias, gamma, beta, a_relu, None, None)
+
+
+def linear_add_norm_then_fits(a, weight, then_weight):
+    """Whether linear_add_norm_then may be used: the fused launch's domain (bf16, 256-wide projections, few rows)."""
+    rows = a.numel() // a.shape[-1]
+    return (FUSED_LINEAR_NORM and FUSED_LINEAR_THEN and a.dtype == torch.bfloat16 and tuple(weight.shape) == (256, 256)
+            and tuple(then_weight.shape) == (256, 256) and rows <= FUSED_LINEAR_NORM_ROWS and _LINEAR_KEEP)
+
+
+def linear_add_norm_then(a, x, weight, bias, gamma, beta, then_weight, then_bias):
+    """(y, y then_weight^T + then_bias) with y = LayerNorm(x + a W^T + b): ONE launch; the second result is a constant
+    for autograd -- hand it to linear_keep(y, then_weight, then_bias, precomputed=...), whose backward needs nothing else."""
+    return LinearAddNormFn.apply(a.contiguous(), x.contiguous(), weight, bias, gamma, beta, False, then_weight, then_bias)
 
 
 # ------------------------------------------------------------------------------------------------

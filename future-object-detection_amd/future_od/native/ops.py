@@ -593,9 +593,10 @@ def layernorm_fwd(x, gamma, beta, residual=None, res_row_div=0, res_row_mod=0, w
     return y, (s if want_sum else x), mean, rstd
 
 
-def linear_add_norm_fwd(a, w, bias, x, gamma, beta, eps=1e-5):
+def linear_add_norm_fwd(a, w, bias, x, gamma, beta, eps=1e-5, then_w=None, then_bias=None):
     """LayerNorm(x + (a w^T + bias)) in one launch (bf16, 256 x 256 projection): returns (y, sum, mean, rstd) as
-    layernorm_fwd(x, ..., residual=gemm_nt(a, w, shift=bias)) does."""
+    layernorm_fwd(x, ..., residual=gemm_nt(a, w, shift=bias)) does.  then_w [256, 256] (+ then_bias): a fifth result,
+    y then_w^T + then_bias, from the same launch."""
     _chk(a, "a", torch.bfloat16); _chk(w, "w", torch.bfloat16); _chk(x, "x", torch.bfloat16)
     _chk(gamma, "gamma", torch.float32); _chk(beta, "beta", torch.float32)
     N, K = w.shape
@@ -607,9 +608,16 @@ def linear_add_norm_fwd(a, w, bias, x, gamma, beta, eps=1e-5):
     s = torch.empty_like(x)
     mean = torch.empty(M, dtype=torch.float32, device=x.device)
     rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    out2 = None
+    if then_w is not None:
+        _chk(then_w, "then_w", torch.bfloat16); assert tuple(then_w.shape) == (N, N)
+        if then_bias is not None:
+            _chk(then_bias, "then_bias", torch.float32); assert then_bias.numel() == N
+        out2 = torch.empty_like(x)
     call("fod_linear_add_norm_fwd", dt(a), ptr(a), K, ptr(w), ptr(bias), ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(s),
-         ptr(mean), ptr(rstd), M, N, K, eps, stream(), work=2.0 * M * N * K, tag="fod_gemm_nt")
-    return y, s, mean, rstd
+         ptr(mean), ptr(rstd), M, N, K, eps, ptr(then_w), ptr(then_bias), ptr(out2), stream(),
+         work=2.0 * M * N * K * (2 if then_w is not None else 1), tag="fod_gemm_nt")
+    return (y, s, mean, rstd) if then_w is None else (y, s, mean, rstd, out2)
 
 
 def linear_add_norm_bwd(dy, xsum, mean, rstd, gamma, w_t, dgamma, dbeta, want_da=True):

@@ -304,7 +304,10 @@ int fod_attn_fwd_fp8(const void* q_pack, const void* kv_pack, int parts, void* o
  * receives x + (a W^T + bias) as fod_layernorm_fwd's does; mean / rstd f32 [M] for fod_layernorm_bwd. */
 int fod_linear_add_norm_fwd(int dtype, const void* a, long lda, const void* w, const float* bias, const void* x,
                             const float* gamma, const float* beta, void* y, void* sum_out, float* mean, float* rstd,
-                            int M, int N, int K, float eps, fod_stream_t stream);
+                            int M, int N, int K, float eps,
+                            /* optional: then_out [M, 256] = y . then_w^T + then_bias (then_w [256, 256]) in the same
+                             * launch -- the next cross-attention block's query-content projection of this output */
+                            const void* then_w, const float* then_bias, void* then_out, fod_stream_t stream);
 /* Its backward counterpart in one launch: dsum = fod_layernorm_bwd(dy, xsum, mean, rstd, gamma) (the gradient of
  * x + o; dgamma / dbeta accumulated), and -- when da is not NULL -- da [M, K] = dsum . W, with w_t = W^T as [K][N]. */
 int fod_linear_add_norm_bwd(int dtype, const void* dy, const void* xsum, const float* mean, const float* rstd,

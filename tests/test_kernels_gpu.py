@@ -282,6 +282,48 @@ def test_fused_linear_add_norm_forward(M, with_bias):
     assert torch.allclose(mean, s.float().mean(-1), atol=1e-4) and torch.allclose(rstd, (s.float().var(-1, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4)
 
 
+@pytest.mark.parametrize("M", [256, 100, 1, 515])
+def test_fused_linear_add_norm_then_next_projection(M):
+    """fod_linear_add_norm_fwd(then_*): the next block's 256 -> 256 projection of the normalised output from the same launch
+    equals fod_gemm_nt on that output within one bf16 ulp (BIT-equal inputs: the y it multiplies is the stored bf16 y), the
+    other four results are bit-equal to the launch without it; through autograd (linear_add_norm_then + linear_keep(
+    precomputed=...)) every gradient equals the unfused graph's."""
+    from future_od.native import functional as Fn
+    dtype = torch.bfloat16
+    a = rnd((M, 256), dtype, 61).to(DEV)
+    w = rnd((256, 256), dtype, 62, scale=1.0 / 16).to(DEV)
+    w2 = rnd((256, 256), dtype, 63, scale=1.0 / 16).to(DEV)
+    x = rnd((M, 256), dtype, 64).to(DEV)
+    b, b2 = (torch.randn(256) * 0.3).to(DEV), (torch.randn(256) * 0.3).to(DEV)
+    gamma, beta = (torch.rand(256) + 0.5).to(DEV), (torch.randn(256) * 0.2).to(DEV)
+    y0, s0, m0, r0 = ops.linear_add_norm_fwd(a, w, b, x, gamma, beta)
+    y, s, mean, rstd, q = ops.linear_add_norm_fwd(a, w, b, x, gamma, beta, then_w=w2, then_bias=b2)
+    assert torch.equal(y, y0) and torch.equal(s, s0) and torch.equal(mean, m0) and torch.equal(rstd, r0)
+    q_ref = ops.gemm_nt(y0, w2, shift=b2)
+    assert float((q.float() - q_ref.float()).abs().max()) <= 2.0 ** -7 * float(q_ref.float().abs().max())
+    # autograd: fused (then) graph vs the plain graph, same parameters
+    lin, lin2, ln = torch.nn.Linear(256, 256).to(DEV), torch.nn.Linear(256, 256).to(DEV), torch.nn.LayerNorm(256).to(DEV)
+    gy, gq = rnd((M, 256), dtype, 65).to(DEV), rnd((M, 256), dtype, 66).to(DEV)
+    grads = []
+    for fused in (True, False):
+        for prm in list(lin.parameters()) + list(lin2.parameters()) + list(ln.parameters()):
+            prm.grad = None
+        Fn.PREP.clear()
+        aa, xx = a.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        if fused:
+            assert Fn.linear_add_norm_then_fits(aa, lin.weight, lin2.weight)
+            yy, pre = Fn.linear_add_norm_then(aa, xx, lin.weight, lin.bias, ln.weight, ln.bias, lin2.weight, lin2.bias)
+            keep, qq = Fn.linear_keep(yy, lin2.weight, lin2.bias, precomputed=pre)
+        else:
+            yy = Fn.linear_add_norm(aa, xx, lin.weight, lin.bias, ln.weight, ln.bias)
+            keep, qq = Fn.linear_keep(yy, lin2.weight, lin2.bias)
+        ((keep.float() * gy.float()).sum() + (qq.float() * gq.float()).sum()).backward()
+        grads.append([aa.grad, xx.grad] + [prm.grad.clone() for prm in list(lin.parameters()) + list(lin2.parameters()) + list(ln.parameters())])
+    for g1, g2 in zip(*grads):
+        err = float((g1.double() - g2.double()).norm() / g2.double().norm().clamp_min(1e-9))
+        assert err <= 1e-2, err
+
+
 @pytest.mark.parametrize("M", [256, 100, 16, 1, 515, 14500])
 def test_fused_linear_add_norm_backward(M):
     """fod_linear_add_norm_bwd (layer-norm gradient + the projection's input gradient in one launch) against
