@@ -186,10 +186,19 @@ struct LanBwdParams {
   float* dgamma;
   float* dbeta;
   int M;
+  // PRE form: the incoming gradient is dy + pre_g . W2 (the THEN projection's input gradient, pre_wt = W2^T as [K][N]);
+  // dy may be NULL (no other consumer of the normalised output)
+  const __bf16* pre_g;
+  const __bf16* pre_wt;
 };
 
+// PRE: the forward launch also computed q = y W2^T + b2 (THEN form), so the gradient of y is dy + dq . W2: that product runs
+// here first (W2^T rows as the A operand, dq rows as the B operand), its result goes through LDS once to reach the operand
+// layout the layer-norm gradient reads (every wave needs whole rows), and the launch that would have formed it is gone.
+template <bool PRE>
 __global__ __launch_bounds__(256) void linear_add_norm_bwd_kernel(const LanBwdParams p) {
   constexpr int D = 256, KS = D / 32;
+  __shared__ __attribute__((aligned(16))) __bf16 dybuf[PRE ? 16 : 1][D + 8];
   __shared__ __attribute__((aligned(16))) float sgam[D];
   __shared__ __attribute__((aligned(16))) float cg[16][D + 4];      // dy * xhat per (row, column); + 4: rows on different banks
   __shared__ __attribute__((aligned(16))) float cb[16][D + 4];      // dy
@@ -214,14 +223,47 @@ __global__ __launch_bounds__(256) void linear_add_norm_bwd_kernel(const LanBwdPa
     const int m = min(m0 + c, p.M - 1);
     const bool live = m0 + c < p.M;
     bf16x8_t fd[KS], fx[KS];
-    const __bf16* dp = p.dy + (long)m * D + 8 * g;
     const __bf16* xp = p.xs + (long)m * D + 8 * g;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      fd[ks] = *reinterpret_cast<const bf16x8_t*>(dp + 32 * ks);
-      fx[ks] = *reinterpret_cast<const bf16x8_t*>(xp + 32 * ks);
-    }
+    for (int ks = 0; ks < KS; ++ks) fx[ks] = *reinterpret_cast<const bf16x8_t*>(xp + 32 * ks);
     const float mu = p.mean[m], rs = p.rstd[m];
+    if (PRE) {
+      // ---- dy_total^T[n, m] = dy[m, n] + sum_o W2^T[n, o] dq[m, o], this wave's 64 columns n
+      bf16x8_t fq[KS], fw2[4][KS];
+      const __bf16* qp = p.pre_g + (long)m * D + 8 * g;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) fq[ks] = *reinterpret_cast<const bf16x8_t*>(qp + 32 * ks);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const __bf16* wp = p.pre_wt + (long)(64 * wave + 16 * t + c) * D + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) fw2[t][ks] = *reinterpret_cast<const bf16x8_t*>(wp + 32 * ks);
+      }
+      bf16x4_t dk[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        dk[t] = p.dy ? *reinterpret_cast<const bf16x4_t*>(p.dy + (long)m * D + 64 * wave + 16 * t + 4 * g)
+                     : bf16x4_t{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+      f32x4v accp[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) accp[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[t][ks], fq[ks], accp[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        *reinterpret_cast<bf16x4_t*>(&dybuf[c][64 * wave + 16 * t + 4 * g]) =
+            bf16x4_t{(__bf16)(accp[t][0] + (float)dk[t][0]), (__bf16)(accp[t][1] + (float)dk[t][1]),
+                     (__bf16)(accp[t][2] + (float)dk[t][2]), (__bf16)(accp[t][3] + (float)dk[t][3])};
+      __syncthreads();                                     // whole rows of the total gradient, as the unfused GEMM would have stored them
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) fd[ks] = *reinterpret_cast<const bf16x8_t*>(&dybuf[c][32 * ks + 8 * g]);
+    } else {
+      const __bf16* dp = p.dy + (long)m * D + 8 * g;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) fd[ks] = *reinterpret_cast<const bf16x8_t*>(dp + 32 * ks);
+    }
 
     // ---- layer-norm gradient of this lane's 64 (row, column) pairs
     float s1 = 0.f, s2 = 0.f;
@@ -332,19 +374,24 @@ extern "C" int fod_linear_add_norm_fwd(int dtype, const void* a, long lda, const
 
 extern "C" int fod_linear_add_norm_bwd(int dtype, const void* dy, const void* xsum, const float* mean, const float* rstd,
                                        const float* gamma, const void* w_t, void* dsum, void* da, float* dgamma,
-                                       float* dbeta, int M, int N, int K, hipStream_t stream) {
+                                       float* dbeta, int M, int N, int K, const void* pre_g, const void* pre_w_t,
+                                       hipStream_t stream) {
   FOD_REQUIRE(dtype == FOD_BF16, "linear_add_norm_bwd: bf16 only (dtype %d)", dtype);
-  FOD_REQUIRE(dy && xsum && mean && rstd && gamma && dsum && dgamma && dbeta && M > 0, "linear_add_norm_bwd: bad args");
+  FOD_REQUIRE((dy || pre_g) && xsum && mean && rstd && gamma && dsum && dgamma && dbeta && M > 0, "linear_add_norm_bwd: bad args");
+  FOD_REQUIRE((pre_g == nullptr) == (pre_w_t == nullptr), "linear_add_norm_bwd: pre_g and pre_w_t come together");
   FOD_REQUIRE((da == nullptr) || w_t, "linear_add_norm_bwd: da needs w_t");
   FOD_REQUIRE(N == 256 && K == 256, "linear_add_norm_bwd: built for 256 x 256 projections (N %d, K %d)", N, K);
   auto al = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
-  FOD_REQUIRE(al(dy) && al(xsum) && al(gamma) && al(dsum) && (!da || (al(da) && al(w_t))),
+  FOD_REQUIRE((!dy || al(dy)) && al(xsum) && al(gamma) && al(dsum) && (!da || (al(da) && al(w_t))) &&
+                  (!pre_g || (al(pre_g) && al(pre_w_t))),
               "linear_add_norm_bwd: operands must be 16-byte aligned");
   LanBwdParams p{};
   p.dy = (const __bf16*)dy; p.xs = (const __bf16*)xsum; p.mean = mean; p.rstd = rstd; p.gamma = gamma;
-  p.wt = (const __bf16*)(w_t ? w_t : dy); p.dsum = (__bf16*)dsum; p.da = (__bf16*)da; p.dgamma = dgamma; p.dbeta = dbeta;
+  p.wt = (const __bf16*)(w_t ? w_t : xsum); p.dsum = (__bf16*)dsum; p.da = (__bf16*)da; p.dgamma = dgamma; p.dbeta = dbeta;
   p.M = M;
-  hipLaunchKernelGGL(linear_add_norm_bwd_kernel, dim3(lan_grid(M)), dim3(256), 0, stream, p);
+  p.pre_g = (const __bf16*)pre_g; p.pre_wt = (const __bf16*)pre_w_t;
+  if (pre_g) hipLaunchKernelGGL(linear_add_norm_bwd_kernel<true>, dim3(lan_grid(M)), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(linear_add_norm_bwd_kernel<false>, dim3(lan_grid(M)), dim3(256), 0, stream, p);
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }

@@ -234,7 +234,10 @@ class SlotToImageAttention(Attention):
         `keep`: also return x for the residual step (one autograd consumer of x instead of two, Fn.LinearKeepFn)."""
         _no_masks(attn_mask, key_padding_mask)
         B, M, D = x.shape
-        if keep:
+        if keep and qc_pre is not None and Fn.FUSED_LINEAR_PRE:
+            # query_content(x) is an output of the node that produced x (_add_norm(then=...)); so is its backward
+            x_keep, qc = x, qc_pre.view(B, M, D)
+        elif keep:
             # qc_pre: query_content(x) as the launch that produced x already computed it (_add_norm(then=...))
             x_keep, qc = Fn.linear_keep(x, self.query_content.weight, self.query_content.bias, precomputed=qc_pre)
         else:

@@ -877,6 +877,9 @@ def layer_norm(x, gamma, beta, residual=None, res_row_div=0):
 FUSED_LINEAR_NORM = os.environ.get("FOD_FUSED_LINEAR_NORM", "1") != "0"
 # the next cross-attention block's query-content projection from the same launch (fod_linear_add_norm_fwd then_*); "0": its own GEMM
 FUSED_LINEAR_THEN = os.environ.get("FOD_FUSED_LINEAR_THEN", "1") != "0"
+# ... and its backward: the input gradient of that projection (dq . then_w) is formed inside the fused backward launch
+# (fod_linear_add_norm_bwd pre_*) instead of by a GEMM of LinearKeepFn; "0": LinearKeepFn(precomputed=...) as before
+FUSED_LINEAR_PRE = os.environ.get("FOD_FUSED_LINEAR_PRE", "1") != "0"
 # rows up to which the fused launches are used.  The kernels walk 16-row tiles with the weights stationary, so they take any
 # row count, but at the encoder's 14 500 rows they do not pay (one wave per SIMD, every tile's loads queue behind the
 # previous tile's stores): forward 19.5 us against 21.3 for GEMM + norm, backward 26.3 against 20.9, whole step +0.1 ms
@@ -914,31 +917,60 @@ class LinearAddNormFn(Function):
             assert then_weight is None, "linear_add_norm(then=...) outside the fused launch's domain (the caller checks)"
             o = ops.gemm_nt(a, w, shift=bias).view(x.shape)
             y, s, mean, rstd = ops.layernorm_fwd(x, gamma, beta, residual=o)
-        ctx.save_for_backward(a, s, mean, rstd, gamma)
+        ctx.then = None
         ctx.weight, ctx.bias, ctx.has_bias, ctx.a_relu = weight, bias, bias is not None, bool(a_relu)
+        if then_weight is not None and FUSED_LINEAR_PRE:
+            # the second result is differentiable: its gradient comes back to THIS node (backward's pre form)
+            ctx.then = (then_weight, then_bias)
+            ctx.save_for_backward(a, s, mean, rstd, gamma, y)
+            return y, nxt
+        ctx.save_for_backward(a, s, mean, rstd, gamma)
         if then_weight is not None:
             ctx.mark_non_differentiable(nxt)
             return y, nxt
         return y
 
     @staticmethod
-    def backward(ctx, dy, _dnxt=None):
-        a, s, mean, rstd, gamma = ctx.saved_tensors
+    def backward(ctx, dy, dnxt=None):
+        a, s, mean, rstd, gamma = ctx.saved_tensors[:5]
         weight = ctx.weight
         N, K = weight.shape
-        dev = dy.device
+        dev = s.device
         dg, dbeta = zeros_f32((N,), dev), zeros_f32((N,), dev)
         da = None
-        rows = dy.numel() // N
-        if (FUSED_LINEAR_NORM and dy.dtype == torch.bfloat16 and N == 256 and K == 256 and rows <= FUSED_LINEAR_NORM_ROWS
+        rows = s.numel() // N
+        dw2 = db2 = None
+        pre_g = pre_wt = None
+        if ctx.then is not None and dnxt is not None:
+            # the THEN projection's own gradients: its weight / bias through the queue (dq^T y), its input gradient
+            # dq . then_w joins dy inside the fused launch below (or through a GEMM epilogue on the fallback path)
+            then_w, then_b = ctx.then
+            y = ctx.saved_tensors[5]
+            pre_g = dnxt.contiguous().view(-1, N)
+            if pre_g.dtype != a.dtype:
+                pre_g = cast(pre_g, a.dtype)
+            pre_wt = prep_linear(then_w, a.dtype, True)
+            want_db2 = then_b is not None and ctx.needs_input_grad[8]
+            if want_db2:
+                db2 = zeros_f32((N,), dev)
+            if ctx.needs_input_grad[7]:
+                dw2 = zeros_f32((N, N), dev)
+                WGRADS.tn(WGRADS.site((then_w, then_b)), pre_g, y.view(-1, N), dw2, db2)
+            elif want_db2:
+                ops.colsum_acc(pre_g, db2)
+        if dy is not None:
+            dy = dy.contiguous()
+        if (FUSED_LINEAR_NORM and s.dtype == torch.bfloat16 and N == 256 and K == 256 and rows <= FUSED_LINEAR_NORM_ROWS
                 and ctx.needs_input_grad[0] and not ctx.a_relu):
             # the decoder's query side: layer-norm gradient and the projection's input gradient as ONE launch
             wt = prep_linear(weight, a.dtype, True)
             assert tuple(wt.shape) == (K, N)
-            dsum, da = ops.linear_add_norm_bwd(dy.contiguous(), s, mean, rstd, gamma, wt, dg, dbeta)
-            dsum, da = dsum.view(dy.shape), da.view(a.shape)
+            dsum, da = ops.linear_add_norm_bwd(dy, s, mean, rstd, gamma, wt, dg, dbeta, pre_g=pre_g, pre_w_t=pre_wt)
+            dsum, da = dsum.view(s.shape), da.view(a.shape)
             g = dsum.view(-1, N)
         else:
+            if pre_g is not None:
+                dy = ops.gemm_nt(pre_g, pre_wt, residual=None if dy is None else dy.view(-1, N)).view(s.shape)
             dsum = ops.layernorm_bwd(dy.contiguous(), s, mean, rstd, gamma, dg, dbeta)     # d(x + o): feeds both branches
             g = dsum.view(-1, N)
             if ctx.needs_input_grad[0]:
@@ -953,7 +985,7 @@ class LinearAddNormFn(Function):
             WGRADS.tn(WGRADS.site((weight, ctx.bias)), g, a.view(-1, K), dw, db)
         elif want_db:
             ops.colsum_acc(g, db)
-        return da, (dsum if ctx.needs_input_grad[1] else None), dw, db, dg, dbeta, None, None, None
+        return da, (dsum if ctx.needs_input_grad[1] else None), dw, db, dg, dbeta, None, dw2, db2
 
 
 def linear_add_norm(a, x, weight, bias, gamma, beta, a_relu=False):
@@ -968,8 +1000,10 @@ def linear_add_norm_then_fits(a, weight, then_weight):
 
 
 def linear_add_norm_then(a, x, weight, bias, gamma, beta, then_weight, then_bias):
-    """(y, y then_weight^T + then_bias) with y = LayerNorm(x + a W^T + b): ONE launch; the second result is a constant
-    for autograd -- hand it to linear_keep(y, then_weight, then_bias, precomputed=...), whose backward needs nothing else."""
+    """(y, y then_weight^T + then_bias) with y = LayerNorm(x + a W^T + b): ONE launch.  With FUSED_LINEAR_PRE the second
+    result is a differentiable output of this node (use it as it is: its gradient returns here and the backward launch
+    forms dq . then_weight itself); without, it is a constant for autograd -- hand it to
+    linear_keep(y, then_weight, then_bias, precomputed=...), whose backward needs nothing else."""
     return LinearAddNormFn.apply(a.contiguous(), x.contiguous(), weight, bias, gamma, beta, False, then_weight, then_bias)
 
 

@@ -80,7 +80,7 @@ SIGNATURES = {
     "fod_conv_stem_fwd": [_i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _EP, _p],
     "fod_stem_pool_fwd": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     "fod_linear_add_norm_fwd": [_i, _p, _l, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _f, _p, _p, _p, _p],
-    "fod_linear_add_norm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
+    "fod_linear_add_norm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _p],
     "fod_clip_to_stem_layout": [_i, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _l, _l, _p, _p, _p],
     "fod_conv2d_wgrad_acc": [_i, _p, _p, _p, _CG, _p, _i, _p, C.c_size_t, _p],
     "fod_bottleneck_fused_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],

@@ -620,18 +620,28 @@ def linear_add_norm_fwd(a, w, bias, x, gamma, beta, eps=1e-5, then_w=None, then_
     return (y, s, mean, rstd) if then_w is None else (y, s, mean, rstd, out2)
 
 
-def linear_add_norm_bwd(dy, xsum, mean, rstd, gamma, w_t, dgamma, dbeta, want_da=True):
+def linear_add_norm_bwd(dy, xsum, mean, rstd, gamma, w_t, dgamma, dbeta, want_da=True, pre_g=None, pre_w_t=None):
     """Backward of linear_add_norm_fwd in one launch: (dsum, da) with dsum = layernorm_bwd(dy, ...) and da = dsum . W
-    (w_t = W^T as [K, N], the operand gemm_nt would take); dgamma / dbeta (f32, accumulated)."""
-    _chk(dy, "dy", torch.bfloat16); _chk(xsum, "xsum", torch.bfloat16); _chk(w_t, "w_t", torch.bfloat16)
+    (w_t = W^T as [K, N], the operand gemm_nt would take); dgamma / dbeta (f32, accumulated).  pre_g [M, N] with
+    pre_w_t [N, N] (= then_w^T): the gradient of the forward launch's then_out; the incoming gradient becomes
+    dy + pre_g . then_w inside the launch (dy may then be None)."""
+    _chk(xsum, "xsum", torch.bfloat16); _chk(w_t, "w_t", torch.bfloat16)
     K, N = w_t.shape
-    M = dy.numel() // N
-    assert xsum.numel() == dy.numel() and mean.numel() == M and rstd.numel() == M and gamma.numel() == N
+    M = xsum.numel() // N
+    if pre_g is not None:
+        _chk(pre_g, "pre_g", torch.bfloat16); _chk(pre_w_t, "pre_w_t", torch.bfloat16)
+        assert pre_g.numel() == M * N and tuple(pre_w_t.shape) == (N, N)
+    else:
+        assert pre_w_t is None and dy is not None
+    if dy is not None:
+        _chk(dy, "dy", torch.bfloat16); assert dy.numel() == xsum.numel()
+    assert mean.numel() == M and rstd.numel() == M and gamma.numel() == N
     _chk(dgamma, "dgamma", torch.float32); _chk(dbeta, "dbeta", torch.float32)
-    dsum = torch.empty_like(dy)
-    da = torch.empty((M, K), dtype=dy.dtype, device=dy.device) if want_da else None
-    call("fod_linear_add_norm_bwd", dt(dy), ptr(dy), ptr(xsum), ptr(mean), ptr(rstd), ptr(gamma), ptr(w_t), ptr(dsum),
-         ptr(da), ptr(dgamma), ptr(dbeta), M, N, K, stream(), work=2.0 * M * N * K if want_da else 0.0, tag="fod_gemm_nt")
+    dsum = torch.empty_like(xsum)
+    da = torch.empty((M, K), dtype=xsum.dtype, device=xsum.device) if want_da else None
+    call("fod_linear_add_norm_bwd", dt(xsum), ptr(dy), ptr(xsum), ptr(mean), ptr(rstd), ptr(gamma), ptr(w_t), ptr(dsum),
+         ptr(da), ptr(dgamma), ptr(dbeta), M, N, K, ptr(pre_g), ptr(pre_w_t), stream(),
+         work=2.0 * M * N * K * ((1 if want_da else 0) + (1 if pre_g is not None else 0)), tag="fod_gemm_nt")
     return dsum, da
 
 

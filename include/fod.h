@@ -312,7 +312,10 @@ int fod_linear_add_norm_fwd(int dtype, const void* a, long lda, const void* w, c
  * x + o; dgamma / dbeta accumulated), and -- when da is not NULL -- da [M, K] = dsum . W, with w_t = W^T as [K][N]. */
 int fod_linear_add_norm_bwd(int dtype, const void* dy, const void* xsum, const float* mean, const float* rstd,
                             const float* gamma, const void* w_t, void* dsum, void* da, float* dgamma, float* dbeta,
-                            int M, int N, int K, fod_stream_t stream);
+                            int M, int N, int K,
+                            /* optional (the forward call had then_*): the gradient of y is dy + pre_g . then_w, with
+                             * pre_g [M, 256] the gradient of then_out and pre_w_t = then_w^T as [256][256]; dy may be NULL */
+                            const void* pre_g, const void* pre_w_t, fod_stream_t stream);
 int fod_layernorm_fwd(int dtype, const void* x, const void* residual, int res_row_div, int res_row_mod,
                       const float* gamma, const float* beta, void* y, void* sum_out, float* mean,
                       float* rstd, int rows, int D, float eps, fod_stream_t stream);

@@ -305,23 +305,62 @@ def test_fused_linear_add_norm_then_next_projection(M):
     lin, lin2, ln = torch.nn.Linear(256, 256).to(DEV), torch.nn.Linear(256, 256).to(DEV), torch.nn.LayerNorm(256).to(DEV)
     gy, gq = rnd((M, 256), dtype, 65).to(DEV), rnd((M, 256), dtype, 66).to(DEV)
     grads = []
-    for fused in (True, False):
-        for prm in list(lin.parameters()) + list(lin2.parameters()) + list(ln.parameters()):
-            prm.grad = None
-        Fn.PREP.clear()
-        aa, xx = a.clone().requires_grad_(True), x.clone().requires_grad_(True)
-        if fused:
-            assert Fn.linear_add_norm_then_fits(aa, lin.weight, lin2.weight)
-            yy, pre = Fn.linear_add_norm_then(aa, xx, lin.weight, lin.bias, ln.weight, ln.bias, lin2.weight, lin2.bias)
-            keep, qq = Fn.linear_keep(yy, lin2.weight, lin2.bias, precomputed=pre)
-        else:
-            yy = Fn.linear_add_norm(aa, xx, lin.weight, lin.bias, ln.weight, ln.bias)
-            keep, qq = Fn.linear_keep(yy, lin2.weight, lin2.bias)
-        ((keep.float() * gy.float()).sum() + (qq.float() * gq.float()).sum()).backward()
-        grads.append([aa.grad, xx.grad] + [prm.grad.clone() for prm in list(lin.parameters()) + list(lin2.parameters()) + list(ln.parameters())])
-    for g1, g2 in zip(*grads):
-        err = float((g1.double() - g2.double()).norm() / g2.double().norm().clamp_min(1e-9))
-        assert err <= 1e-2, err
+    pre_was = Fn.FUSED_LINEAR_PRE
+    try:
+        for fused in ("pre", "then", None):
+            for prm in list(lin.parameters()) + list(lin2.parameters()) + list(ln.parameters()):
+                prm.grad = None
+            Fn.PREP.clear()
+            Fn.FUSED_LINEAR_PRE = fused == "pre"
+            aa, xx = a.clone().requires_grad_(True), x.clone().requires_grad_(True)
+            if fused == "pre":
+                # the projection's result is a differentiable output of the fused node; its input gradient is formed
+                # inside fod_linear_add_norm_bwd (pre_*)
+                keep, qq = Fn.linear_add_norm_then(aa, xx, lin.weight, lin.bias, ln.weight, ln.bias, lin2.weight, lin2.bias)
+            elif fused == "then":
+                assert Fn.linear_add_norm_then_fits(aa, lin.weight, lin2.weight)
+                yy, pre = Fn.linear_add_norm_then(aa, xx, lin.weight, lin.bias, ln.weight, ln.bias, lin2.weight, lin2.bias)
+                keep, qq = Fn.linear_keep(yy, lin2.weight, lin2.bias, precomputed=pre)
+            else:
+                yy = Fn.linear_add_norm(aa, xx, lin.weight, lin.bias, ln.weight, ln.bias)
+                keep, qq = Fn.linear_keep(yy, lin2.weight, lin2.bias)
+            ((keep.float() * gy.float()).sum() + (qq.float() * gq.float()).sum()).backward()
+            grads.append([aa.grad, xx.grad] + [prm.grad.clone() for prm in list(lin.parameters()) + list(lin2.parameters()) + list(ln.parameters())])
+    finally:
+        Fn.FUSED_LINEAR_PRE = pre_was
+    for other in grads[:2]:
+        for g1, g2 in zip(other, grads[2]):
+            err = float((g1.double() - g2.double()).norm() / g2.double().norm().clamp_min(1e-9))
+            assert err <= 1e-2, err
+
+
+@pytest.mark.parametrize("M", [256, 100, 16, 1, 515])
+@pytest.mark.parametrize("with_dy", [True, False])
+def test_fused_linear_add_norm_backward_pre(M, with_dy):
+    """fod_linear_add_norm_bwd(pre_*): the incoming gradient dy + pre_g . then_w formed inside the launch equals
+    fod_gemm_nt(pre_g, then_w^T, residual=dy) handed to the launch without pre_* -- the same bf16 rounding of the total, so
+    dsum / da agree within one bf16 ulp of their range (MFMA summation order) and dgamma / dbeta to f32 noise."""
+    dtype = torch.bfloat16
+    dy = rnd((M, 256), dtype, 71).to(DEV) if with_dy else None
+    gq = rnd((M, 256), dtype, 72).to(DEV)
+    s = rnd((M, 256), dtype, 73).to(DEV)
+    gamma = (torch.rand(256) + 0.5).to(DEV)
+    mean = s.float().mean(-1).contiguous()
+    rstd = (s.float().var(-1, unbiased=False) + 1e-5).rsqrt().contiguous()
+    wt = rnd((256, 256), dtype, 74, scale=1.0 / 16).to(DEV)                 # W^T as [K, N]
+    w2t = rnd((256, 256), dtype, 75, scale=1.0 / 16).to(DEV)                # then_w^T as [N, N]
+    dg1, db1 = torch.zeros(256, device=DEV), torch.zeros(256, device=DEV)
+    dg2, db2 = torch.zeros(256, device=DEV), torch.zeros(256, device=DEV)
+    dsum, da = ops.linear_add_norm_bwd(dy, s, mean, rstd, gamma, wt, dg1, db1, pre_g=gq, pre_w_t=w2t)
+    total = ops.gemm_nt(gq, w2t, residual=dy)
+    dsum2, da2 = ops.linear_add_norm_bwd(total, s, mean, rstd, gamma, wt, dg2, db2)
+    ref = gq.double() @ w2t.double().t() + (dy.double() if with_dy else 0)
+    assert float((total.double() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+    tol = 2.0 ** -6
+    assert float((dsum.float() - dsum2.float()).abs().max()) <= tol * float(dsum2.float().abs().max())
+    assert float((da.float() - da2.float()).abs().max()) <= tol * max(float(da2.float().abs().max()), 1e-3)
+    assert torch.allclose(dg1, dg2, rtol=1e-2, atol=2e-2 * float(dg2.abs().max()))
+    assert torch.allclose(db1, db2, rtol=1e-2, atol=2e-2 * float(db2.abs().max()))
 
 
 @pytest.mark.parametrize("M", [256, 100, 16, 1, 515, 14500])
