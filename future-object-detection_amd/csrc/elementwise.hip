@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
                                                      int rdiv, int rmod, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      T* __restrict__ sum_out, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, int rows, float eps) {
+                                                     float* __restrict__ rstd, int rows, float eps,
+                                                     int group_rows) {
   constexpr int EPL = D / LPR, RPW = 64 / LPR;      // channels per lane, rows per wave
   const int lane = threadIdx.x & 63;
   const int sub = lane % LPR, rsel = lane / LPR;
@@ -65,6 +66,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
     const long row = base + rsel;
     const bool live = row < rows;
     const long r = live ? row : rows - 1;             // idle lane groups shadow the last row, nothing is stored
+    if (group_rows > 0) {
+      // grouped form: rows [g * group_rows, (g + 1) * group_rows) are normalised with the g-th (gamma, beta) pair of a
+      // [groups, D] table (the same sub-layer of several transformer layers in one launch)
+      const long goff = (r / group_rows) * D + c0;
+      __builtin_memcpy(ga, __builtin_assume_aligned(gamma + goff, SliceAlign<float, EPL>::VALUE), EPL * sizeof(float));
+      __builtin_memcpy(be, __builtin_assume_aligned(beta + goff, SliceAlign<float, EPL>::VALUE), EPL * sizeof(float));
+    }
     float v[EPL];
     ln_load<T, EPL>(v, x + r * D + c0);
     if (res) {
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, T* __restrict__ dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     int rows) {
+                                                     int rows, int group_rows) {
   constexpr int EPL = D / LPR, RPW = 64 / LPR;
   __shared__ float sg[4][D];
   __shared__ float sb[4][D];
@@ -122,6 +130,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   float ag[EPL], ab[EPL];
 #pragma unroll
   for (int i = 0; i < EPL; ++i) ag[i] = ab[i] = 0.f;
+  if (group_rows > 0) {
+    // grouped form ([groups, D] parameter tables, see ln_fwd_kernel; LPR = 64, one row per wave, the grid covers the rows
+    // in one pass -- host-checked): the wave's row adds its terms to its group's dgamma / dbeta rows itself
+    const long row = (long)blockIdx.x * 4 + w;
+    if (row >= rows) return;
+    const long goff = (row / group_rows) * D + c0;
+    __builtin_memcpy(ga, __builtin_assume_aligned(gamma + goff, SliceAlign<float, EPL>::VALUE), EPL * sizeof(float));
+    const float mu = mean[row], rs = rstd[row];
+    float d[EPL], g[EPL], xh[EPL];
+    ln_load<T, EPL>(d, dy + row * D + c0);
+    ln_load<T, EPL>(xh, xs + row * D + c0);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      xh[i] = (xh[i] - mu) * rs;
+      g[i] = d[i] * ga[i];
+      s1 += g[i];
+      s2 += g[i] * xh[i];
+    }
+    s1 = row_sum<LPR>(s1) * (1.f / D);
+    s2 = row_sum<LPR>(s2) * (1.f / D);
+    float o[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) o[i] = rs * (g[i] - s1 - xh[i] * s2);
+    ln_store<T, EPL>(dx + row * D + c0, o);
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) {
+      atomicAdd(dgamma + goff + i, d[i] * xh[i]);
+      atomicAdd(dbeta + goff + i, d[i]);
+    }
+    return;
+  }
   for (long base = (long)blockIdx.x * (4 * RPW) + w * RPW; base < rows; base += (long)gridDim.x * (4 * RPW)) {
     const long row = base + rsel;
     const bool live = row < rows;
@@ -715,8 +755,9 @@ inline int grid_for(long n, int per_block = 256) {
 
 extern "C" int fod_layernorm_fwd(int dtype, const void* x, const void* residual, int res_row_div, int res_row_mod,
                                  const float* gamma, const float* beta, void* y, void* sum_out, float* mean,
-                                 float* rstd, int rows, int D, float eps, hipStream_t stream) {
+                                 float* rstd, int rows, int D, float eps, int group_rows, hipStream_t stream) {
   FOD_REQUIRE(x && gamma && beta && y && mean && rstd && rows > 0, "layernorm_fwd: bad args");
+  FOD_REQUIRE(group_rows >= 0 && (group_rows == 0 || rows % group_rows == 0), "layernorm_fwd: %d rows in groups of %d", rows, group_rows);
   FOD_REQUIRE(D % 64 == 0 && D >= 64 && D <= 512, "layernorm_fwd: D=%d must be a multiple of 64, <= 512", D);
   FOD_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)residual % 16) == 0 &&
               ((uintptr_t)sum_out % 16) == 0 && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0,
@@ -728,11 +769,11 @@ extern "C" int fod_layernorm_fwd(int dtype, const void* x, const void* residual,
     if (rows < 8192) {                                                                                        \
       hipLaunchKernelGGL((ln_fwd_kernel<T, DD, 64>), dim3(grid_for(rows, 4)), dim3(256), 0, stream,           \
                          (const T*)x, (const T*)residual, res_row_div, res_row_mod, gamma, beta, (T*)y,       \
-                         (T*)sum_out, mean, rstd, rows, eps);                                                 \
+                         (T*)sum_out, mean, rstd, rows, eps, group_rows);                                     \
     } else {                                                                                                  \
       hipLaunchKernelGGL((ln_fwd_kernel<T, DD, LPR>), dim3(grid_for(rows, 4 * (64 / LPR))), dim3(256), 0,     \
                          stream, (const T*)x, (const T*)residual, res_row_div, res_row_mod, gamma, beta,      \
-                         (T*)y, (T*)sum_out, mean, rstd, rows, eps);                                          \
+                         (T*)y, (T*)sum_out, mean, rstd, rows, eps, group_rows);                              \
     }                                                                                                         \
   } while (0)
   FOD_DISPATCH_T(dtype, "layernorm_fwd", switch (D / 64) {
@@ -745,8 +786,10 @@ extern "C" int fod_layernorm_fwd(int dtype, const void* x, const void* residual,
 
 extern "C" int fod_layernorm_bwd(int dtype, const void* dy, const void* xsum, const float* mean, const float* rstd,
                                  const float* gamma, void* dx, float* dgamma, float* dbeta, int rows, int D,
-                                 hipStream_t stream) {
+                                 int group_rows, hipStream_t stream) {
   FOD_REQUIRE(dy && xsum && mean && rstd && gamma && dx && dgamma && dbeta && rows > 0, "layernorm_bwd: bad args");
+  FOD_REQUIRE(group_rows >= 0 && (group_rows == 0 || (rows % group_rows == 0 && rows <= 4096)),
+              "layernorm_bwd: %d rows in groups of %d (grouped form: at most 4096 rows)", rows, group_rows);
   FOD_REQUIRE(D % 64 == 0 && D >= 64 && D <= 512, "layernorm_bwd: D=%d must be a multiple of 64, <= 512", D);
   FOD_REQUIRE(((uintptr_t)dy % 16) == 0 && ((uintptr_t)xsum % 16) == 0 && ((uintptr_t)dx % 16) == 0 &&
               ((uintptr_t)gamma % 16) == 0, "layernorm_bwd: operands must be 16-byte aligned");
@@ -756,13 +799,14 @@ extern "C" int fod_layernorm_bwd(int dtype, const void* dy, const void* xsum, co
     if (rows < 8192) {                                                                                        \
       int grid = grid_for(rows, 16);                                                                          \
       if (grid > 512) grid = 512;                                                                             \
+      if (group_rows > 0) grid = (rows + 3) / 4;        /* one row per wave, one pass */                      \
       hipLaunchKernelGGL((ln_bwd_kernel<T, DD, 64>), dim3(grid), dim3(256), 0, stream, (const T*)dy,          \
-                         (const T*)xsum, mean, rstd, gamma, (T*)dx, dgamma, dbeta, rows);                     \
+                         (const T*)xsum, mean, rstd, gamma, (T*)dx, dgamma, dbeta, rows, group_rows);         \
     } else {                                                                                                  \
       int grid = grid_for(rows, 4 * (64 / LPR) * 4);    /* ~4 row groups per wave: fewer atomics on dgamma */  \
       if (grid > 512) grid = 512;                                                                             \
       hipLaunchKernelGGL((ln_bwd_kernel<T, DD, LPR>), dim3(grid), dim3(256), 0, stream, (const T*)dy,         \
-                         (const T*)xsum, mean, rstd, gamma, (T*)dx, dgamma, dbeta, rows);                     \
+                         (const T*)xsum, mean, rstd, gamma, (T*)dx, dgamma, dbeta, rows, 0);                  \
     }                                                                                                         \
   } while (0)
   FOD_DISPATCH_T(dtype, "layernorm_bwd", switch (D / 64) {

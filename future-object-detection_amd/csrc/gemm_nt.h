@@ -38,6 +38,10 @@ struct NtParams {
   int ksplit;
   float* split_ws;
   unsigned* split_tickets;
+  // short-launch kernel, batched form (fod_gemm_nt_batched): `batches` independent problems of one shape in one launch;
+  // blockIdx.y = batch * m-tiles + m-tile; operand b of batch z starts *_batch elements after that of batch z - 1
+  int batches;
+  long a_batch, b_batch, c_batch, shift_batch, res_batch, mask_batch;
   // gather geometry
   int Hs, Ws, Cs;   // source image dims / channels
   int Hd, Wd;       // m-domain dims

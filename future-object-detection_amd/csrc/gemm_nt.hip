@@ -523,11 +523,24 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const NtParams p) {
   __shared__ __attribute__((aligned(16))) float sC[4][64][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 31, fh = lane >> 5;
-  const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+  // batched form: blockIdx.y = batch * m-tiles + m-tile, every operand of batch z a fixed stride further
+  int by = blockIdx.y;
+  long bz = 0;
+  if (p.batches > 1) {
+    const int mt = (p.M + 63) >> 6;
+    bz = by / mt;
+    by -= (int)bz * mt;
+  }
+  const int n0 = blockIdx.x * 64, m0 = by * 64;
   FOD_STAMP(0);
   constexpr unsigned OOB = 0xFFFFFFF0u;
-  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
-  const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, p.b_bytes, 0x00020000);
+  const T* pA = reinterpret_cast<const T*>(p.A) + bz * p.a_batch;
+  const T* pB = reinterpret_cast<const T*>(p.B) + bz * p.b_batch;
+  const float* pShift = p.shift ? p.shift + bz * p.shift_batch : nullptr;
+  const T* pRes = p.res ? reinterpret_cast<const T*>(p.res) + bz * p.res_batch : nullptr;
+  const T* pMask = p.mask ? reinterpret_cast<const T*>(p.mask) + bz * p.mask_batch : nullptr;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(pA), 0, p.a_bytes, 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(pB), 0, p.b_bytes, 0x00020000);
   auto bload = [](const auto& rs, unsigned off) {
     const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
     Frag<T> f;
@@ -541,9 +554,9 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const NtParams p) {
   const bool n_ok = n < p.N;
   const int M1 = p.M - 1;
   const auto rsScale = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.scale), 0, p.scale ? p.N * 4 : 0, 0x00020000);
-  const auto rsShift = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.shift), 0, p.shift ? p.N * 4 : 0, 0x00020000);
-  const auto rsRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, p.res ? 0x7FFFFFF0 : 0, 0x00020000);
-  const auto rsMask = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.mask), 0, p.mask ? 0x7FFFFFF0 : 0, 0x00020000);
+  const auto rsShift = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pShift), 0, p.shift ? p.N * 4 : 0, 0x00020000);
+  const auto rsRes = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(pRes), 0, p.res ? 0x7FFFFFF0 : 0, 0x00020000);
+  const auto rsMask = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(pMask), 0, p.mask ? 0x7FFFFFF0 : 0, 0x00020000);
   f32x4 sc, sh;
   {
     const auto a = __builtin_amdgcn_raw_buffer_load_b128(rsScale, n_ok ? n * 4 : (int)OOB, 0, 0);
@@ -643,11 +656,11 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const NtParams p) {
   __syncthreads();
   FOD_STAMP(3);
   const bool has_scale = p.scale != nullptr, has_mask = p.mask != nullptr;
-  long c_base = 0;             // segmented C: this block's columns lie in one segment (c_seg_cols % 64 == 0)
+  long c_base = bz * p.c_batch; // segmented C: this block's columns lie in one segment (c_seg_cols % 64 == 0)
   int n_c = n;
   if (p.c_seg_cols > 0) {
     const int cseg = n0 / p.c_seg_cols;
-    c_base = (long)cseg * p.c_seg_stride;
+    c_base += (long)cseg * p.c_seg_stride;
     n_c = n - cseg * p.c_seg_cols;
   }
   f32x4 vsum[4];
@@ -890,6 +903,44 @@ extern "C" int fod_gemm_nt_grouped(int dtype, const void* A, long lda, int a_seg
   p.a_bytes = (unsigned)ab;
   p.b_bytes = (unsigned)bb;
   hipLaunchKernelGGL(gemm_nt_small_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, stream, p);
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
+}
+
+extern "C" int fod_gemm_nt_batched(int dtype, int batches, const void* A, long lda, long a_batch, const void* B, long ldb,
+                                   long b_batch, void* C, long ldc, long c_batch, int M, int N, int K,
+                                   const fod_epilogue* epi, long shift_batch, long residual_batch, long mask_batch,
+                                   hipStream_t stream) {
+  FOD_REQUIRE(dtype == FOD_BF16, "gemm_nt_batched: bf16 only (dtype %d)", dtype);
+  FOD_REQUIRE(A && B && C && batches > 0, "gemm_nt_batched: null operand / no batch");
+  FOD_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt_batched: empty problem %d %d %d", M, N, K);
+  FOD_REQUIRE(K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "gemm_nt_batched: K=%d lda=%ld ldb=%ld must be multiples of 8",
+              K, lda, ldb);
+  FOD_REQUIRE(a_batch % 8 == 0 && b_batch % 8 == 0 && c_batch % 8 == 0 && shift_batch % 4 == 0 && residual_batch % 8 == 0 &&
+                  mask_batch % 8 == 0,
+              "gemm_nt_batched: batch strides must keep every operand 16-byte aligned");
+  FOD_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0, "gemm_nt_batched: operands must be 16-byte aligned");
+  NtParams p{};
+  p.A = A; p.B = B; p.C = C;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K;
+  fill_epilogue(p, epi);
+  p.split_ws = nullptr; p.split_tickets = nullptr;          // (blockIdx.z is not a K split here)
+  decide_vec_epilogue(p);
+  FOD_REQUIRE(p.vec_epi, "gemm_nt_batched: N, ldc and the epilogue operands must be 4-element / 16-byte aligned");
+  FOD_REQUIRE(!p.res || p.res_row_mod == 0, "gemm_nt_batched: no periodic residual");
+  FOD_REQUIRE(!p.res || ((long)M * p.ldr + N) * 2 < 0x7FFFFFF0L, "gemm_nt_batched: residual larger than 2 GiB");
+  FOD_REQUIRE(!p.mask || ((long)M * p.ldmask + N) * 2 < 0x7FFFFFF0L, "gemm_nt_batched: mask larger than 2 GiB");
+  const long ab = ((long)(M - 1) * lda + K) * 2, bb = ((long)(N - 1) * ldb + K) * 2;
+  FOD_REQUIRE(ab < 0xFFFFFFF0L - 16 && bb < 0xFFFFFFF0L - 16, "gemm_nt_batched: operand larger than 4 GiB");
+  p.a_bytes = (unsigned)ab;
+  p.b_bytes = (unsigned)bb;
+  const long gy = (long)ceil_div(M, 64) * batches;
+  FOD_REQUIRE(gy <= 65535, "gemm_nt_batched: %ld row tiles x batches exceed the grid", gy);
+  p.batches = batches;
+  p.a_batch = a_batch; p.b_batch = b_batch; p.c_batch = c_batch;
+  p.shift_batch = shift_batch; p.res_batch = residual_batch; p.mask_batch = mask_batch;
+  hipLaunchKernelGGL(gemm_nt_small_kernel, dim3(ceil_div(N, 64), (unsigned)gy), dim3(256), 0, stream, p);
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }

@@ -463,9 +463,11 @@ class TransformerEncoderLayer(nn.Module):
         else:
             self.egodeep_attend = None
 
-    def forward(self, x, pos, egodeep: Optional[Tensor] = None, prevout: Optional[Tensor] = None, memory=None):
+    def forward(self, x, pos, egodeep: Optional[Tensor] = None, prevout: Optional[Tensor] = None, memory=None,
+                imu_pre: Optional[Tensor] = None):
         """x [F,N,D]; pos table [N,D] or [F,N,D]; egodeep [F,D] (one IMU token per frame), [F,S,D] (S tokens) or
-        None; prevout [F,N,D] or None; memory: list of [F,N,D] (most recent first) or None."""
+        None; prevout [F,N,D] or None; memory: list of [F,N,D] (most recent first) or None.  `imu_pre` [F,D]: this
+        layer's one-key IMU block as TransformerEncoder computed it for all layers at once."""
         x = self.self_attn(x, pos)
         if prevout is not None and self.prevout_attn is not None:
             x = self.prevout_attn(x, pos, other=prevout)
@@ -480,7 +482,7 @@ class TransformerEncoderLayer(nn.Module):
             x = Fn.layer_norm(x, self.norm_eda.weight, self.norm_eda.bias, residual=e)
         elif egodeep is not None and self.egodeep_attend is not None:
             N = x.shape[1]
-            e = self.egodeep_attend.forward_single_key(egodeep)
+            e = imu_pre if imu_pre is not None else self.egodeep_attend.forward_single_key(egodeep)
             e = Fn.dropout(e, self.egodeep_attend.droprate, self.training)          # dropout_eda (reference :444,485)
             x = Fn.layer_norm(x, self.norm_eda.weight, self.norm_eda.bias, residual=e, res_row_div=N)
             if torch.is_grad_enabled():
@@ -495,6 +497,16 @@ class TransformerEncoder(nn.Module):
         _reset_parameters(self.parameters())
 
     def forward(self, x, pos, egodeep: Optional[Tensor] = None, prevout: Optional[Tensor] = None, memory=None):
-        for layer in self.layers:
-            x = layer(x, pos, egodeep, prevout, memory)
+        # one IMU token per frame: every layer's IMU block reads only that token (softmax over one key is 1), so the
+        # blocks of all layers are computed here at once -- a handful of launches instead of 6 per layer (Fn.ImuBranchFn)
+        pre = None
+        blocks = [getattr(layer, "egodeep_attend", None) for layer in self.layers]
+        if (egodeep is not None and egodeep.dim() == 2 and all(b is not None for b in blocks)
+                and not any(b.training and b.droprate > 0.0 for b in blocks) and Fn.imu_branch_fits(egodeep, blocks)):
+            pre = Fn.imu_branch(egodeep, blocks)
+        for i, layer in enumerate(self.layers):
+            if pre is not None:
+                x = layer(x, pos, egodeep, prevout, memory, imu_pre=pre[i])
+            else:
+                x = layer(x, pos, egodeep, prevout, memory)
         return x

@@ -1589,6 +1589,167 @@ def group_linear(x, linears):
     return list(GroupLinearFn.apply(x.contiguous(), *[m.weight for m in linears], *[m.bias for m in linears]))
 
 
+class _StackCache:
+    """P same-length f32 vectors (the LayerNorm weights / biases of P layers) as one [P, D] table, refreshed with the
+    other prepared operands."""
+
+    def get(self, vecs):
+        def build():
+            D = vecs[0].numel()
+            table = torch.empty((len(vecs), D), dtype=torch.float32, device=vecs[0].device)
+            jobs = []
+            for i, v in enumerate(vecs):
+                vd = v.detach()
+                jobs.append(_Job(vd, table[i], (1, 1, D), (0, 0, vd.stride(0))))
+            return (table,), jobs
+
+        key = (tuple(v.data_ptr() for v in vecs), torch.float32, "stack")
+        return PREP.get(key, list(vecs), build)[0]
+
+
+STACK = _StackCache()
+
+# "0": every encoder layer computes its IMU-token block itself (4 GEMMs + 2 norms on [frames, D] rows per layer)
+IMU_BATCHED = os.environ.get("FOD_IMU_BATCHED", "1") != "0"
+
+
+class ImuBranchFn(Function):
+    """The one-key IMU-token blocks of P transformer layers at once (EgodeepAttention.forward_single_key of every layer;
+    reference transformer.py:108-119 with one key per frame, where softmax = 1 and the block reduces to
+    value -> out_proj [-> norm1(o + o) -> MLP -> norm2]).  The blocks read only the IMU embedding `ego` [frames, D] -- not
+    the layer's tokens -- so the P of them are independent: every step of the chain runs for all layers in ONE launch
+    (fod_gemm_nt_grouped for the shared input, fod_gemm_nt_batched after it, the norms with per-layer parameter tables).
+    Per layer that was 4 GEMMs + 2 norms forward and 4 + 2 + 2 backward on ~10 rows, each a ~5-9 us graph node.
+
+    apply(ego, P, use_mlp, *params) with params = P value weights, P value biases, P out_proj weights, P biases and, with
+    use_mlp, norm1 weights, biases, mlp[0] weights, biases, mlp[3] weights, biases, norm2 weights, biases (P each)
+    -> P tensors [frames, D] (blocks of one buffer)."""
+
+    @staticmethod
+    def forward(ctx, ego, P, use_mlp, *params):
+        groups = [params[i * P:(i + 1) * P] for i in range(len(params) // P)]
+        wv, bv, wo, bo = groups[:4]
+        M, D = ego.shape
+        dtype = ego.dtype
+        t = ops.group_linear_fwd(ego, *CAT.get(wv, bv, dtype)[:2], P)                       # [P, M, D]
+        wo_cat, bo_cat, _ = CAT.get(wo, bo, dtype)
+        o = ops.gemm_nt_batched(t, wo_cat, shift=bo_cat)
+        saved = [ego, t]
+        if use_mlp:
+            g1, b1, w0, b0, w3, b3, g2, b2 = groups[4:]
+            o2 = o.view(P * M, D)
+            n1, s1, mean1, rstd1 = ops.layernorm_fwd(o2, STACK.get(g1), STACK.get(b1), residual=o2, group_rows=M)
+            w0_cat, b0_cat, _ = CAT.get(w0, b0, dtype)
+            h = ops.gemm_nt_batched(n1.view(P, M, D), w0_cat, shift=b0_cat, relu=True)      # [P, M, Dff]
+            w3_cat, b3_cat, _ = CAT.get(w3, b3, dtype)
+            y = ops.gemm_nt_batched(h, w3_cat, shift=b3_cat)
+            e, s2, mean2, rstd2 = ops.layernorm_fwd(n1, STACK.get(g2), STACK.get(b2), residual=y.view(P * M, D),
+                                                    group_rows=M)
+            saved += [s1, mean1, rstd1, n1, h, s2, mean2, rstd2]
+            e = e.view(P, M, D)
+        else:
+            e = o
+        ctx.save_for_backward(*saved)
+        ctx.P, ctx.use_mlp, ctx.params = P, use_mlp, params
+        return tuple(e[p] for p in range(P))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        P, use_mlp, params = ctx.P, ctx.use_mlp, ctx.params
+        groups = [params[i * P:(i + 1) * P] for i in range(len(params) // P)]
+        wv, bv, wo, bo = groups[:4]
+        saved = ctx.saved_tensors
+        ego, t = saved[:2]
+        M, D = ego.shape
+        dtype, dev = ego.dtype, ego.device
+        de = _as_segments(gs, M, D)
+        if de is None or de.dtype != dtype:
+            de = torch.empty((P, M, D), dtype=dtype, device=dev)
+            dsts, srcs = [], []
+            for p_, gp in enumerate(gs):
+                if gp is None:
+                    de[p_].zero_()
+                else:
+                    dsts.append(de[p_])
+                    srcs.append(gp.reshape(M, D))
+            if all(s_.dtype == dtype and s_.is_contiguous() for s_ in srcs):
+                torch._foreach_copy_(dsts, srcs)
+            else:
+                for d_, s_ in zip(dsts, srcs):
+                    d_.copy_(s_)
+
+        def wgrads(ws, bs, g, x):
+            """queued weight / bias gradients of P layers with their own inputs: g [P, M, N], x [P, M, K]"""
+            N, K = ws[0].shape
+            dw, db = zeros_f32((P * N, K), dev), zeros_f32((P * N,), dev)
+            for p_ in range(P):
+                WGRADS.tn(WGRADS.site((ws[p_], bs[p_])), g[p_], x[p_], dw[p_ * N:(p_ + 1) * N], db[p_ * N:(p_ + 1) * N])
+            return [dw[p_ * N:(p_ + 1) * N] for p_ in range(P)], [db[p_ * N:(p_ + 1) * N] for p_ in range(P)]
+
+        extra = []
+        if use_mlp:
+            g1, b1, w0, b0, w3, b3, g2, b2 = groups[4:]
+            s1, mean1, rstd1, n1, h, s2, mean2, rstd2 = saved[2:]
+            Dff = w0[0].shape[0]
+            dg2, db2 = zeros_f32((P * D,), dev), zeros_f32((P * D,), dev)
+            ds2 = ops.layernorm_bwd(de.view(P * M, D), s2, mean2, rstd2, STACK.get(g2), dg2, db2, group_rows=M)
+            ds2 = ds2.view(P, M, D)                          # gradient of n1 + mlp(n1): the MLP output's and n1's residual share
+            # the ReLU's gate rides in the epilogue of the GEMM that forms the hidden gradient
+            dh = ops.gemm_nt_batched(ds2, CAT.get(w3, b3, dtype)[2], b_cols=True, relu_mask=h)          # [P, M, Dff]
+            dw3, db3 = wgrads(w3, b3, ds2, h)
+            dn1 = ops.gemm_nt_batched(dh, CAT.get(w0, b0, dtype)[2], b_cols=True, residual=ds2)         # + the residual path
+            dw0, db0 = wgrads(w0, b0, dh, n1.view(P, M, D))
+            dg1, db1 = zeros_f32((P * D,), dev), zeros_f32((P * D,), dev)
+            ds1 = ops.layernorm_bwd(dn1.view(P * M, D), s1, mean1, rstd1, STACK.get(g1), dg1, db1, group_rows=M)
+            do = ops.eltwise(L.EW_SCALE, ds1, alpha=2.0).view(P, M, D)       # norm1(o + o): o enters twice
+            sl = lambda v: [v[p_ * D:(p_ + 1) * D] for p_ in range(P)]
+            extra = sl(dg1) + sl(db1) + dw0 + db0 + dw3 + db3 + sl(dg2) + sl(db2)
+        else:
+            do = de
+        dt_ = ops.gemm_nt_batched(do, CAT.get(wo, bo, dtype)[2], b_cols=True)                           # [P, M, D]
+        dwo, dbo = wgrads(wo, bo, do, t)
+        dego = ops.group_linear_dgrad(dt_, CAT.get(wv, bv, dtype)[2], P) if ctx.needs_input_grad[0] else None
+        dwv, dbv = zeros_f32((P * D, D), dev), zeros_f32((P * D,), dev)
+        WGRADS.grouped(WGRADS.site(tuple(wv) + tuple(bv)), dt_, ego, dwv, dbv)
+        sl = lambda v: [v[p_ * D:(p_ + 1) * D] for p_ in range(P)]
+        return (dego, None, None) + tuple(sl(dwv) + sl(dbv) + dwo + dbo + extra)
+
+
+def imu_branch_fits(ego, blocks):
+    """Whether the one-key IMU blocks `blocks` (EgodeepAttention-like holders) can run as ImuBranchFn: bf16, >= 2 same-shaped
+    blocks with biases, widths inside the short-launch kernel's vector epilogue."""
+    if not IMU_BATCHED or len(blocks) < 2 or ego.dim() != 2 or ego.dtype != torch.bfloat16:
+        return False
+    D = ego.shape[1]
+    b0 = blocks[0]
+    for b in blocks:
+        if b.use_mlp != b0.use_mlp:
+            return False
+        lins = [b.value, b.fun.out_proj] + ([b.mlp[0], b.mlp[3]] if b.use_mlp else [])
+        if any(m.bias is None for m in lins):
+            return False
+        if tuple(b.value.weight.shape) != (D, D) or tuple(b.fun.out_proj.weight.shape) != (D, D):
+            return False
+        if b.use_mlp and (tuple(b.mlp[0].weight.shape) != tuple(b0.mlp[0].weight.shape)
+                          or tuple(b.mlp[3].weight.shape) != (D, b0.mlp[0].weight.shape[0])):
+            return False
+    return D % 64 == 0 and (not b0.use_mlp or b0.mlp[0].weight.shape[0] % 64 == 0)
+
+
+def imu_branch(ego, blocks):
+    """[block.forward_single_key(ego) without dropout for block in blocks] in a handful of launches (ImuBranchFn)."""
+    P = len(blocks)
+    use_mlp = blocks[0].use_mlp
+    params = ([b.value.weight for b in blocks] + [b.value.bias for b in blocks]
+              + [b.fun.out_proj.weight for b in blocks] + [b.fun.out_proj.bias for b in blocks])
+    if use_mlp:
+        params += ([b.norm1.weight for b in blocks] + [b.norm1.bias for b in blocks]
+                   + [b.mlp[0].weight for b in blocks] + [b.mlp[0].bias for b in blocks]
+                   + [b.mlp[3].weight for b in blocks] + [b.mlp[3].bias for b in blocks]
+                   + [b.norm2.weight for b in blocks] + [b.norm2.bias for b in blocks])
+    return list(ImuBranchFn.apply(ego.contiguous(), P, use_mlp, *params))
+
+
 def _sum_leading(t, n):
     """[n, ...] -> [...] : sum over the (tiny) leading dim."""
     acc = t[0]

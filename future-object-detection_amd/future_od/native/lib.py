@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "lib", "libfod_hip.so"))
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 F32, BF16 = 0, 1
 EW_ADD, EW_MUL, EW_RELU_MASK, EW_SCALE, EW_ADD3, EW_RELU, EW_COPY_B = range(7)
@@ -70,6 +70,7 @@ SIGNATURES = {
     "fod_gemm_nt": [_i, _p, _l, _i, _p, _l, _p, _l, _i, _i, _i, _EP, _p],
     "fod_gemm_tn_acc": [_i, _p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p, C.c_size_t, _p],
     "fod_gemm_nt_grouped": [_i, _p, _l, _i, _l, _p, _l, _p, _l, _i, _l, _i, _i, _i, _EP, _p],
+    "fod_gemm_nt_batched": [_i, _i, _p, _l, _l, _p, _l, _l, _p, _l, _l, _i, _i, _i, _EP, _l, _l, _l, _p],
     "fod_gemm_tn_grouped": [_i, _p, _l, _i, _l, _p, _l, _p, _l, _i, _i, _i, _p, _i, _p],
     "fod_gemm_tn_multi": [_p, _p, _p, _i, _p],
     "fod_gemm_tn_multi_long": [_p, _p, _p, _i, _p],
@@ -97,8 +98,8 @@ SIGNATURES = {
     "fod_attn_fp8_pack_bytes": [_AS, _i, _p, _p],
     "fod_attn_quant_fp8": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _AS, _p],
     "fod_attn_fwd_fp8": [_p, _p, _i, _p, _p, _AS, _p],
-    "fod_layernorm_fwd": [_i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p],
-    "fod_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
+    "fod_layernorm_fwd": [_i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p],
+    "fod_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     "fod_eltwise": [_i, _i, _p, _p, _p, _p, _l, _i, _i, _i, _f, _p],
     "fod_posenc_table": [_i, _p, _i, _i, _i, _f, _p],
     "fod_posenc_temporal": [_i, _p, _p, _i, _i, _i, _f, _f, _p],

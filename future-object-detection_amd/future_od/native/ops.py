@@ -148,6 +148,32 @@ def gemm_nt(a, b, *, a_row_mod=0, m_rows=None, scale=None, shift=None, residual=
     return out
 
 
+def gemm_nt_batched(a, b, *, b_cols=False, shift=None, residual=None, relu=False, relu_mask=None):
+    """C[z] = epi(A[z] . B[z]^T) for z < P in ONE launch of the short-launch kernel: a [P, M, K]; b [P*N, K] (B[z] = rows
+    z N .. of it: P stacked weights) or, with b_cols, [N, P*K] (B[z] = COLUMNS z K .. of it: the transposed stack
+    functional.CAT keeps for input gradients); shift f32 [P, N], residual / relu_mask [P, M, N] -> [P, M, N].  bf16."""
+    _chk(a, "a", torch.bfloat16); _chk(b, "b", torch.bfloat16)
+    P, M, K = a.shape
+    if b_cols:
+        N = b.shape[0]
+        assert b.dim() == 2 and b.shape[1] == P * K, (a.shape, b.shape)
+        ldb, b_batch = P * K, K
+    else:
+        N = b.numel() // (P * K)
+        assert b.shape[-1] == K and N * P * K == b.numel(), (a.shape, b.shape)
+        ldb, b_batch = K, N * K
+    if shift is not None:
+        _chk(shift, "shift", torch.float32); assert shift.numel() == P * N
+    for v, n in ((residual, "residual"), (relu_mask, "relu_mask")):
+        if v is not None:
+            _chk(v, n, torch.bfloat16); assert v.numel() == P * M * N
+    out = torch.empty((P, M, N), dtype=a.dtype, device=a.device)
+    call("fod_gemm_nt_batched", dt(a), P, ptr(a), K, M * K, ptr(b), ldb, b_batch, ptr(out), N, M * N, M, N, K,
+         _epi(None, shift, residual, N, 0, relu_mask, N, relu, False), N, M * N, M * N, stream(),
+         work=2.0 * P * M * N * K, tag="fod_gemm_nt")
+    return out
+
+
 def gemm_tn_acc(g, x, dw, row_scale=None, colsum=None, zeroed=False):
     """dw[N1,K2] (f32) += g[M,N1]^T . x[M,K2];  colsum[N1] (f32, optional) += column sums of g."""
     _chk(g, "g"); _chk(x, "x", g.dtype); _chk(dw, "dw", torch.float32)
@@ -569,11 +595,15 @@ def attn_bwd(q1, k1, v, o, dout, lse2, scale, q2=None, k2=None, dk1_out=None, dv
 
 
 # ------------------------------------------------------------------------------------------------ norm / eltwise
-def layernorm_fwd(x, gamma, beta, residual=None, res_row_div=0, res_row_mod=0, want_sum=None, eps=1e-5):
+def layernorm_fwd(x, gamma, beta, residual=None, res_row_div=0, res_row_mod=0, want_sum=None, eps=1e-5, group_rows=0):
+    """group_rows > 0: gamma / beta are [rows / group_rows, D] tables, one entry per group of consecutive rows."""
     _chk(x, "x"); _chk(gamma, "gamma", torch.float32); _chk(beta, "beta", torch.float32)
     D = x.shape[-1]
     rows = x.numel() // D
-    assert gamma.numel() == D and beta.numel() == D
+    if group_rows:
+        assert rows % group_rows == 0 and gamma.numel() == (rows // group_rows) * D and beta.numel() == gamma.numel()
+    else:
+        assert gamma.numel() == D and beta.numel() == D
     if residual is not None:
         _chk(residual, "residual", x.dtype); assert residual.shape[-1] == D
         rr = residual.numel() // D
@@ -589,7 +619,7 @@ def layernorm_fwd(x, gamma, beta, residual=None, res_row_div=0, res_row_mod=0, w
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     call("fod_layernorm_fwd", dt(x), ptr(x), ptr(residual), res_row_div, res_row_mod, ptr(gamma), ptr(beta),
-         ptr(y), ptr(s), ptr(mean), ptr(rstd), rows, D, eps, stream())
+         ptr(y), ptr(s), ptr(mean), ptr(rstd), rows, D, eps, group_rows, stream())
     return y, (s if want_sum else x), mean, rstd
 
 
@@ -645,16 +675,18 @@ def linear_add_norm_bwd(dy, xsum, mean, rstd, gamma, w_t, dgamma, dbeta, want_da
     return dsum, da
 
 
-def layernorm_bwd(dy, xsum, mean, rstd, gamma, dgamma, dbeta):
+def layernorm_bwd(dy, xsum, mean, rstd, gamma, dgamma, dbeta, group_rows=0):
     _chk(dy, "dy"); _chk(xsum, "xsum", dy.dtype)
     D = dy.shape[-1]
     rows = dy.numel() // D
     assert xsum.numel() == dy.numel() and mean.numel() == rows and rstd.numel() == rows
+    groups = rows // group_rows if group_rows else 1
+    assert not group_rows or (rows % group_rows == 0 and rows <= 4096)
     for t in (gamma, dgamma, dbeta):
-        _chk(t, "gamma/dgamma/dbeta", torch.float32); assert t.numel() == D
+        _chk(t, "gamma/dgamma/dbeta", torch.float32); assert t.numel() == groups * D
     dx = torch.empty_like(dy)
     call("fod_layernorm_bwd", dt(dy), ptr(dy), ptr(xsum), ptr(mean), ptr(rstd), ptr(gamma), ptr(dx),
-         ptr(dgamma), ptr(dbeta), rows, D, stream())
+         ptr(dgamma), ptr(dbeta), rows, D, group_rows, stream())
     return dx
 
 

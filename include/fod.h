@@ -37,7 +37,7 @@ enum { FOD_OK = 0, FOD_ERR_ARG = 1, FOD_ERR_LAUNCH = 2, FOD_ERR_RUNTIME = 3 };
 size_t fod_last_error(char* buf, size_t cap);
 /* ABI version of this header; the loader refuses a library that disagrees. */
 int fod_abi_version(void);
-#define FOD_ABI_VERSION 3
+#define FOD_ABI_VERSION 4
 
 /* Fused epilogue of the NT contraction family.  In order:
  *   v = acc * scale[n] + shift[n];  v += residual[row(m), n];  v = relu ? max(v,0) : v;
@@ -99,6 +99,15 @@ int fod_gemm_tn_acc(int dtype, const void* G, long ldg, const void* X, long ldx,
 int fod_gemm_nt_grouped(int dtype, const void* A, long lda, int a_seg_len, long a_seg_stride, const void* B,
                         long ldb, void* C, long ldc, int c_seg_cols, long c_seg_stride, int M, int N, int K,
                         const fod_epilogue* epi, fod_stream_t stream);
+/* `batches` independent problems of ONE shape in one launch of the short-launch kernel (bf16): operand X of batch z
+ * starts x_batch elements after that of batch z - 1 (A [M, K], B [N, K], C [M, N]; the epilogue's shift [N], residual and
+ * relu_mask [M, N] likewise, strides in elements; scale and residual_row_mod are not batched).  The same sub-layer of
+ * several transformer layers whose inputs do not depend on each other: the encoder layers' IMU-token blocks
+ * (future_od/models/transformer.py:108-119 with one key per frame: value -> out_proj -> norm -> MLP -> norm act on
+ * [frames, D] rows that are the same for every layer). */
+int fod_gemm_nt_batched(int dtype, int batches, const void* A, long lda, long a_batch, const void* B, long ldb,
+                        long b_batch, void* C, long ldc, long c_batch, int M, int N, int K, const fod_epilogue* epi,
+                        long shift_batch, long residual_batch, long mask_batch, fod_stream_t stream);
 int fod_gemm_tn_grouped(int dtype, const void* G, long ldg, int g_seg_cols, long g_seg_stride, const void* X,
                         long ldx, float* dW, long ldw, int M, int N1, int K2, float* colsum, int accumulate,
                         fod_stream_t stream);
@@ -316,13 +325,15 @@ int fod_linear_add_norm_bwd(int dtype, const void* dy, const void* xsum, const f
                             /* optional (the forward call had then_*): the gradient of y is dy + pre_g . then_w, with
                              * pre_g [M, 256] the gradient of then_out and pre_w_t = then_w^T as [256][256]; dy may be NULL */
                             const void* pre_g, const void* pre_w_t, fod_stream_t stream);
+/* group_rows > 0 (rows % group_rows == 0): gamma / beta (and dgamma / dbeta) are [rows / group_rows, D] tables and rows
+ * [g * group_rows, (g + 1) * group_rows) use entry g -- the same norm of several layers in one launch; 0: one [D] pair. */
 int fod_layernorm_fwd(int dtype, const void* x, const void* residual, int res_row_div, int res_row_mod,
                       const float* gamma, const float* beta, void* y, void* sum_out, float* mean,
-                      float* rstd, int rows, int D, float eps, fod_stream_t stream);
+                      float* rstd, int rows, int D, float eps, int group_rows, fod_stream_t stream);
 /* dx from dy; dgamma/dbeta += (f32 [D]).  xsum is the tensor that was normalised (x + residual). */
 int fod_layernorm_bwd(int dtype, const void* dy, const void* xsum, const float* mean, const float* rstd,
                       const float* gamma, void* dx, float* dgamma, float* dbeta, int rows, int D,
-                      fod_stream_t stream);
+                      int group_rows, fod_stream_t stream);
 
 enum {
   FOD_EW_ADD = 0,       /* out = a + b[row(m)]            */

@@ -1275,3 +1275,60 @@ def test_fused_frozen_bottleneck_matches_the_layer_by_layer_path(cin, shape, ver
     e_unf = float((fused.float() - hcur.float()).abs().max()) / span
     print(f"fused bottleneck cin={cin} {shape}: vs fp32 torch {e_ref:.3e}, vs layer-by-layer HIP {e_unf:.3e} of max|ref|")
     assert e_ref <= 2e-2 and e_unf <= 1.6e-2, (e_ref, e_unf)
+
+
+@pytest.mark.parametrize("P,M,N,K", [(6, 10, 256, 256), (6, 10, 2048, 256), (6, 10, 256, 2048), (3, 70, 192, 64), (2, 1, 64, 32)])
+def test_gemm_nt_batched_equals_separate_launches(P, M, N, K):
+    """fod_gemm_nt_batched (P problems of one shape in one launch of the short-launch kernel; the encoder layers' IMU
+    blocks) against P fod_gemm_nt launches: bit-equal (the same kernel body walks the same k order), with bias, ReLU,
+    residual and ReLU-gate epilogues, for stacked weights [P*N, K] and for column blocks of a transposed stack [N, P*K]."""
+    dtype = torch.bfloat16
+    a = rnd((P, M, K), dtype, 81).to(DEV)
+    w = rnd((P * N, K), dtype, 82, scale=1.0 / 16).to(DEV)
+    bias = (torch.randn(P * N) * 0.3).to(DEV)
+    res = rnd((P, M, N), dtype, 83).to(DEV)
+    gate = rnd((P, M, N), dtype, 84).to(DEV)
+    for kw in (dict(shift=True), dict(shift=True, relu=True), dict(residual=True), dict(relu_mask=True), dict()):
+        out = ops.gemm_nt_batched(a, w, shift=bias if kw.get("shift") else None, relu=bool(kw.get("relu")),
+                                  residual=res if kw.get("residual") else None, relu_mask=gate if kw.get("relu_mask") else None)
+        for z in range(P):
+            ref = ops.gemm_nt(a[z], w[z * N:(z + 1) * N], shift=bias[z * N:(z + 1) * N] if kw.get("shift") else None,
+                              relu=bool(kw.get("relu")), residual=res[z] if kw.get("residual") else None,
+                              relu_mask=gate[z] if kw.get("relu_mask") else None)
+            if K >= 1024 and M * N <= 64 * 64 * 64:
+                # (the single launch may split K across blocks: another summation order)
+                assert float((out[z].float() - ref.float()).abs().max()) <= 2.0 ** -6 * max(float(ref.float().abs().max()), 1e-3)
+            else:
+                assert torch.equal(out[z], ref), (kw, z, float((out[z].float() - ref.float()).abs().max()))
+    # transposed stack: B[z] = columns z K .. of wt [N, P*K]
+    wt = rnd((N, P * K), dtype, 85, scale=1.0 / 16).to(DEV)
+    out = ops.gemm_nt_batched(a, wt, b_cols=True)
+    for z in range(P):
+        ref = a[z].double() @ wt[:, z * K:(z + 1) * K].double().t()
+        check(out[z], ref.float().cpu(), dtype, float(ref.abs().max()), f"batched b_cols z={z}")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("P,M,with_res", [(6, 10, True), (6, 10, False), (3, 7, True), (2, 1, True)])
+def test_layernorm_grouped_parameter_tables(dtype, P, M, with_res):
+    """fod_layernorm_fwd / _bwd with group_rows: rows [g M, (g + 1) M) use row g of [P, D] gamma / beta tables (the same
+    norm of P layers in one launch) -- against P separate launches: forward bit-equal, dx bit-equal, dgamma / dbeta equal
+    to f32 summation order."""
+    D = 256
+    x = rnd((P * M, D), dtype, 91).to(DEV)
+    res = rnd((P * M, D), dtype, 92).to(DEV) if with_res else None
+    gamma, beta = (torch.rand(P, D) + 0.5).to(DEV), (torch.randn(P, D) * 0.2).to(DEV)
+    y, s, mean, rstd = ops.layernorm_fwd(x, gamma, beta, residual=res, group_rows=M)
+    dy = rnd((P * M, D), dtype, 93).to(DEV)
+    dg, db = torch.zeros(P, D, device=DEV), torch.zeros(P, D, device=DEV)
+    dx = ops.layernorm_bwd(dy, s, mean, rstd, gamma, dg, db, group_rows=M)
+    for g in range(P):
+        sl = slice(g * M, (g + 1) * M)
+        y1, s1, m1, r1 = ops.layernorm_fwd(x[sl].contiguous(), gamma[g].contiguous(), beta[g].contiguous(),
+                                           residual=None if res is None else res[sl].contiguous())
+        assert torch.equal(y[sl], y1) and torch.equal(mean[sl], m1) and torch.equal(rstd[sl], r1)
+        dg1, db1 = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+        dx1 = ops.layernorm_bwd(dy[sl].contiguous(), s1, m1, r1, gamma[g].contiguous(), dg1, db1)
+        assert torch.equal(dx[sl], dx1)
+        assert torch.allclose(dg[g], dg1, rtol=1e-5, atol=1e-5 * float(dg1.abs().max()) + 1e-6)
+        assert torch.allclose(db[g], db1, rtol=1e-5, atol=1e-5 * float(db1.abs().max()) + 1e-6)

@@ -386,3 +386,60 @@ def test_ctypes_fallback_binding_still_runs_the_model():
     out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=root, env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "smoke ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("use_mlp", [True, False])
+def test_imu_blocks_of_all_layers_at_once(use_mlp, monkeypatch):
+    """Fn.imu_branch (ImuBranchFn: the one-key IMU blocks of all layers in a handful of batched launches) against the
+    layer-by-layer EgodeepAttention.forward_single_key: outputs bit-equal (the same kernels on the same rows) or within one
+    bf16 ulp where the batched launch cannot split K, every parameter gradient and the input gradient within bf16
+    tolerance; then through TransformerEncoder with the switch on and off."""
+    torch.manual_seed(7)
+    P, F_, D, Dff = 6, 10, 256, 2048
+    blocks = nn.ModuleList([T.EgodeepAttention(D, 8, droprate=0.1, Dff=Dff if use_mlp else None) for _ in range(P)]).to(DEV)
+    blocks.eval()
+    with torch.no_grad():
+        for prm in blocks.parameters():
+            if prm.dim() == 1:
+                prm.add_(torch.randn_like(prm) * 0.2)
+    ego = (torch.randn(F_, D, device=DEV) * 0.7).to(torch.bfloat16)
+    gout = [(torch.randn(F_, D, device=DEV)).to(torch.bfloat16) for _ in range(P)]
+    live = [prm for b in blocks for n, prm in b.named_parameters() if not n.startswith(("query_", "key."))]
+    res = []
+    for batched in (True, False):
+        for prm in blocks.parameters():
+            prm.grad = None
+        Fn.PREP.clear()
+        e = ego.clone().requires_grad_(True)
+        if batched:
+            assert Fn.imu_branch_fits(e, list(blocks))
+            outs = Fn.imu_branch(e, list(blocks))
+        else:
+            outs = [b.forward_single_key(e) for b in blocks]
+        sum((o.float() * g.float()).sum() for o, g in zip(outs, gout)).backward()
+        res.append(([o.detach().clone() for o in outs], e.grad.clone(), [prm.grad.clone() for prm in live]))
+    (o1, ge1, gp1), (o2, ge2, gp2) = res
+    for a, b in zip(o1, o2):
+        assert float((a.float() - b.float()).abs().max()) <= 2.0 ** -6 * float(b.float().abs().max())
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-9))
+    assert rel(ge1, ge2) <= 1e-2, rel(ge1, ge2)
+    for a, b in zip(gp1, gp2):
+        assert rel(a, b) <= 1e-2, (a.shape, rel(a, b))
+    # through the encoder
+    enc = T.TransformerEncoder(nn.ModuleList(T.TransformerEncoderLayer(D, 8, 512, use_egodeep=True) for _ in range(3))).to(DEV)
+    enc.eval()
+    x = (torch.randn(F_, 96, D, device=DEV) * 0.5).to(torch.bfloat16)
+    pos = torch.randn(96, D, device=DEV).to(torch.bfloat16)
+    ys = []
+    for batched in (True, False):
+        monkeypatch.setattr(Fn, "IMU_BATCHED", batched)
+        for prm in enc.parameters():
+            prm.grad = None
+        Fn.PREP.clear()
+        y = enc(x, pos, ego)
+        y.float().square().sum().backward()
+        ys.append((y.detach().clone(), {n: prm.grad.clone() for n, prm in enc.named_parameters() if prm.grad is not None}))
+    assert float((ys[0][0].float() - ys[1][0].float()).abs().max()) <= 2e-2 * float(ys[1][0].float().abs().max())
+    assert ys[0][1].keys() == ys[1][1].keys()
+    for n in ys[0][1]:
+        assert rel(ys[0][1][n], ys[1][1][n]) <= 3e-2, (n, rel(ys[0][1][n], ys[1][1][n]))

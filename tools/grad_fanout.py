@@ -24,12 +24,20 @@ def main():
     model.eval()
     data = make_batch(bench.BATCH_PER_GPU, bench.T_FRAMES, bench.HEIGHT, bench.WIDTH, seed=1234, device=dev)
     calls = collections.Counter()
+    gemms = collections.Counter()
     real = ops.call
 
     def counting(name, *a, **k):
         if name in ("fod_eltwise", "fod_layernorm_fwd", "fod_permute3_cast", "fod_colsum_acc"):
             fr = [f for f in traceback.extract_stack(limit=7)[:-1] if "native/ops.py" not in f.filename]
             calls[(name, a[0] if name == "fod_eltwise" else "", " < ".join(f"{f.name}:{f.lineno}" for f in fr[-3:][::-1]))] += 1
+        if name in ("fod_gemm_nt", "fod_gemm_nt_grouped", "fod_linear_add_norm_fwd", "fod_linear_add_norm_bwd"):
+            # M, N, K of the launch (argument positions of native/ops.py's calls) and who asked for it
+            dims = {"fod_gemm_nt": a[8:11], "fod_gemm_nt_grouped": a[11:14], "fod_linear_add_norm_fwd": a[12:15],
+                    "fod_linear_add_norm_bwd": a[11:14]}[name]
+            fr = [f for f in traceback.extract_stack(limit=12)[:-1]
+                  if "native/ops.py" not in f.filename and "/torch/" not in f.filename]
+            gemms[(name, tuple(dims), " < ".join(f"{f.name}:{f.lineno}" for f in fr[-4:][::-1]))] += 1
         return real(name, *a, **k)
 
     ops.call = counting
@@ -65,6 +73,12 @@ def main():
     print("element-wise / norm / cast entry calls of one eager step, by caller:")
     for (name, op, where), n in sorted(calls.items(), key=lambda kv: -kv[1]):
         print(f"  {n:3d}  {name} {op}  {where}")
+    print("NT GEMM launches of one eager step (forward + backward) by shape and caller:")
+    tot = 0
+    for (name, dims, where), n in sorted(gemms.items(), key=lambda kv: (-kv[1], kv[0])):
+        tot += n
+        print(f"  {n:3d}  {name} {dims}  {where}")
+    print(f"  = {tot} launches")
 
 
 main()
