@@ -335,6 +335,238 @@ __global__ __launch_bounds__(256) void linear_add_norm_bwd_kernel(const LanBwdPa
   atomicAdd(p.dbeta + tid, ab);
 }
 
+// ---- out = ((relu(x W1^T + b1)) W2^T + b2) * table[m % mod]: a two-layer 256 -> 256 -> 256 MLP and the periodic multiply that
+// follows it, in ONE launch -- the decoder's query_scale MLP and the product with the reference points' sine embedding
+// (reference transformer.py:384-386: `query_sine = self.query_scale(x) * query_sine_embed`), once per decoder layer.  The
+// same 16-row workgroups as above: the hidden tile goes through LDS once (accumulator layout -> operand layout), the
+// second weight matrix is requested behind the first product's MFMAs.  Stores what the backward launch reads: the hidden
+// activations h (ReLU gate, weight gradient of the second layer) and the MLP's output q (gradient of the table).
+struct Mlp2Params {
+  const __bf16* x;
+  const __bf16* w1;
+  const float* b1;
+  const __bf16* w2;
+  const float* b2;
+  const __bf16* table;     // [mod, 256] or NULL (no multiply)
+  __bf16* h;
+  __bf16* q;               // NULL without a table (out IS q)
+  __bf16* out;
+  int M, mod;
+};
+
+__global__ __launch_bounds__(256) void mlp2_mul_kernel(const Mlp2Params p) {
+  constexpr int D = 256, KS = D / 32;
+  __shared__ __attribute__((aligned(16))) __bf16 hbuf[16][D + 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  bf16x8_t fw[4][KS];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const __bf16* wp = p.w1 + (long)(64 * wave + 16 * t + c) * D + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) fw[t][ks] = *reinterpret_cast<const bf16x8_t*>(wp + 32 * ks);
+  }
+  f32x4v bi1[4], bi2[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int n = 64 * wave + 16 * t + 4 * g;
+    bi1[t] = p.b1 ? *reinterpret_cast<const f32x4v*>(p.b1 + n) : f32x4v{0.f, 0.f, 0.f, 0.f};
+    bi2[t] = p.b2 ? *reinterpret_cast<const f32x4v*>(p.b2 + n) : f32x4v{0.f, 0.f, 0.f, 0.f};
+  }
+  const int ntiles = (p.M + 15) / 16;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * 16;
+    const int m = min(m0 + c, p.M - 1);
+    const bool live = m0 + c < p.M;
+    bf16x8_t fa[KS];
+    const __bf16* ap = p.x + (long)m * D + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) fa[ks] = *reinterpret_cast<const bf16x8_t*>(ap + 32 * ks);
+    bf16x4_t tb[4];
+    const int mt = p.mod > 0 ? m % p.mod : m;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      tb[t] = p.table ? *reinterpret_cast<const bf16x4_t*>(p.table + (long)mt * D + 64 * wave + 16 * t + 4 * g)
+                      : bf16x4_t{(__bf16)1.f, (__bf16)1.f, (__bf16)1.f, (__bf16)1.f};
+    f32x4v acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[t][ks], fa[ks], acc[t], 0, 0, 0);
+    bf16x8_t fw2[4][KS];                                   // requested now, needed behind the barrier
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const __bf16* wp = p.w2 + (long)(64 * wave + 16 * t + c) * D + 8 * g;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) fw2[t][ks] = *reinterpret_cast<const bf16x8_t*>(wp + 32 * ks);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int n = 64 * wave + 16 * t + 4 * g;
+      bf16x4_t hv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hv[r] = (__bf16)fmaxf(acc[t][r] + bi1[t][r], 0.f);
+      *reinterpret_cast<bf16x4_t*>(&hbuf[c][n]) = hv;
+      if (live) *reinterpret_cast<bf16x4_t*>(p.h + (long)m * D + n) = hv;
+    }
+    __syncthreads();                                       // the 16 x 256 hidden tile (as stored: bf16) is in LDS
+    f32x4v acc2[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc2[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8_t fy = *reinterpret_cast<const bf16x8_t*>(&hbuf[c][32 * ks + 8 * g]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[t][ks], fy, acc2[t], 0, 0, 0);
+    }
+    if (live) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int n = 64 * wave + 16 * t + 4 * g;
+        bf16x4_t qv, ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          qv[r] = (__bf16)(acc2[t][r] + bi2[t][r]);
+          ov[r] = (__bf16)((float)qv[r] * (float)tb[t][r]);
+        }
+        if (p.table) {
+          if (p.q) *reinterpret_cast<bf16x4_t*>(p.q + (long)m * D + n) = qv;
+          *reinterpret_cast<bf16x4_t*>(p.out + (long)m * D + n) = ov;
+        } else {
+          *reinterpret_cast<bf16x4_t*>(p.out + (long)m * D + n) = qv;
+        }
+      }
+    }
+    __syncthreads();                                       // (a further tile of this workgroup overwrites hbuf)
+  }
+}
+
+// ---- its backward in one launch: ds = dout * table[m % mod] (the second layer's output gradient), dtable[m % mod] += dout * q
+// (f32 atomics: the rows of a batch that share a table row, and -- the caller hands every layer the same buffer -- all
+// decoder layers), dh = (ds W2) gated by h > 0, dx = dh W1.  ds and dh are stored for the weight-gradient queue.  Every
+// wave loads whole rows of dout / table / q in operand layout (as linear_add_norm_bwd_kernel does) and owns 64 columns of
+// each result.
+struct Mlp2BwdParams {
+  const __bf16* dout;
+  const __bf16* table;     // NULL: ds = dout
+  const __bf16* q;
+  const __bf16* h;
+  const __bf16* w2t;       // W2^T as [K = hidden][N = out]
+  const __bf16* w1t;       // W1^T as [K = in][N = hidden]
+  __bf16* ds;              // NULL without a table (ds is dout)
+  __bf16* dh;
+  __bf16* dx;
+  float* dtable;           // [mod, 256] f32, accumulated
+  int M, mod;
+};
+
+__global__ __launch_bounds__(256) void mlp2_mul_bwd_kernel(const Mlp2BwdParams p) {
+  constexpr int D = 256, KS = D / 32;
+  __shared__ __attribute__((aligned(16))) __bf16 gbuf[16][D + 8];
+  __shared__ __attribute__((aligned(16))) float pbuf[16][D + 4];     // dout * q of the tile (each wave: its own 64 columns)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  bf16x8_t fw2[4][KS];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const __bf16* wp = p.w2t + (long)(64 * wave + 16 * t + c) * D + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) fw2[t][ks] = *reinterpret_cast<const bf16x8_t*>(wp + 32 * ks);
+  }
+  const int ntiles = (p.M + 15) / 16;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * 16;
+    const int m = min(m0 + c, p.M - 1);
+    const bool live = m0 + c < p.M;
+    const int mt = p.mod > 0 ? m % p.mod : m;
+    bf16x8_t fd[KS];
+    const __bf16* dp = p.dout + (long)m * D + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) fd[ks] = *reinterpret_cast<const bf16x8_t*>(dp + 32 * ks);
+    bf16x4_t hm[4];                                        // the gate of this lane's hidden units (accumulator layout)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) hm[t] = *reinterpret_cast<const bf16x4_t*>(p.h + (long)m * D + 64 * wave + 16 * t + 4 * g);
+    bf16x8_t fw1[4][KS];                                   // requested now, needed behind the barrier
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const __bf16* wp = p.w1t + (long)(64 * wave + 16 * t + c) * D + 8 * g;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) fw1[t][ks] = *reinterpret_cast<const bf16x8_t*>(wp + 32 * ks);
+    }
+    if (p.table) {
+      // this wave's 64 columns (k-steps 2 wave, 2 wave + 1) also produce the table's gradient and the stored ds
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8_t ft = *reinterpret_cast<const bf16x8_t*>(p.table + (long)mt * D + 32 * ks + 8 * g);
+        const bool mine = (ks >> 1) == wave;
+        bf16x8_t fq;
+        if (mine) fq = *reinterpret_cast<const bf16x8_t*>(p.q + (long)m * D + 32 * ks + 8 * g);
+        bf16x8_t dsv;
+        f32x4v p0, p1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = live ? (float)fd[ks][j] : 0.f;
+          dsv[j] = (__bf16)(d * (float)ft[j]);
+          if (mine) {
+            if (j < 4) p0[j] = d * (float)fq[j]; else p1[j - 4] = d * (float)fq[j];
+          }
+        }
+        if (mine) {
+          *reinterpret_cast<f32x4v*>(&pbuf[c][32 * ks + 8 * g]) = p0;
+          *reinterpret_cast<f32x4v*>(&pbuf[c][32 * ks + 8 * g + 4]) = p1;
+          if (live && p.ds) *reinterpret_cast<bf16x8_t*>(p.ds + (long)m * D + 32 * ks + 8 * g) = dsv;
+        }
+        fd[ks] = dsv;
+      }
+      // the table's gradient: one atomic instruction per (row, 64 consecutive columns) -- in the operand layout an
+      // instruction's 64 lanes hit 64 different 32-byte pieces (21 us per launch; this way ~the forward launch's time).
+      // A wave reads back only what it wrote itself: no barrier
+#pragma unroll 4
+      for (int r = 0; r < 16; ++r) {
+        const int mr = m0 + r;
+        if (mr < p.M) atomicAdd(p.dtable + (long)(p.mod > 0 ? mr % p.mod : mr) * D + 64 * wave + lane, pbuf[r][64 * wave + lane]);
+      }
+    }
+    // ---- dh^T[k, m] = sum_n W2^T[k, n] ds[m, n], gated
+    f32x4v acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[t][ks], fd[ks], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int n = 64 * wave + 16 * t + 4 * g;
+      bf16x4_t gv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) gv[r] = (float)hm[t][r] > 0.f ? (__bf16)acc[t][r] : (__bf16)0.f;
+      *reinterpret_cast<bf16x4_t*>(&gbuf[c][n]) = gv;
+      if (live) *reinterpret_cast<bf16x4_t*>(p.dh + (long)m * D + n) = gv;
+    }
+    __syncthreads();
+    // ---- dx^T[j, m] = sum_k W1^T[j, k] dh[m, k]
+    f32x4v acc2[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc2[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8_t fy = *reinterpret_cast<const bf16x8_t*>(&gbuf[c][32 * ks + 8 * g]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[t][ks], fy, acc2[t], 0, 0, 0);
+    }
+    if (live) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        *reinterpret_cast<bf16x4_t*>(p.dx + (long)m * D + 64 * wave + 16 * t + 4 * g) =
+            bf16x4_t{(__bf16)acc2[t][0], (__bf16)acc2[t][1], (__bf16)acc2[t][2], (__bf16)acc2[t][3]};
+    }
+    __syncthreads();
+  }
+}
+
 // one workgroup per 16-row tile up to one per CU (the kernels hold ~260-320 registers: one wave per SIMD); beyond that the workgroups walk the tiles (weights stay in
 // their registers)
 int lan_grid(int M) {
@@ -392,6 +624,44 @@ extern "C" int fod_linear_add_norm_bwd(int dtype, const void* dy, const void* xs
   p.pre_g = (const __bf16*)pre_g; p.pre_wt = (const __bf16*)pre_w_t;
   if (pre_g) hipLaunchKernelGGL(linear_add_norm_bwd_kernel<true>, dim3(lan_grid(M)), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(linear_add_norm_bwd_kernel<false>, dim3(lan_grid(M)), dim3(256), 0, stream, p);
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
+}
+
+extern "C" int fod_mlp2_mul_fwd(int dtype, const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                                const void* table, int table_rows, void* h, void* q, void* out, int M, int D,
+                                hipStream_t stream) {
+  FOD_REQUIRE(dtype == FOD_BF16, "mlp2_mul_fwd: bf16 only (dtype %d)", dtype);
+  FOD_REQUIRE(x && w1 && w2 && h && out && M > 0, "mlp2_mul_fwd: bad args");
+  FOD_REQUIRE(D == 256, "mlp2_mul_fwd: built for 256 -> 256 -> 256 (D %d)", D);
+  FOD_REQUIRE(!table || (q && table_rows > 0), "mlp2_mul_fwd: a table needs q and its row count");
+  auto al = [](const void* p_) { return ((uintptr_t)p_ % 16) == 0; };
+  FOD_REQUIRE(al(x) && al(w1) && al(w2) && al(h) && al(out) && (!b1 || al(b1)) && (!b2 || al(b2)) && (!table || (al(table) && al(q))),
+              "mlp2_mul_fwd: operands must be 16-byte aligned");
+  Mlp2Params p{};
+  p.x = (const __bf16*)x; p.w1 = (const __bf16*)w1; p.b1 = b1; p.w2 = (const __bf16*)w2; p.b2 = b2;
+  p.table = (const __bf16*)table; p.h = (__bf16*)h; p.q = (__bf16*)q; p.out = (__bf16*)out; p.M = M;
+  p.mod = table ? table_rows : 0;
+  hipLaunchKernelGGL(mlp2_mul_kernel, dim3(lan_grid(M)), dim3(256), 0, stream, p);
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
+}
+
+extern "C" int fod_mlp2_mul_bwd(int dtype, const void* dout, const void* table, int table_rows, const void* q, const void* h,
+                                const void* w2_t, const void* w1_t, void* ds, void* dh, void* dx, float* dtable, int M,
+                                int D, hipStream_t stream) {
+  FOD_REQUIRE(dtype == FOD_BF16, "mlp2_mul_bwd: bf16 only (dtype %d)", dtype);
+  FOD_REQUIRE(dout && h && w2_t && w1_t && dh && dx && M > 0, "mlp2_mul_bwd: bad args");
+  FOD_REQUIRE(D == 256, "mlp2_mul_bwd: built for 256 -> 256 -> 256 (D %d)", D);
+  FOD_REQUIRE(!table || (q && ds && dtable && table_rows > 0), "mlp2_mul_bwd: a table needs q, ds, dtable and its row count");
+  auto al = [](const void* p_) { return ((uintptr_t)p_ % 16) == 0; };
+  FOD_REQUIRE(al(dout) && al(h) && al(w2_t) && al(w1_t) && al(dh) && al(dx) && (!table || (al(table) && al(q) && al(ds))),
+              "mlp2_mul_bwd: operands must be 16-byte aligned");
+  Mlp2BwdParams p{};
+  p.dout = (const __bf16*)dout; p.table = (const __bf16*)table; p.q = (const __bf16*)q; p.h = (const __bf16*)h;
+  p.w2t = (const __bf16*)w2_t; p.w1t = (const __bf16*)w1_t; p.ds = (__bf16*)ds; p.dh = (__bf16*)dh; p.dx = (__bf16*)dx;
+  p.dtable = dtable; p.M = M; p.mod = table ? table_rows : 0;
+  hipLaunchKernelGGL(mlp2_mul_bwd_kernel, dim3(lan_grid(M)), dim3(256), 0, stream, p);
   FOD_LAUNCH_CHECK();
   return FOD_OK;
 }

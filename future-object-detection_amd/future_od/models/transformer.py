@@ -247,9 +247,12 @@ class SlotToImageAttention(Attention):
             qc = Fn.add(qc, qpos_proj if qpos_proj is not None else _lin(qpos, self.query_pos), b_row_mod=M)
         if qs is None:
             qs = _lin(query_sine, self.query_sine)
-        if qs.dim() == 2:
+        if is_first and qs.dim() == 2:
+            # (as below, with the broadcast of the batch-independent sine projection inside the same launch)
+            qs = Fn.add(qc, qs, b_row_mod=M)
+        elif qs.dim() == 2:
             qs = Fn.expand_rows(qs, B).view(B, M, D)
-        if is_first:
+        elif is_first:
             # reference: k_content += k_sine in the first layer.  q_c.(k_c + k_s) + q_s.k_s == q_c.k_c + (q_c + q_s).k_s,
             # so the addition moves to the (tiny) query side and the key slots are used as they are
             qs = Fn.add(qs, qc)
@@ -376,12 +379,18 @@ class TransformerDecoder(nn.Module):
             pos_lin += [self.layers[0].image_attend[j].query_pos for j in range(K)]
         pos_all = Fn.group_linear(qpos, pos_lin)
         inter = []
+        sine_acc, first_scaled = Fn.TableGradAcc(), True
         for lid, layer in enumerate(self.layers):
             special = lid == 0 and first_layer_special
             pos_proj = {"sa": (pos_all[2 * lid], pos_all[2 * lid + 1]),
                         "ca": pos_all[2 * len(self.layers):] if special else None}
             if special:
                 q_sine = sine0
+            elif Fn.mlp2_mul_fits(x, self.query_scale, sine0):
+                # the MLP and the product in one launch; the layers' gradients of sine0 meet in one buffer
+                q_sine = Fn.mlp2_mul(x.view(B * M, D), self.query_scale, sine0, acc=sine_acc,
+                                     hands_on=first_scaled).view(B, M, D)
+                first_scaled = False
             else:
                 q_sine = Fn.mul(self.query_scale(x).view(B * M, D), sine0, b_row_mod=M).view(B, M, D)
             x = layer(x, qpos, q_sine, side, lid, is_first=special, pos_proj=pos_proj, slotstates=slotstates,

@@ -804,6 +804,97 @@ class MulFn(Function):
         return da, db, None
 
 
+def _queued_linear_wgrad(weight, bias, g, x, need_w, need_b):
+    """(dw, db) of a Linear layer as LinearFn.backward produces them: through the weight-gradient queue, a further use of a
+    shared layer inside the first use's job ((None, None) then)."""
+    N, K = weight.shape
+    want_db = bias is not None and need_b
+    if need_w and WGRADS.chain(weight, want_db, g, x):
+        return None, None
+    db = zeros_f32((N,), x.device) if want_db else None
+    dw = None
+    if need_w:
+        dw = zeros_f32((N, K), x.device)
+        WGRADS.tn(WGRADS.site((weight, bias)), g, x, dw, db, owner=weight)
+    elif want_db:
+        ops.colsum_acc(g, db)
+    return dw, db
+
+
+class TableGradAcc:
+    """One f32 accumulation buffer for the gradient of a table that several Mlp2MulFn nodes multiply by (the decoder
+    layers' query_scale(x) * sine embedding): every node's backward launch adds into it with atomics; the node that runs
+    LAST in the backward pass (the first in the forward pass: later layers depend on its output) hands the total on --
+    one gradient instead of one per layer that autograd would sum with kernels of its own."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, shape, device):
+        if self.buf is None:
+            self.buf = zeros_f32(shape, device)
+        return self.buf
+
+    def take(self):
+        buf, self.buf = self.buf, None
+        return buf
+
+
+# "0": the decoder's query_scale MLP and the product with the sine embedding as separate launches (2 GEMMs + multiply)
+FUSED_MLP2 = os.environ.get("FOD_FUSED_MLP2", "1") != "0"
+
+
+class Mlp2MulFn(Function):
+    """((relu(x W1^T + b1)) W2^T + b2) * table[m % rows(table)] as ONE launch forward and ONE backward
+    (fod_mlp2_mul_fwd / _bwd, csrc/linear_norm.hip): reference transformer.py:384-386, once per decoder layer.  As separate
+    nodes that was 2 GEMMs + a multiply forward and 2 GEMMs + a ReLU gate + 2 multiplies + a sum over the batch backward."""
+
+    @staticmethod
+    def forward(ctx, x, table, w1, b1, w2, b2, acc, hands_on):
+        D = x.shape[-1]
+        x2 = x.view(-1, D)
+        out, h, q = ops.mlp2_mul_fwd(x2, prep_linear(w1, x.dtype, False), b1, prep_linear(w2, x.dtype, False), b2, table)
+        ctx.save_for_backward(x2, h, q, table)
+        ctx.params, ctx.acc, ctx.hands_on = (w1, b1, w2, b2), acc, hands_on
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, h, q, table = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.params
+        D = x2.shape[-1]
+        g = g.contiguous().view(-1, D)
+        if g.dtype != x2.dtype:
+            g = cast(g, x2.dtype)
+        acc = ctx.acc if ctx.acc is not None else TableGradAcc()
+        buf = acc.get(tuple(table.shape), x2.device)
+        ds, dh, dx = ops.mlp2_mul_bwd(g, table, q, h, prep_linear(w2, x2.dtype, True), prep_linear(w1, x2.dtype, True), buf)
+        dw2, db2 = _queued_linear_wgrad(w2, b2, ds, h, ctx.needs_input_grad[4], ctx.needs_input_grad[5])
+        dw1, db1 = _queued_linear_wgrad(w1, b1, dh, x2, ctx.needs_input_grad[2], ctx.needs_input_grad[3])
+        dtable = None
+        if ctx.needs_input_grad[1] and (ctx.acc is None or ctx.hands_on):
+            dtable = cast(acc.take(), table.dtype).view(table.shape)
+        return (dx.view(-1, D).view(x2.shape) if ctx.needs_input_grad[0] else None), dtable, dw1, db1, dw2, db2, None, None
+
+
+def mlp2_mul_fits(x, mlp, table):
+    """Whether Mlp2MulFn applies: bf16, a two-layer 256 -> 256 -> 256 MLP with biases, a [rows, 256] table dividing x's rows."""
+    if not FUSED_MLP2 or x.dtype != torch.bfloat16 or getattr(mlp, "num_layers", 0) != 2:
+        return False
+    l0, l1 = mlp.layers
+    D = x.shape[-1]
+    return (D == 256 and tuple(l0.weight.shape) == (D, D) and tuple(l1.weight.shape) == (D, D) and l0.bias is not None
+            and l1.bias is not None and table.dtype == x.dtype and table.dim() == 2 and table.shape[1] == D
+            and (x.numel() // D) % table.shape[0] == 0)
+
+
+def mlp2_mul(x, mlp, table, acc=None, hands_on=True):
+    """mlp(x) * table[m % rows(table)] (see Mlp2MulFn).  `acc` (TableGradAcc) shared by several calls on one table: only the
+    call with hands_on=True -- the FIRST of them in the forward pass -- returns the table's (total) gradient."""
+    l0, l1 = mlp.layers
+    return Mlp2MulFn.apply(x.contiguous(), table.contiguous(), l0.weight, l0.bias, l1.weight, l1.bias, acc, hands_on)
+
+
 def _sum_periodic(g, mod):
     """[rows, cols] -> [mod, cols]: sum of the rows congruent modulo `mod` (rows/mod is tiny)."""
     cols = g.shape[-1]

@@ -675,6 +675,50 @@ def linear_add_norm_bwd(dy, xsum, mean, rstd, gamma, w_t, dgamma, dbeta, want_da
     return dsum, da
 
 
+def mlp2_mul_fwd(x, w1, b1, w2, b2, table=None):
+    """((relu(x w1^T + b1)) w2^T + b2) * table[m % table_rows] in one launch (bf16, 256 -> 256 -> 256): (out, h, q) with h the
+    hidden activations and q the MLP's output before the product (None without a table)."""
+    _chk(x, "x", torch.bfloat16); _chk(w1, "w1", torch.bfloat16); _chk(w2, "w2", torch.bfloat16)
+    D = x.shape[-1]
+    M = x.numel() // D
+    assert tuple(w1.shape) == (D, D) and tuple(w2.shape) == (D, D), (x.shape, w1.shape, w2.shape)
+    for b in (b1, b2):
+        if b is not None:
+            _chk(b, "bias", torch.float32); assert b.numel() == D
+    rows_t = 0
+    if table is not None:
+        _chk(table, "table", torch.bfloat16); assert table.shape[-1] == D
+        rows_t = table.numel() // D
+        assert M % rows_t == 0
+    h = torch.empty((M, D), dtype=x.dtype, device=x.device)
+    q = torch.empty((M, D), dtype=x.dtype, device=x.device) if table is not None else None
+    out = torch.empty((M, D), dtype=x.dtype, device=x.device)
+    call("fod_mlp2_mul_fwd", dt(x), ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(table), rows_t, ptr(h), ptr(q),
+         ptr(out), M, D, stream(), work=4.0 * M * D * D, tag="fod_gemm_nt")
+    return out, h, q
+
+
+def mlp2_mul_bwd(dout, table, q, h, w2_t, w1_t, dtable):
+    """Backward of mlp2_mul_fwd in one launch: (ds, dh, dx); dtable f32 [table_rows, D] += dout * q (atomics)."""
+    _chk(dout, "dout", torch.bfloat16); _chk(h, "h", torch.bfloat16)
+    _chk(w2_t, "w2_t", torch.bfloat16); _chk(w1_t, "w1_t", torch.bfloat16)
+    D = dout.shape[-1]
+    M = dout.numel() // D
+    assert h.numel() == M * D and tuple(w2_t.shape) == (D, D) and tuple(w1_t.shape) == (D, D)
+    rows_t = 0
+    ds = None
+    if table is not None:
+        _chk(table, "table", torch.bfloat16); _chk(q, "q", torch.bfloat16); _chk(dtable, "dtable", torch.float32)
+        rows_t = table.numel() // D
+        assert q.numel() == M * D and dtable.numel() == rows_t * D and M % rows_t == 0
+        ds = torch.empty((M, D), dtype=dout.dtype, device=dout.device)
+    dh = torch.empty((M, D), dtype=dout.dtype, device=dout.device)
+    dx = torch.empty((M, D), dtype=dout.dtype, device=dout.device)
+    call("fod_mlp2_mul_bwd", dt(dout), ptr(dout), ptr(table), rows_t, ptr(q), ptr(h), ptr(w2_t), ptr(w1_t), ptr(ds), ptr(dh),
+         ptr(dx), ptr(dtable), M, D, stream(), work=4.0 * M * D * D, tag="fod_gemm_nt")
+    return (ds if table is not None else dout), dh, dx
+
+
 def layernorm_bwd(dy, xsum, mean, rstd, gamma, dgamma, dbeta, group_rows=0):
     _chk(dy, "dy"); _chk(xsum, "xsum", dy.dtype)
     D = dy.shape[-1]

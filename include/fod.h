@@ -325,6 +325,18 @@ int fod_linear_add_norm_bwd(int dtype, const void* dy, const void* xsum, const f
                             /* optional (the forward call had then_*): the gradient of y is dy + pre_g . then_w, with
                              * pre_g [M, 256] the gradient of then_out and pre_w_t = then_w^T as [256][256]; dy may be NULL */
                             const void* pre_g, const void* pre_w_t, fod_stream_t stream);
+/* out [M, 256] = ((relu(x W1^T + b1)) W2^T + b2) * table[m % table_rows] in ONE launch (bf16, 256 -> 256 -> 256): the
+ * decoder's query_scale MLP and its product with the reference points' sine embedding, once per decoder layer (reference
+ * transformer.py:384-386).  h [M, 256] (hidden activations) and q [M, 256] (the MLP's output before the product) are
+ * stored for the backward launch.  table NULL: out = the MLP's output, q unused. */
+int fod_mlp2_mul_fwd(int dtype, const void* x, const void* w1, const float* b1, const void* w2, const float* b2,
+                     const void* table, int table_rows, void* h, void* q, void* out, int M, int D, fod_stream_t stream);
+/* Its backward in one launch: ds = dout * table[m % table_rows], dtable[m % table_rows] += dout * q (f32 [table_rows, 256],
+ * accumulated with atomics -- several launches may share one buffer), dh = (ds W2) gated by h > 0, dx = dh W1; w2_t / w1_t =
+ * the weights transposed as fod_gemm_nt takes them for input gradients.  ds and dh are stored (weight gradients). */
+int fod_mlp2_mul_bwd(int dtype, const void* dout, const void* table, int table_rows, const void* q, const void* h,
+                     const void* w2_t, const void* w1_t, void* ds, void* dh, void* dx, float* dtable, int M, int D,
+                     fod_stream_t stream);
 /* group_rows > 0 (rows % group_rows == 0): gamma / beta (and dgamma / dbeta) are [rows / group_rows, D] tables and rows
  * [g * group_rows, (g + 1) * group_rows) use entry g -- the same norm of several layers in one launch; 0: one [D] pair. */
 int fod_layernorm_fwd(int dtype, const void* x, const void* residual, int res_row_div, int res_row_mod,

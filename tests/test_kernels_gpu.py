@@ -1332,3 +1332,69 @@ def test_layernorm_grouped_parameter_tables(dtype, P, M, with_res):
         assert torch.equal(dx[sl], dx1)
         assert torch.allclose(dg[g], dg1, rtol=1e-5, atol=1e-5 * float(dg1.abs().max()) + 1e-6)
         assert torch.allclose(db[g], db1, rtol=1e-5, atol=1e-5 * float(db1.abs().max()) + 1e-6)
+
+
+@pytest.mark.parametrize("B,Mq", [(2, 128), (1, 128), (3, 100), (2, 7)])
+def test_fused_mlp2_mul_forward_backward(B, Mq):
+    """fod_mlp2_mul_fwd / _bwd (the decoder's query_scale MLP + the product with the sine embedding in one launch each way)
+    against the launches they replace (2 x fod_gemm_nt + fod_eltwise forward; multiply, GEMM with ReLU gate, GEMM backward):
+    every result within one bf16 ulp of its range (MFMA summation order), the table's f32 gradient against float64; then
+    through autograd -- three uses of one MLP on one table, as the decoder layers make them, with the shared gradient
+    accumulator -- against the unfused graph."""
+    from future_od.native import functional as Fn
+    import future_od.models.transformer as T
+    dtype = torch.bfloat16
+    M, D = B * Mq, 256
+    x = rnd((M, D), dtype, 101).to(DEV)
+    w1 = rnd((D, D), dtype, 102, scale=1.0 / 16).to(DEV)
+    w2 = rnd((D, D), dtype, 103, scale=1.0 / 16).to(DEV)
+    b1, b2 = (torch.randn(D) * 0.3).to(DEV), (torch.randn(D) * 0.3).to(DEV)
+    table = rnd((Mq, D), dtype, 104).to(DEV)
+    out, h, q = ops.mlp2_mul_fwd(x, w1, b1, w2, b2, table)
+    h_ref = ops.gemm_nt(x, w1, shift=b1, relu=True)
+    ulp = 2.0 ** -7
+    assert float((h.float() - h_ref.float()).abs().max()) <= ulp * float(h_ref.float().abs().max())
+    q_ref = ops.gemm_nt(h, w2, shift=b2)                           # (from the fused launch's own h: isolates the second product)
+    assert float((q.float() - q_ref.float()).abs().max()) <= ulp * float(q_ref.float().abs().max())
+    out_ref = ops.eltwise(L.EW_MUL, q, table, b_row_mod=Mq)
+    assert torch.equal(out, out_ref)
+    out_nt, h_nt, q_nt = ops.mlp2_mul_fwd(x, w1, b1, w2, b2, None)
+    assert q_nt is None and torch.equal(out_nt, q) and torch.equal(h_nt, h)
+    # backward
+    dout = rnd((M, D), dtype, 105).to(DEV)
+    w1t, w2t = w1.t().contiguous(), w2.t().contiguous()
+    dtab = torch.zeros(Mq, D, device=DEV)
+    ds, dh, dx = ops.mlp2_mul_bwd(dout, table, q, h, w2t, w1t, dtab)
+    ds_ref = ops.eltwise(L.EW_MUL, dout, table, b_row_mod=Mq)
+    assert torch.equal(ds, ds_ref)
+    dh_ref = ops.gemm_nt(ds, w2t, relu_mask=h)
+    assert float((dh.float() - dh_ref.float()).abs().max()) <= ulp * max(float(dh_ref.float().abs().max()), 1e-3)
+    dx_ref = ops.gemm_nt(dh, w1t)
+    assert float((dx.float() - dx_ref.float()).abs().max()) <= ulp * max(float(dx_ref.float().abs().max()), 1e-3)
+    dtab_ref = (dout.double() * q.double()).view(B, Mq, D).sum(0)
+    assert torch.allclose(dtab.double(), dtab_ref, rtol=1e-5, atol=1e-5 * float(dtab_ref.abs().max()))
+    # autograd, three uses sharing the table
+    mlp = T.MLP(D, D, D, 2).to(DEV)
+    gs = [rnd((M, D), dtype, 110 + i).to(DEV) for i in range(3)]
+    grads = []
+    for fused in (True, False):
+        for prm in mlp.parameters():
+            prm.grad = None
+        Fn.PREP.clear()
+        xs = [rnd((M, D), dtype, 120 + i).to(DEV).requires_grad_(True) for i in range(3)]
+        tb = table.clone().requires_grad_(True)
+        # each use depends on the previous one's result, as the decoder layers do: the first use's backward runs last
+        assert Fn.mlp2_mul_fits(xs[0], mlp, tb)
+        acc = Fn.TableGradAcc()
+        outs, prev = [], None
+        for i, xx in enumerate(xs):
+            xin = xx if prev is None else xx + 0.5 * prev
+            prev = (Fn.mlp2_mul(xin, mlp, tb, acc=acc, hands_on=(i == 0)) if fused
+                    else Fn.mul(mlp(xin), tb, b_row_mod=Mq))
+            outs.append(prev)
+        total = sum((o.float() * g.float()).sum() for o, g in zip(outs, gs))
+        total.backward()
+        grads.append([xx.grad for xx in xs] + [tb.grad] + [prm.grad.clone() for prm in mlp.parameters()])
+    for g1, g2 in zip(*grads):
+        err = float((g1.double() - g2.double()).norm() / g2.double().norm().clamp_min(1e-9))
+        assert err <= 1e-2, err
