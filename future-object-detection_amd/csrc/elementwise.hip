@@ -1,6 +1,8 @@
 // HBM-bound helpers of the path: layer normalisation (+residual), element-wise ops, layout / dtype
 // conversion, max pooling, positional tables, reference-point sine embedding, box-head finish.
 // All are one pass over their tensors; grids are capped and grid-strided (<= 2048 blocks x 256).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -326,6 +328,21 @@ FOD_DEVINL void multi_permute_body(const fod_permute_job& j, long chunk, float* 
     const unsigned tf = rest % tilesf, ig = rest / tilesf;
     if (ig >= dg) return;
     const unsigned f0 = tf * 32, c0 = t2 * 256;
+    if (df <= 16) {
+      // few indices along f (the 9 taps of a 3x3 convolution weight: half of the backbone's parameters, in both of their
+      // layouts): lanes walk (column, f) pairs with f fastest, so every lane reads and consecutive lanes read consecutive
+      // addresses wherever the source allows (OIHW -> [Cout][tap][Cin]: the whole [Cin][9] block is contiguous); with one
+      // lane per f index 23 of 32 lanes idled and a wave-load covered 72 bytes
+      for (unsigned e = tid; e < 256 * df; e += 256) {
+        const unsigned cc = e / df, ifx = e - cc * df;
+        const unsigned i2 = c0 + cc;
+        float v = 0.f;
+        const unsigned i1 = fast == 1 ? ifx : ig;
+        if (i2 < d2 && i1 < (unsigned)j.valid1 && i2 < (unsigned)j.valid2)
+          v = to_f32(src[(long)ig * sg + ifx + (long)i2 * j.s2]);
+        tile[ifx * 257 + cc] = v;
+      }
+    } else {
     // read: lane = index along f (contiguous in the source), 8 columns per pass
     const unsigned lf = tid & 31, lc = tid >> 5;
 #pragma unroll 4
@@ -336,6 +353,7 @@ FOD_DEVINL void multi_permute_body(const fod_permute_job& j, long chunk, float* 
       if (ifx < df && i2 < d2 && i1 < (unsigned)j.valid1 && i2 < (unsigned)j.valid2)
         v = to_f32(src[(long)ig * sg + ifx + (long)i2 * j.s2]);
       tile[lf * 257 + cc] = v;
+    }
     }
     __syncthreads();
     // write: lane = column (contiguous in the destination)
@@ -784,6 +802,16 @@ extern "C" int fod_layernorm_fwd(int dtype, const void* x, const void* residual,
   return FOD_OK;
 }
 
+// row groups a wave of the many-row layer-norm backward walks (FOD_LN_BWD_GROUPS; measured at the encoder's 14 500 rows)
+static int ln_bwd_groups() {
+  static const int v = [] {
+    const char* e = getenv("FOD_LN_BWD_GROUPS");
+    const int n = e ? atoi(e) : 4;
+    return n >= 1 && n <= 16 ? n : 4;
+  }();
+  return v;
+}
+
 extern "C" int fod_layernorm_bwd(int dtype, const void* dy, const void* xsum, const float* mean, const float* rstd,
                                  const float* gamma, void* dx, float* dgamma, float* dbeta, int rows, int D,
                                  int group_rows, hipStream_t stream) {
@@ -803,7 +831,7 @@ extern "C" int fod_layernorm_bwd(int dtype, const void* dy, const void* xsum, co
       hipLaunchKernelGGL((ln_bwd_kernel<T, DD, 64>), dim3(grid), dim3(256), 0, stream, (const T*)dy,          \
                          (const T*)xsum, mean, rstd, gamma, (T*)dx, dgamma, dbeta, rows, group_rows);         \
     } else {                                                                                                  \
-      int grid = grid_for(rows, 4 * (64 / LPR) * 4);    /* ~4 row groups per wave: fewer atomics on dgamma */  \
+      int grid = grid_for(rows, 4 * (64 / LPR) * ln_bwd_groups());  /* row groups per wave: fewer atomics */    \
       if (grid > 512) grid = 512;                                                                             \
       hipLaunchKernelGGL((ln_bwd_kernel<T, DD, LPR>), dim3(grid), dim3(256), 0, stream, (const T*)dy,         \
                          (const T*)xsum, mean, rstd, gamma, (T*)dx, dgamma, dbeta, rows, 0);                  \
