@@ -141,6 +141,10 @@ def _load():
         raise FodError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or future-object-detection_amd/build.sh). There is no fallback path.")
+    # torch first: it ships its own libamdhip64.so, and the device memory and streams these entry points are handed come
+    # from it.  Loaded the other way round (this module imported before torch, as __graft_entry__.build() does), the library
+    # binds to the system runtime instead and its first launch fails with "no ROCm-capable device is detected"
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     lib.fod_abi_version.restype = C.c_int
     lib.fod_abi_version.argtypes = []

@@ -1,16 +1,12 @@
 set -e
-o=gpurun_out/r03perm
-mkdir -p $o
-timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py tests/test_graph_gpu.py -m gpu -x -q > $o/test.log 2>&1 || { tail -40 $o/test.log; exit 1; }
-tail -2 $o/test.log
-for v in 4 2 1 4 2 1; do
-  FOD_LN_BWD_GROUPS=$v python bench.py --no-cpu-baseline --no-extras --no-roofline 2> $o/ab.err | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FOD_LN_BWD_GROUPS=$v', round(d['value'],2), round(d['ms_per_step'],3))" | tee -a $o/ab.txt
-done
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$o/kt -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > $GRAFT_REPO_ROOT/$o/kt.log 2>&1
-cd $GRAFT_REPO_ROOT
-grep -h -E "multi_permute3|ln_bwd|mlp2|multi_adamw" $(ls $o/kt/*/*kernel_stats.csv | head -1) | cut -c1-200 > $o/kstats.txt
-rm -rf $o/kt
-cat $o/kstats.txt
+tag=r03q
+o=gpurun_out/$tag
+bash tools/profile_round.sh $tag > gpurun_out/${tag}_profile.log 2>&1 || { tail -30 gpurun_out/${tag}_profile.log; exit 1; }
+tail -3 gpurun_out/${tag}_profile.log
+bash tools/trace_graph.sh ${tag}_trace > /dev/null 2>&1
+python tools/trace_summary_graph.py gpurun_out/${tag}_trace/kernel_trace.csv > gpurun_out/${tag}_trace/summary.txt 2>&1
+rm -f gpurun_out/${tag}_trace/kernel_trace.csv
+head -2 gpurun_out/${tag}_trace/summary.txt
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_gpu_tests.txt 2>&1 || { tail -40 gpurun_out/${tag}_gpu_tests.txt; exit 1; }
+tail -2 gpurun_out/${tag}_gpu_tests.txt
+python __graft_entry__.py smoke 2>&1 | tail -1
