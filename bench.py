@@ -72,7 +72,7 @@ _KERNEL_ENTRY = [
     (r"conv2d_fwd_kernel|conv_stem_fwd_kernel|stem_pool_kernel|nt_big_kernel(<|ILi)1|bottleneck_fused", "fod_conv2d_fwd"),
     (r"conv2d_dgrad|nt_big_kernel(<|ILi)[23]", "fod_conv2d_dgrad"),
     (r"tn_big_kernel|tn_reduce_kernel", "fod_conv2d_wgrad_acc"),
-    (r"gemm_nt_small_kernel|gemm_nt_kernel|gemm_nt_grouped|nt_big_kernel(<|ILi)0|linear_add_norm", "fod_gemm_nt"),
+    (r"gemm_nt_small_kernel|gemm_nt_kernel|gemm_nt_grouped|nt_big_kernel(<|ILi)0|linear_add_norm|mlp2_mul", "fod_gemm_nt"),
     (r"gemm_tn_multi_long", "fod_gemm_tn_multi_long"), (r"gemm_tn_multi", "fod_gemm_tn_multi"),
     (r"gemm_tn|colsum", "fod_gemm_tn_acc"),
     (r"attn_quant_fp8", "fod_attn_quant_fp8"), (r"attn_fwd_fp8", "fod_attn_fwd_fp8"),

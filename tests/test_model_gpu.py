@@ -388,6 +388,21 @@ def test_ctypes_fallback_binding_still_runs_the_model():
     assert out.returncode == 0 and "smoke ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_library_imported_before_torch_still_launches():
+    """`__graft_entry__.build()` imports future_od.native.lib BEFORE anything has imported torch; run in the same process,
+    `smoke()` then failed at its first launch with "no ROCm-capable device is detected": the library had bound to the
+    system HIP runtime, the tensors and streams came from the one torch ships.  The binding imports torch before it loads
+    the library; this runs the smoke step in a process that imports the binding first."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, __graft_entry__ as g; assert 'torch' not in sys.modules; import future_od.native.lib; "
+            "import runs._model; g.smoke()")
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "smoke ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 @pytest.mark.parametrize("use_mlp", [True, False])
 def test_imu_blocks_of_all_layers_at_once(use_mlp, monkeypatch):
     """Fn.imu_branch (ImuBranchFn: the one-key IMU blocks of all layers in a handful of batched launches) against the

@@ -14,7 +14,7 @@ ENTRY = [  # (substring of the kernel name, entry point)
     ("nt_big_kernel<3>", "fod_conv2d_dgrad"), ("conv_stem_fwd_kernel", "fod_conv2d_fwd"),
     ("stem_layout_kernel", "fod_clip_to_stem_layout"), ("lap_dev_kernel", "fod_lap_solve_batch_dev"),
     ("pack_targets_kernel", "fod_pack_targets"), ("attn_fwd_lds_kernel", "fod_attn_fwd"),
-    ("attn_quant_fp8", "fod_attn_quant_fp8"), ("attn_fwd_fp8", "fod_attn_fwd_fp8"), ("bottleneck_fused", "fod_conv2d_fwd"), ("stem_pool_kernel", "fod_conv2d_fwd"), ("linear_add_norm", "fod_gemm_nt"),
+    ("attn_quant_fp8", "fod_attn_quant_fp8"), ("attn_fwd_fp8", "fod_attn_fwd_fp8"), ("bottleneck_fused", "fod_conv2d_fwd"), ("stem_pool_kernel", "fod_conv2d_fwd"), ("linear_add_norm", "fod_gemm_nt"), ("mlp2_mul", "fod_gemm_nt"),
     ("gemm_tn_multi_long", "fod_gemm_tn_multi_long"),
     ("conv2d_fwd_kernel", "fod_conv2d_fwd"), ("conv2d_dgrad", "fod_conv2d_dgrad"),
     ("conv2d_wgrad_kernel", "fod_conv2d_wgrad_acc"), ("gemm_nt_small_kernel", "fod_gemm_nt"),
