@@ -29,12 +29,18 @@ namespace {
 
 using namespace fodnt;
 
-constexpr int BMB = 256, BNB = 128, BKB_EL = 64;
-constexpr int NSTAGE = 3;
-constexpr int STAGE_BYTES = (BMB + BNB) * ROW_BYTES;      // 48 KiB
-constexpr int A_DMA = BMB / 64, B_DMA = BNB / 64;          // DMA instructions per wave and tile (8 waves x 8 rows each)
-template <int MODE>
+constexpr int BMB = 256, BKB_EL = 64;
+constexpr int A_DMA = BMB / 64;                            // DMA instructions per wave and tile (8 waves x 8 rows each)
+// Two tile shapes: 256 x 128 with a three-stage ring (48 KiB per stage), and -- FOD_NT_BIG256 -- 256 x 256 with a two-stage
+// ring (64 KiB per stage: three would not fit the 160 KiB of LDS).  The stage loop of the 256 x 128 tile runs at the
+// L2 -> LDS rate (85 FLOP per staged byte at ~12 TB/s); the square tile stages 128 FLOP per byte.
+template <int MODE, int BNB, int NSTAGE>
 __global__ __launch_bounds__(512) void nt_big_kernel(const NtParams p) {
+  constexpr int STAGE_BYTES = (BMB + BNB) * ROW_BYTES;
+  constexpr int B_DMA = BNB / 64;
+  constexpr int N_DMA = A_DMA + B_DMA;                     // per wave and tile: the counted waits below
+  constexpr int NJ = BNB / 64;                             // 32-column fragments per wave (a wave owns 64 x BNB / 2)
+  static_assert((BNB == 128 && NSTAGE == 3) || (BNB == 256 && NSTAGE == 2), "tile shapes: 256 x 128 x 3 stages, 256 x 256 x 2");
   typedef __bf16 T;
   constexpr unsigned ESZ = 2;
   constexpr unsigned BKB = BKB_EL * ESZ;                  // 128 bytes of k per tile row
@@ -175,11 +181,11 @@ __global__ __launch_bounds__(512) void nt_big_kernel(const NtParams p) {
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -192,8 +198,8 @@ __global__ __launch_bounds__(512) void nt_big_kernel(const NtParams p) {
       __builtin_memcpy(&fa[i], &v, 16);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = wn * 64 + j * 32 + fr;
+    for (int j = 0; j < NJ; ++j) {
+      const int row = wn * (BNB / 2) + j * 32 + fr;
       const uint4 v = *reinterpret_cast<const uint4*>(b_s + lds_off(row, 2 * ks + fh));
       __builtin_memcpy(&fb[j], &v, 16);
     }
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(512) void nt_big_kernel(const NtParams p) {
   auto compute = [&](int stage) {
     const unsigned char* a_s = smem + stage * STAGE_BYTES;
     const unsigned char* b_s = a_s + BMB * ROW_BYTES;
-    Frag<T> fa[2][2], fb[2][2];
+    Frag<T> fa[2][2], fb[2][NJ];
     read_frags(a_s, b_s, 0, fa[0], fb[0]);
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -209,22 +215,34 @@ __global__ __launch_bounds__(512) void nt_big_kernel(const NtParams p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mma16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+        for (int j = 0; j < NJ; ++j) mma16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
     }
   };
 
+  // the ring holds NSTAGE - 1 tiles ahead of the one being consumed; every wait is COUNTED: it retires everything but the
+  // (NSTAGE - 2) * N_DMA requests of the youngest tiles in flight (6 for the three-stage ring, 0 for the two-stage one)
+  auto wait_landed = [&](auto with_lgkm) {
+    if constexpr (NSTAGE == 3) {
+      static_assert(N_DMA == 6, "vmcnt immediate");
+      if constexpr (decltype(with_lgkm)::value) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      if constexpr (decltype(with_lgkm)::value) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
   const int nkt = (p.K + BKB_EL - 1) / BKB_EL;
-  issue_tile(0);
-  issue_tile(1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // tile 0 has landed (this wave's six pieces of it)
+#pragma unroll
+  for (int t = 0; t < NSTAGE - 1; ++t) issue_tile(t);
+  wait_landed(std::false_type{});                       // tile 0 has landed (this wave's pieces of it)
   __builtin_amdgcn_s_barrier();                         // ... and everybody else's
-  int st_c = 0, st_i = 2;                               // stage being consumed / stage being filled
+  int st_c = 0, st_i = NSTAGE - 1;                      // stage being consumed / stage being filled
   for (int kt = 0; kt < nkt; ++kt) {
-    issue_tile(st_i);                                   // tile kt + 2 (zero fill past the end: the count stays 6)
+    issue_tile(st_i);                                   // tile kt + NSTAGE - 1 (zero fill past the end: the count never varies)
     compute(st_c);
-    // tile kt + 1 landed, tile kt + 2 stays in flight; lgkmcnt(0): this wave's fragment reads of stage st_c have
-    // RETURNED before the barrier after which another wave may request tile kt + 3 into that stage
-    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    // tile kt + 1 landed, younger tiles stay in flight; lgkmcnt(0): this wave's fragment reads of stage st_c have
+    // RETURNED before the barrier after which another wave may request a tile into that stage
+    wait_landed(std::true_type{});
     __builtin_amdgcn_s_barrier();
     st_c = st_c == NSTAGE - 1 ? 0 : st_c + 1;
     st_i = st_i == NSTAGE - 1 ? 0 : st_i + 1;
@@ -244,26 +262,22 @@ __global__ __launch_bounds__(512) void nt_big_kernel(const NtParams p) {
     const int wq = rem - hq * p.Wd;
     return ((long)img * p.out_H + 2 * hq + p.par_h) * p.out_W + 2 * wq + p.par_w;
   };
-  constexpr int CPR = BNB / 4;               // 4-column chunks per row (32)
-  constexpr int RPP = 512 / CPR;             // rows per pass (16)
-  constexpr int NPASS = BMB / RPP;           // 16
+  // The f32 tile goes over the ring in HALVES row halves (the 256 x 256 tile is 256 KiB, its ring 128)
+  constexpr int HALVES = (BMB * BNB * 4 > NSTAGE * STAGE_BYTES) ? 2 : 1;
+  constexpr int ROWS_H = BMB / HALVES;       // rows per half
+  constexpr int CPR = BNB / 4;               // 4-column chunks per row (32 / 64)
+  constexpr int RPP = 512 / CPR;             // rows per pass (16 / 8)
+  constexpr int NPASS = ROWS_H / RPP;        // 16
   constexpr int PB = 8;                      // passes per prefetch batch
   const int cq = tid % CPR, rq = tid / CPR;
   const int n = n0 + cq * 4;
   const int nc = min(n, p.N - 4);
   float* sC = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        sC[(wm * 64 + i * 32 + acc_row(r, lane)) * BNB + wn * 64 + j * 32 + fr] = acc[i][j][r];
   f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
   if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + nc);
   if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + nc);
-  __syncthreads();
   const bool full = m0 + BMB <= p.M && n0 + BNB <= p.N && !p.c_is_f32;
+  int mh = 0;                                // first tile row of the half in LDS
   auto rows_out = [&](auto has_res, auto do_relu, auto has_mask, auto is_full) {
 #pragma unroll
     for (int base = 0; base < NPASS; base += PB) {
@@ -271,7 +285,7 @@ __global__ __launch_bounds__(512) void nt_big_kernel(const NtParams p) {
       f32x4 v[PB];
 #pragma unroll
       for (int ps = 0; ps < PB; ++ps) {
-        const long m = out_row(min(m0 + rq + (base + ps) * RPP, p.M - 1));
+        const long m = out_row(min(m0 + mh + rq + (base + ps) * RPP, p.M - 1));
         if constexpr (decltype(has_res)::value) {
           const long rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
           rres[ps] = *reinterpret_cast<const bf16x4_t*>(Rp + rm * p.ldr + nc);
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(512) void nt_big_kernel(const NtParams p) {
           if constexpr (decltype(do_relu)::value) w[e] = fmaxf(w[e], 0.f);
           if constexpr (decltype(has_mask)::value) w[e] = ((float)rmsk[ps][e] > 0.f) ? w[e] : 0.f;
         }
-        const int mt = m0 + rq + (base + ps) * RPP;
+        const int mt = m0 + mh + rq + (base + ps) * RPP;
         if constexpr (!decltype(is_full)::value) {
           if (mt >= p.M || n >= p.N) continue;
         }
@@ -317,22 +331,55 @@ __global__ __launch_bounds__(512) void nt_big_kernel(const NtParams p) {
     else if (!R && L && K) rows_out(N_{}, Y{}, Y{}, is_full);
     else rows_out(Y{}, Y{}, Y{}, is_full);
   };
-  if (full) pick(Y{});
-  else pick(N_{});
+#pragma unroll
+  for (int h = 0; h < HALVES; ++h) {
+    mh = h * ROWS_H;
+    if (h > 0) __syncthreads();                          // the previous half has been read out of LDS
+    if (wm / (4 / HALVES) == h) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            sC[((wm % (4 / HALVES)) * 64 + i * 32 + acc_row(r, lane)) * BNB + wn * (BNB / 2) + j * 32 + fr] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (full) pick(Y{});
+    else pick(N_{});
+  }
 }
 
-template <int MODE>
+template <int MODE, int BNB, int NSTAGE>
 int launch_big(const NtParams& p, hipStream_t stream) {
   NtParams q = p;
   q.gy = ceil_div(p.M, BMB);
   q.gx = ceil_div(p.N, BNB);
-  static LdsLimitOnce lds_once;                     // one per MODE instantiation
-  const size_t lds = (size_t)NSTAGE * STAGE_BYTES;
-  if (int rc = fod_lds_limit_once(lds_once, reinterpret_cast<const void*>(&nt_big_kernel<MODE>), lds, "gemm_nt_big")) return rc;
+  static LdsLimitOnce lds_once;                     // one per instantiation
+  const size_t lds = (size_t)NSTAGE * (BMB + BNB) * ROW_BYTES;
+  if (int rc = fod_lds_limit_once(lds_once, reinterpret_cast<const void*>(&nt_big_kernel<MODE, BNB, NSTAGE>), lds, "gemm_nt_big")) return rc;
   const dim3 grid(q.gx * ((q.gy + 7) / 8 * 8));
-  hipLaunchKernelGGL((nt_big_kernel<MODE>), grid, dim3(512), lds, stream, q);
+  hipLaunchKernelGGL((nt_big_kernel<MODE, BNB, NSTAGE>), grid, dim3(512), lds, stream, q);
   FOD_LAUNCH_CHECK();
   return FOD_OK;
+}
+
+// The 256 x 256 tile where it fills the chip (N a multiple of 256, >= 200 square tiles): layer3's 3x3 convolutions at the
+// headline extent, 863 -> 1027 TFLOP/s forward, 831 -> 977 input gradient (profiles/r03q_square_tile.txt).  layer4 (14 500
+// rows: 114 square tiles for 256 CUs) stays on 256 x 128.  FOD_NT_BIG256: "0" = never, "2" = whenever N >= 256 (tests).
+bool big256_applies(const NtParams& p) {
+  const char* env = getenv("FOD_NT_BIG256");
+  if (env && env[0] == '0') return false;
+  if (p.N < 256) return false;
+  if (env && env[0] == '2') return true;
+  const long tiles = (long)ceil_div(p.M, BMB) * ceil_div(p.N, 256);
+  return p.N % 256 == 0 && tiles >= 200;
+}
+
+template <int MODE>
+int launch_big_pick(const NtParams& p, hipStream_t stream) {
+  if (big256_applies(p)) return launch_big<MODE, 256, 2>(p, stream);
+  return launch_big<MODE, 128, 3>(p, stream);
 }
 
 }  // namespace
@@ -353,17 +400,20 @@ bool big_applies(int mode, const NtParams& p) {
   if (mode != MODE_DENSE && (p.Cs % BKB_EL != 0 || p.K < BKB_EL)) return false;
   if (mode == MODE_DENSE && p.K % 8 != 0) return false;
   if (p.N % 4 != 0) return false;
-  const long tiles = (long)ceil_div(p.M, BMB) * ceil_div(p.N, BNB);
+  const long tiles = (long)ceil_div(p.M, BMB) * ceil_div(p.N, 128);
   if (env && env[0] == '2') return true;                      // always (tests)
+  const char* env_k = getenv("FOD_NT_BIG256_MINK");           // experiment knob: contraction depth from which the square tile is taken
+  const int mink256 = env_k ? atoi(env_k) : 128;
+  if (p.K >= mink256 && p.K < 1536 && big256_applies(p)) return true;
   return p.K >= 1536 && p.N >= 256 && tiles >= 200;
 }
 
 int launch_big_mode(int mode, const NtParams& p, hipStream_t stream) {
   switch (mode) {
-    case MODE_DENSE: return launch_big<MODE_DENSE>(p, stream);
-    case MODE_CONV: return launch_big<MODE_CONV>(p, stream);
-    case MODE_DGRAD: return launch_big<MODE_DGRAD>(p, stream);
-    case MODE_DGRAD_S2: return launch_big<MODE_DGRAD_S2>(p, stream);
+    case MODE_DENSE: return launch_big_pick<MODE_DENSE>(p, stream);
+    case MODE_CONV: return launch_big_pick<MODE_CONV>(p, stream);
+    case MODE_DGRAD: return launch_big_pick<MODE_DGRAD>(p, stream);
+    case MODE_DGRAD_S2: return launch_big_pick<MODE_DGRAD_S2>(p, stream);
     default: break;
   }
   fod_set_error("gemm_nt_big: unsupported mode %d", mode);

@@ -32,9 +32,10 @@ namespace {
 using namespace fodtn;
 
 constexpr int MS = 64;                          // reduction rows per stage
-constexpr int NSTAGE = 3;
-constexpr int STAGE_BYTES = MS * 384 * 2;       // BI + BJ = 384 bf16 columns per row: 48 KiB
-constexpr int N_DMA = 6;                        // DMA instructions per wave and stage (48 pieces of 1 KiB / 8 waves)
+// 128 x 256 / 256 x 128 tiles: three stages of 48 KiB (BI + BJ = 384 bf16 columns per row), 6 DMA instructions per wave and
+// stage; the 256 x 256 tile (FOD_TN_BIG256): two stages of 64 KiB (three do not fit the 160 KiB of LDS), 8 per wave and stage
+constexpr int tn_stages(int bi, int bj) { return bi + bj == 512 ? 2 : 3; }
+constexpr int tn_stage_bytes(int bi, int bj) { return MS * (bi + bj) * 2; }
 
 // fragment of 8 consecutive staged rows (natural kappa: row = 16 ks + 8 h + j) of one column: two transposing reads.
 // `a0` = byte address of (row 8h + q, this lane's 8-byte column group) inside the operand tile, swizzle applied;
@@ -53,11 +54,16 @@ FOD_DEVINL Frag<__bf16> tr_frag(const unsigned char* tile, int a0, int ks) {
 
 template <int MODE, int BI, int BJ>
 __global__ __launch_bounds__(512) void tn_big_kernel(const TnParams p) {
-  static_assert(BI + BJ == 384 && (BI == 128 || BI == 256), "tile shapes: 128 x 256 or 256 x 128");
+  static_assert((BI + BJ == 384 && (BI == 128 || BI == 256)) || (BI == 256 && BJ == 256),
+                "tile shapes: 128 x 256, 256 x 128 or 256 x 256");
+  constexpr int NSTAGE = tn_stages(BI, BJ), STAGE_BYTES = tn_stage_bytes(BI, BJ);
   constexpr int PG = BI * 2, PX = BJ * 2;               // LDS row pitches (bytes)
   constexpr int G_BYTES = MS * PG;
   constexpr int G_DMA = BI / 64, X_DMA = BJ / 64;       // pieces per wave and stage
-  constexpr int WJ = BJ / 64;                           // waves along j
+  constexpr int N_DMA = G_DMA + X_DMA;                  // 6 or 8: the counted waits below
+  constexpr int WTJ = BI * BJ / 8 / 64;                 // columns of a wave's 64-row tile: 64, or 128 for the square tile
+  constexpr int NB = WTJ / 32;                          // its 32-column fragments
+  constexpr int WJ = BJ / WTJ;                          // waves along j
   constexpr unsigned OOB = 0xFFFFFFF0u;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -181,28 +187,32 @@ __global__ __launch_bounds__(512) void tn_big_kernel(const TnParams p) {
     issue_piece(stage, std::integral_constant<int, 3>{});
     issue_piece(stage, std::integral_constant<int, 4>{});
     issue_piece(stage, std::integral_constant<int, 5>{});
+    if constexpr (N_DMA == 8) {
+      issue_piece(stage, std::integral_constant<int, 6>{});
+      issue_piece(stage, std::integral_constant<int, 7>{});
+    }
   };
 
   // ---- fragment addresses (loop-invariant part): lane -> (row 8h + q, columns colbase + 16 (g & 1) + 4 pp .. + 3)
   const int g4 = lane >> 4, idx = lane & 15;
   const int fh = g4 >> 1, fq = idx >> 2, fpp = idx & 3;
-  int ga[2], xa[2];
+  int ga[2], xa[NB];
 #pragma unroll
   for (int a = 0; a < 2; ++a) {
     const int col = wi * 64 + a * 32 + 16 * (g4 & 1) + 4 * fpp;
     ga[a] = (8 * fh + fq) * PG + ((((col >> 3) ^ (fq << 2)) << 4) | ((col & 7) * 2));
   }
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int col = wj * 64 + b * 32 + 16 * (g4 & 1) + 4 * fpp;
+  for (int b = 0; b < NB; ++b) {
+    const int col = wj * WTJ + b * 32 + 16 * (g4 & 1) + 4 * fpp;
     xa[b] = (8 * fh + fq) * PX + ((((col >> 3) ^ (fq << 2)) << 4) | ((col & 7) * 2));
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NB];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(512) void tn_big_kernel(const TnParams p) {
 #pragma unroll
     for (int a = 0; a < 2; ++a) fa[a] = tr_frag<PG>(g_s, ga[a], ks);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) fb[b] = tr_frag<PX>(x_s, xa[b], ks);
+    for (int b = 0; b < NB; ++b) fb[b] = tr_frag<PX>(x_s, xa[b], ks);
   };
   // One stage: 16 MFMAs per wave with the six DMA pieces of stage t + 2 issued BETWEEN them (two per k-step): with all
   // eight waves in lockstep behind the per-stage barrier, a burst of 48 pieces at the top of the stage kept the texture
@@ -232,20 +242,23 @@ __global__ __launch_bounds__(512) void tn_big_kernel(const TnParams p) {
   auto compute = [&](int stage, int fill) {
     const unsigned char* g_s = smem + stage * STAGE_BYTES;
     const unsigned char* x_s = g_s + G_BYTES;
-    Frag<__bf16> fa[2][2], fb[2][2];
+    Frag<__bf16> fa[2][2], fb[2][NB];
     read_frags(g_s, x_s, 0, fa[0], fb[0]);
 #pragma unroll
     for (int ks = 0; ks < MS / 16; ++ks) {
       if (ks + 1 < MS / 16) read_frags(g_s, x_s, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
-      mma16(fa[ks & 1][0], fb[ks & 1][0], acc[0][0]);
-      mma16(fa[ks & 1][0], fb[ks & 1][1], acc[0][1]);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) mma16(fa[ks & 1][0], fb[ks & 1][b], acc[0][b]);
       __builtin_amdgcn_sched_barrier(0);
       if (ks == 0) issue_piece(fill, std::integral_constant<int, 0>{});
       if (ks == 1) issue_piece(fill, std::integral_constant<int, 2>{});
       if (ks == 2) issue_piece(fill, std::integral_constant<int, 4>{});
+      if constexpr (N_DMA == 8) {
+        if (ks == 3) issue_piece(fill, std::integral_constant<int, 6>{});
+      }
       __builtin_amdgcn_sched_barrier(0);
-      mma16(fa[ks & 1][1], fb[ks & 1][0], acc[1][0]);
-      mma16(fa[ks & 1][1], fb[ks & 1][1], acc[1][1]);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) mma16(fa[ks & 1][1], fb[ks & 1][b], acc[1][b]);
       if (do_cs && (ks % WJ) == wj) {
         mma16(fa[ks & 1][0], fones, cs[0]);
         mma16(fa[ks & 1][1], fones, cs[1]);
@@ -254,22 +267,37 @@ __global__ __launch_bounds__(512) void tn_big_kernel(const TnParams p) {
       if (ks == 0) issue_piece(fill, std::integral_constant<int, 1>{});
       if (ks == 1) issue_piece(fill, std::integral_constant<int, 3>{});
       if (ks == 2) issue_piece(fill, std::integral_constant<int, 5>{});
+      if constexpr (N_DMA == 8) {
+        if (ks == 3) issue_piece(fill, std::integral_constant<int, 7>{});
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  static_assert(G_DMA + X_DMA == N_DMA, "the counted waits below assume 6 pieces per wave and stage");
-  issue_stage(0);
-  issue_stage(1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // stage 0 has landed (this wave's six pieces of it)
+  // The ring holds NSTAGE - 1 stages ahead of the one being consumed; every wait is COUNTED: it retires everything but the
+  // (NSTAGE - 2) * N_DMA requests of the youngest stage in flight (6 for the three-stage ring, none for the two-stage one)
+  static_assert(MS / 16 * 2 >= N_DMA, "a stage's pieces are issued two per k-step");
+  auto wait_landed = [&](auto with_lgkm) {
+    if constexpr (NSTAGE == 3) {
+      static_assert(NSTAGE != 3 || N_DMA == 6, "vmcnt immediate");
+      if constexpr (decltype(with_lgkm)::value) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      if constexpr (decltype(with_lgkm)::value) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+#pragma unroll
+  for (int t = 0; t < NSTAGE - 1; ++t) issue_stage(t);
+  wait_landed(std::false_type{});                       // stage 0 has landed (this wave's pieces of it)
   __builtin_amdgcn_s_barrier();                         // ... and everybody else's
   BLK_STAMP(1);
-  int st_c = 0, st_i = 2;
+  int st_c = 0, st_i = NSTAGE - 1;
   for (int t = 0; t < nst; ++t) {
-    compute(st_c, st_i);                                // ... and request stage t + 2 (zero fill past the end: the count stays 6)
-    // stage t + 1 landed, stage t + 2 stays in flight; lgkmcnt(0): this wave's fragment reads of stage st_c have
-    // RETURNED before the barrier after which another wave may request stage t + 3 into that slot
-    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    compute(st_c, st_i);                                // ... and request stage t + NSTAGE - 1 (zero fill past the end: the count never varies)
+    // stage t + 1 landed, a younger one stays in flight; lgkmcnt(0): this wave's fragment reads of stage st_c have
+    // RETURNED before the barrier after which another wave may request a stage into that slot
+    wait_landed(std::true_type{});
     __builtin_amdgcn_s_barrier();
     st_c = st_c == NSTAGE - 1 ? 0 : st_c + 1;
     st_i = st_i == NSTAGE - 1 ? 0 : st_i + 1;
@@ -305,16 +333,16 @@ __global__ __launch_bounds__(512) void tn_big_kernel(const TnParams p) {
     // short launch, and the sum no longer depends on the order in which blocks finish
     float* mine = p.ws + ((long)split * ntile + tile) * (BI * BJ);
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          mine[(wi * 64 + a * 32 + acc_row(r, lane)) * BJ + wj * 64 + b * 32 + (lane & 31)] = acc[a][b][r] * rs[a][r];
+          mine[(wi * 64 + a * 32 + acc_row(r, lane)) * BJ + wj * WTJ + b * 32 + (lane & 31)] = acc[a][b][r] * rs[a][r];
   } else {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int j = j0 + wj * 64 + b * 32 + (lane & 31);
+    for (int b = 0; b < NB; ++b) {
+      const int j = j0 + wj * WTJ + b * 32 + (lane & 31);
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -377,7 +405,7 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const TnParams p) {
 template <int MODE, int BI, int BJ>
 int launch_shape(const TnParams& p, hipStream_t stream) {
   static LdsLimitOnce lds_once;                    // one per instantiation
-  const size_t lds = (size_t)NSTAGE * STAGE_BYTES;
+  const size_t lds = (size_t)tn_stages(BI, BJ) * tn_stage_bytes(BI, BJ);
   if (int rc = fod_lds_limit_once(lds_once, reinterpret_cast<const void*>(&tn_big_kernel<MODE, BI, BJ>), lds, "gemm_tn_big")) return rc;
   const int ntile = p.ti * p.tj;
   const dim3 grid(p.xcd_order ? 8 * ceil_div((long)ntile * p.nsplit, 8) : ntile * p.nsplit);
@@ -402,13 +430,19 @@ int launch_shape(const TnParams& p, hipStream_t stream) {
 // to 256 as the tile count allows (each block pays ~13 us of f32 atomics for its 32 K-element tile whatever its share of
 // the rows); the tile shape with less padding wins, ties go to the one with more blocks in flight.
 struct Plan {
-  int bi, ti, tj, nsplit, m_per_split;
+  int bi, bj, ti, tj, nsplit, m_per_split;
 };
 Plan plan(const TnParams& p) {
   Plan best{};
   double best_cost = 1e30;
-  for (int shape = 0; shape < 2; ++shape) {
-    const int bi = shape == 0 ? 128 : 256, bj = 384 - bi;
+  // FOD_TN_BIG256: "1" = the 256 x 256 tile when both output dimensions are multiples of 256 and the reduction is long,
+  // "2" = whenever both are >= 256 (tests), unset / "0" = never
+  const char* env_sq = getenv("FOD_TN_BIG256");
+  const int sq = env_sq ? atoi(env_sq) : 0;
+  const bool square = (sq == 2 && p.N1 >= 256 && p.K2 >= 256) ||
+                      (sq == 1 && p.N1 % 256 == 0 && p.K2 % 256 == 0 && p.M >= 256 * 64);
+  for (int shape = square ? 2 : 0; shape < (square ? 3 : 2); ++shape) {
+    const int bi = shape == 0 ? 128 : 256, bj = shape == 2 ? 256 : 384 - bi;
     const int ti = ceil_div(p.N1, bi), tj = ceil_div(p.K2, bj);
     const int ntile = ti * tj;
     int s = 256 / ntile;
@@ -421,7 +455,7 @@ Plan plan(const TnParams& p) {
     const double cost = rounds * (mps / MS * 0.55 + 17.0);
     if (cost < best_cost) {
       best_cost = cost;
-      best = Plan{bi, ti, tj, ns, mps};
+      best = Plan{bi, bj, ti, tj, ns, mps};
     }
   }
   return best;
@@ -465,10 +499,14 @@ int launch_big_mode(int mode, const TnParams& p, hipStream_t stream) {
     q.m_per_split = ceil_div(ceil_div(p.M, s), MS) * MS;
     q.nsplit = ceil_div(p.M, q.m_per_split);
   }
-  if (mode == MODE_DENSE)
+  if (mode == MODE_DENSE) {
+    if (pl.bj == 256 && pl.bi == 256) return launch_shape<MODE_DENSE, 256, 256>(q, stream);
     return pl.bi == 128 ? launch_shape<MODE_DENSE, 128, 256>(q, stream) : launch_shape<MODE_DENSE, 256, 128>(q, stream);
-  if (mode == MODE_CONV)
+  }
+  if (mode == MODE_CONV) {
+    if (pl.bj == 256 && pl.bi == 256) return launch_shape<MODE_CONV, 256, 256>(q, stream);
     return pl.bi == 128 ? launch_shape<MODE_CONV, 128, 256>(q, stream) : launch_shape<MODE_CONV, 256, 128>(q, stream);
+  }
   fod_set_error("gemm_tn_big: unsupported mode %d", mode);
   return FOD_ERR_ARG;
 }

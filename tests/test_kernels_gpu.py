@@ -906,6 +906,72 @@ def test_big_tile_kernel_conv_modes(monkeypatch, case):
     check(dx, dx_ref, dtype, 4, f"big conv dgrad {case}")
 
 
+BIG256_CONV_CASES = [  # (Nimg, H, W, Cin, Cout, k, stride, pad): Cout and / or Cin >= 256 (the 256-wide tile needs N >= 256)
+    (2, 9, 12, 256, 512, 1, 2, 0),
+    (1, 20, 30, 128, 256, 3, 1, 1),
+    (2, 11, 13, 256, 320, 1, 1, 0),
+    (1, 15, 21, 320, 264, 3, 2, 1),
+    (1, 33, 47, 256, 256, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", BIG256_CONV_CASES)
+def test_big_square_tile_kernel_conv_modes(monkeypatch, case):
+    """The 256 x 256 tile of gemm_nt_big.hip (two-stage ring, epilogue in two row halves; FOD_NT_BIG256) on small shapes:
+    every conv mode with ragged tiles in both directions, full epilogue; bit-equal to the 128-row kernel (same k order)."""
+    monkeypatch.setenv("FOD_NT_BIG", "2")
+    monkeypatch.setenv("FOD_NT_BIG256", "2")
+    dtype = torch.bfloat16
+    n, h, w_, cin, cout, k, stride, pad = case
+    x = rnd((n, h, w_, cin), dtype, 1)
+    w = rnd((cout, k, k, cin), dtype, 2, scale=1.0 / math.sqrt(k * k * cin))
+    scale, shift = torch.rand(cout) + 0.5, torch.randn(cout) * 0.1
+    geom = ops.conv_geom(x.shape, cout, k, stride, pad)
+    x32 = x.float().requires_grad_(True)
+    w32 = w.float().requires_grad_(True)
+    y_lin = _conv_ref(x32, w32, stride, pad)
+    res = rnd((n, geom.Ho, geom.Wo, cout), dtype, 3)
+    y_ref = (y_lin * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res.float().permute(0, 3, 1, 2)).clamp(min=0)
+    args = dict(scale=scale.to(DEV), shift=shift.to(DEV), residual=res.to(DEV), relu=True)
+    y = ops.conv2d_fwd(x.to(DEV), w.to(DEV), geom, **args)
+    check(y, y_ref.permute(0, 2, 3, 1), dtype, 2, f"big256 conv fwd {case}")
+    monkeypatch.setenv("FOD_NT_BIG", "0")
+    y_small = ops.conv2d_fwd(x.to(DEV), w.to(DEV), geom, **args)
+    monkeypatch.setenv("FOD_NT_BIG", "2")
+    assert torch.equal(y, y_small), float((y.float() - y_small.float()).abs().max())
+    dy = rnd((n, geom.Ho, geom.Wo, cout), dtype, 4)
+    y_lin.backward(dy.float().permute(0, 3, 1, 2))
+    w_t = w.permute(3, 1, 2, 0).contiguous()
+    dres = rnd((n, h, w_, cin), dtype, 5)
+    mask = rnd((n, h, w_, cin), dtype, 6)
+    dx = ops.conv2d_dgrad(dy.to(DEV), w_t.to(DEV), geom, residual=dres.to(DEV), relu_mask=mask.to(DEV))
+    dx_ref = torch.where(mask.float() > 0, x32.grad + dres.float(), torch.zeros(()))
+    check(dx, dx_ref, dtype, 4, f"big256 conv dgrad {case}")
+    monkeypatch.setenv("FOD_NT_BIG", "0")
+    dx_small = ops.conv2d_dgrad(dy.to(DEV), w_t.to(DEV), geom, residual=dres.to(DEV), relu_mask=mask.to(DEV))
+    assert torch.equal(dx, dx_small), float((dx.float() - dx_small.float()).abs().max())
+
+
+@pytest.mark.parametrize("mnk", [(300, 256, 128), (1000, 264, 72), (257, 512, 256), (4097, 260, 64), (515, 768, 1536)])
+def test_big_square_tile_kernel_dense(monkeypatch, mnk):
+    monkeypatch.setenv("FOD_NT_BIG", "2")
+    monkeypatch.setenv("FOD_NT_BIG256", "2")
+    monkeypatch.setenv("FOD_NT_SMALL", "0")
+    dtype = torch.bfloat16
+    M, N, K = mnk
+    a, b = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2)
+    shift = torch.randn(N)
+    res = rnd((50, N), dtype, 3)
+    mask = rnd((M, N), dtype, 4)
+    acc = (a.float() @ b.float().t()) + shift + res.float().repeat(M // 50 + 1, 1)[:M]
+    ref = torch.where(mask.float() > 0, acc.clamp(min=0), torch.zeros(()))
+    out = ops.gemm_nt(a.to(DEV), b.to(DEV), shift=shift.to(DEV), residual=res.to(DEV), residual_row_mod=50, relu=True,
+                      relu_mask=mask.to(DEV))
+    check(out, ref, dtype, math.sqrt(K), f"big256 dense {mnk}")
+    out32 = ops.gemm_nt(a.to(DEV), b.to(DEV), shift=shift.to(DEV), out_f32=True)
+    check(out32, a.float() @ b.float().t() + shift, dtype, math.sqrt(K), f"big256 dense f32 out {mnk}")
+
+
 @pytest.mark.parametrize("mnk", [(300, 128, 128), (1000, 40, 72), (257, 132, 256), (513, 64, 96), (4097, 8, 64)])
 def test_big_tile_kernel_dense(monkeypatch, mnk):
     monkeypatch.setenv("FOD_NT_BIG", "2")
@@ -979,6 +1045,63 @@ def test_tn_big_kernel_dense(monkeypatch, mnk, splits):
     ops.gemm_tn_acc(g.to(DEV), x.to(DEV), dw2, colsum=cs, zeroed=True)
     check(dw2, g.float().t() @ x.float(), dtype, math.sqrt(M), f"tn big {mnk} zeroed")
     check(cs, g.float().sum(0), torch.float32, math.sqrt(M), "tn big colsum")
+
+
+@pytest.mark.parametrize("splits", [0, 3, 8])
+@pytest.mark.parametrize("mnk", [(777, 264, 296), (3000, 384, 520), (130, 256, 256), (64, 512, 256), (2111, 256, 768),
+                                 (9000, 520, 264)])
+def test_tn_big_square_tile_dense(monkeypatch, mnk, splits):
+    """The 256 x 256 tile of gemm_tn_big.hip (two-stage ring, 8 DMA pieces per wave and stage; FOD_TN_BIG256=2 takes it
+    whenever both output dimensions are >= 256): ragged tiles, M-splits with partial tiles and with atomics (gemm_tn_acc
+    hands the workspace over from 8192 rows on), row scales, accumulation, the fused column sums."""
+    monkeypatch.setenv("FOD_TN_BIG", "2")
+    monkeypatch.setenv("FOD_TN_BIG256", "2")
+    monkeypatch.setenv("FOD_TN_SMALL", "0")
+    if splits:
+        monkeypatch.setenv("FOD_TN_BIG_SPLITS", str(splits))
+    dtype = torch.bfloat16
+    M, N1, K2 = mnk
+    g, x = rnd((M, N1), dtype, 1), rnd((M, K2), dtype, 2)
+    rs = torch.rand(N1) + 0.5
+    dw0 = torch.randn(N1, K2)
+    ref = dw0 + (g.float().t() @ x.float()) * rs[:, None]
+    dw = dw0.clone().to(DEV)
+    ops.gemm_tn_acc(g.to(DEV), x.to(DEV), dw, row_scale=rs.to(DEV))
+    check(dw, ref, dtype, math.sqrt(M), f"tn big square {mnk}")
+    dw2, cs = torch.zeros(N1, K2, device=DEV), torch.zeros(N1, device=DEV)
+    ops.gemm_tn_acc(g.to(DEV), x.to(DEV), dw2, colsum=cs, zeroed=True)
+    check(dw2, g.float().t() @ x.float(), dtype, math.sqrt(M), f"tn big square {mnk} zeroed")
+    check(cs, g.float().sum(0), torch.float32, math.sqrt(M), "tn big square colsum")
+
+
+TN_BIG_SQUARE_CONV_CASES = [(2, 57, 100, 256, 256, 3, 1, 1), (2, 9, 12, 256, 512, 1, 2, 0), (1, 33, 47, 256, 264, 3, 1, 1),
+                            (3, 20, 30, 320, 256, 1, 1, 0), (1, 15, 21, 256, 256, 3, 2, 1)]
+
+
+@pytest.mark.parametrize("splits", [0, 5])
+@pytest.mark.parametrize("case", TN_BIG_SQUARE_CONV_CASES)
+def test_tn_big_square_tile_conv(monkeypatch, case, splits):
+    dtype = torch.bfloat16
+    n, h, w_, cin, cout, k, stride, pad = case
+    x = rnd((n, h, w_, cin), dtype, 1)
+    geom = ops.conv_geom(x.shape, cout, k, stride, pad)
+    dy = rnd((n, geom.Ho, geom.Wo, cout), dtype, 4)
+    x32 = x.float().permute(0, 3, 1, 2)
+    w32 = torch.zeros(cout, cin, k, k, requires_grad=True)
+    F.conv2d(x32, w32, None, stride, pad).backward(dy.float().permute(0, 3, 1, 2))
+    rs = torch.rand(cout) + 0.5
+    ref = (w32.grad * rs.view(-1, 1, 1, 1)).permute(0, 2, 3, 1)
+    monkeypatch.setenv("FOD_TN_BIG", "2")
+    monkeypatch.setenv("FOD_TN_BIG256", "2")
+    if splits:
+        monkeypatch.setenv("FOD_TN_BIG_SPLITS", str(splits))
+    dw = torch.zeros((cout, k, k, cin), device=DEV)
+    ops.conv2d_wgrad_acc(dy.to(DEV), x.to(DEV), dw, geom, row_scale=rs.to(DEV))
+    check(dw, ref, dtype, math.sqrt(n * geom.Ho * geom.Wo), f"tn big square conv wgrad {case}")
+    monkeypatch.setenv("FOD_TN_BIG256", "0")
+    dw_rect = torch.zeros((cout, k, k, cin), device=DEV)
+    ops.conv2d_wgrad_acc(dy.to(DEV), x.to(DEV), dw_rect, geom, row_scale=rs.to(DEV))
+    check(dw, dw_rect, torch.float32, math.sqrt(n * geom.Ho * geom.Wo) * 8, "square vs 128 x 256 tile (f32 summation order only)")
 
 
 TN_BIG_CONV_CASES = BIG_CONV_CASES + [(2, 17, 23, 8, 64, 7, 2, 3), (1, 29, 50, 32, 40, 3, 1, 1), (2, 57, 100, 256, 256, 3, 1, 1),

@@ -10,8 +10,8 @@ import collections, csv, glob, json, re, sys
 
 ENTRY = [  # (substring of the kernel name, entry point)
     ("tn_big_kernel<1", "fod_conv2d_wgrad_acc"), ("tn_big_kernel<0", "fod_gemm_tn_acc"), ("tn_reduce_kernel", "fod_conv2d_wgrad_acc"),
-    ("nt_big_kernel<0>", "fod_gemm_nt"), ("nt_big_kernel<1>", "fod_conv2d_fwd"), ("nt_big_kernel<2>", "fod_conv2d_dgrad"),
-    ("nt_big_kernel<3>", "fod_conv2d_dgrad"), ("conv_stem_fwd_kernel", "fod_conv2d_fwd"),
+    ("nt_big_kernel<0", "fod_gemm_nt"), ("nt_big_kernel<1", "fod_conv2d_fwd"), ("nt_big_kernel<2", "fod_conv2d_dgrad"),
+    ("nt_big_kernel<3", "fod_conv2d_dgrad"), ("conv_stem_fwd_kernel", "fod_conv2d_fwd"),
     ("stem_layout_kernel", "fod_clip_to_stem_layout"), ("lap_dev_kernel", "fod_lap_solve_batch_dev"),
     ("pack_targets_kernel", "fod_pack_targets"), ("attn_fwd_lds_kernel", "fod_attn_fwd"),
     ("attn_quant_fp8", "fod_attn_quant_fp8"), ("attn_fwd_fp8", "fod_attn_fwd_fp8"), ("bottleneck_fused", "fod_conv2d_fwd"), ("stem_pool_kernel", "fod_conv2d_fwd"), ("linear_add_norm", "fod_gemm_nt"), ("mlp2_mul", "fod_gemm_nt"),
