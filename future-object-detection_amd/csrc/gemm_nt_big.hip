@@ -405,7 +405,9 @@ bool big_applies(int mode, const NtParams& p) {
   const char* env_k = getenv("FOD_NT_BIG256_MINK");           // experiment knob: contraction depth from which the square tile is taken
   const int mink256 = env_k ? atoi(env_k) : 128;
   if (p.K >= mink256 && p.K < 1536 && big256_applies(p)) return true;
-  return p.K >= 1536 && p.N >= 256 && tiles >= 200;
+  const char* env_rk = getenv("FOD_NT_BIG_MINK");             // experiment knobs for the 256 x 128 tile's domain
+  const char* env_rn = getenv("FOD_NT_BIG_MINN");
+  return p.K >= (env_rk ? atoi(env_rk) : 1536) && p.N >= (env_rn ? atoi(env_rn) : 256) && tiles >= 200;
 }
 
 int launch_big_mode(int mode, const NtParams& p, hipStream_t stream) {

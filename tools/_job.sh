@@ -1,10 +1,12 @@
 set -e
-o=gpurun_out/r03sq
-mkdir -p $o
-timeout -k 10 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py tests/test_fullsize_oracle_gpu.py tests/test_fullsize_gpu.py tests/test_configs_gpu.py tests/test_graph_gpu.py -m gpu -x -q > $o/test_all.log 2>&1 || { tail -40 $o/test_all.log; exit 1; }
-tail -2 $o/test_all.log
-for v in 0 1 0 1 0 1; do
-  FOD_NT_BIG256=$v python bench.py --no-cpu-baseline --no-extras --no-roofline --steps 30 --warmup 5 2> $o/ab.err | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FOD_NT_BIG256=$v', round(d['value'],2), round(d['ms_per_step'],3))" | tee -a $o/ab3.txt
-done
+tag=r03r
+o=gpurun_out/$tag
+bash tools/profile_round.sh $tag > gpurun_out/${tag}_profile.log 2>&1 || { tail -30 gpurun_out/${tag}_profile.log; exit 1; }
+tail -3 gpurun_out/${tag}_profile.log
+bash tools/trace_graph.sh ${tag}_trace > /dev/null 2>&1
+python tools/trace_summary_graph.py gpurun_out/${tag}_trace/kernel_trace.csv > gpurun_out/${tag}_trace/summary.txt 2>&1
+rm -f gpurun_out/${tag}_trace/kernel_trace.csv
+head -2 gpurun_out/${tag}_trace/summary.txt
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_gpu_tests.txt 2>&1 || { tail -40 gpurun_out/${tag}_gpu_tests.txt; exit 1; }
+tail -2 gpurun_out/${tag}_gpu_tests.txt
+python __graft_entry__.py smoke 2>&1 | tail -1
