@@ -34,7 +34,10 @@ constexpr int A_DMA = BMB / 64;                            // DMA instructions p
 // Two tile shapes: 256 x 128 with a three-stage ring (48 KiB per stage), and -- FOD_NT_BIG256 -- 256 x 256 with a two-stage
 // ring (64 KiB per stage: three would not fit the 160 KiB of LDS).  The stage loop of the 256 x 128 tile runs at the
 // L2 -> LDS rate (85 FLOP per staged byte at ~12 TB/s); the square tile stages 128 FLOP per byte.
-template <int MODE, int BNB, int NSTAGE>
+// ILV: the DMA requests of the tile being fetched are issued BETWEEN the MFMAs of the tile being consumed (two per k-step)
+// instead of in one burst before them -- the eight waves run in lockstep behind the per-tile barrier, so a burst is a
+// stretch in which no wave has matrix work to issue (gemm_tn_big.hip measured the same effect)
+template <int MODE, int BNB, int NSTAGE, bool ILV>
 __global__ __launch_bounds__(512) void nt_big_kernel(const NtParams p) {
   constexpr int STAGE_BYTES = (BMB + BNB) * ROW_BYTES;
   constexpr int B_DMA = BNB / 64;
@@ -132,7 +135,13 @@ __global__ __launch_bounds__(512) void nt_big_kernel(const NtParams p) {
   if (MODE == MODE_DGRAD_S2) tap_kb = (unsigned)((p.r_first * p.kw + p.s_first) * p.Cs) * ESZ;
   int next_kt = 0;                                   // tile the walk stands at
 
-  auto issue_tile = [&](int stage) {
+  struct TileCtx {
+    int kt, r, s;
+    unsigned kbyte, toff, kb, sA, sB;
+    bool tile_in;
+  };
+  // the walk advances by one tile; what the tile's pieces need is returned
+  auto begin_tile = [&](int stage) {
     const int kt = next_kt++;
     const unsigned kbyte = (unsigned)kt * BKB;       // byte offset of the tile inside a dense row
     const int r = tap_r, s = tap_s;
@@ -158,27 +167,49 @@ __global__ __launch_bounds__(512) void nt_big_kernel(const NtParams p) {
     const unsigned sA = lds0 + (unsigned)(stage * STAGE_BYTES + wave * 1024);
     const unsigned sB = sA + BMB * ROW_BYTES;
     const bool tile_in = kt * BKB_EL < p.K;
-#pragma unroll
-    for (int i = 0; i < A_DMA; ++i) {
+    return TileCtx{kt, r, s, kbyte, toff, kb, sA, sB, tile_in};
+  };
+  // piece pc of a tile: this wave's A pieces 0 .. A_DMA - 1, then its B pieces
+  auto issue_piece = [&](const TileCtx& c, auto pc_) {
+    constexpr int pc = decltype(pc_)::value;
+    if constexpr (pc < A_DMA) {
+      constexpr int i = pc;
       unsigned off;
       if (MODE == MODE_DENSE) {
         // K % 8 == 0: a 16-byte chunk is all in or all out
-        const bool kin = (int)(kt * BKB_EL + (a_cc[i] >> 1)) < p.K;
-        off = (kin && a_base[i] != OOB) ? a_base[i] + kbyte : OOB;
+        const bool kin = (int)(c.kt * BKB_EL + (a_cc[i] >> 1)) < p.K;
+        off = (kin && a_base[i] != OOB) ? a_base[i] + c.kbyte : OOB;
       } else {
-        const int hs = MODE == MODE_CONV ? a_h[i] + r : a_h[i] - r;
-        const int ws = MODE == MODE_CONV ? a_w[i] + s : a_w[i] - s;
-        const bool ok = tile_in && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
-        off = ok ? (MODE == MODE_CONV ? a_base[i] + toff : a_base[i] - toff) : OOB;
+        const int hs = MODE == MODE_CONV ? a_h[i] + c.r : a_h[i] - c.r;
+        const int ws = MODE == MODE_CONV ? a_w[i] + c.s : a_w[i] - c.s;
+        const bool ok = c.tile_in && (unsigned)hs < (unsigned)p.Hs && (unsigned)ws < (unsigned)p.Ws;
+        off = ok ? (MODE == MODE_CONV ? a_base[i] + c.toff : a_base[i] - c.toff) : OOB;
       }
-      dma16(rsA, sA + i * 8192, off);
+      dma16(rsA, c.sA + i * 8192, off);
+    } else if constexpr (pc < A_DMA + B_DMA) {
+      constexpr int i = pc - A_DMA;
+      const bool kin = MODE == MODE_DENSE ? (int)(c.kt * BKB_EL + (b_cc[i] >> 1)) < p.K : c.tile_in;
+      const unsigned off = (kin && b_base[i] != OOB) ? b_base[i] + c.kb : OOB;
+      dma16(rsB, c.sB + i * 8192, off);
     }
+  };
+  auto issue_idx = [&](const TileCtx& c, int idx) {      // idx is a constant after unrolling
+    switch (idx) {
+      case 0: issue_piece(c, std::integral_constant<int, 0>{}); break;
+      case 1: issue_piece(c, std::integral_constant<int, 1>{}); break;
+      case 2: issue_piece(c, std::integral_constant<int, 2>{}); break;
+      case 3: issue_piece(c, std::integral_constant<int, 3>{}); break;
+      case 4: issue_piece(c, std::integral_constant<int, 4>{}); break;
+      case 5: issue_piece(c, std::integral_constant<int, 5>{}); break;
+      case 6: issue_piece(c, std::integral_constant<int, 6>{}); break;
+      case 7: issue_piece(c, std::integral_constant<int, 7>{}); break;
+      default: break;
+    }
+  };
+  auto issue_tile = [&](int stage) {
+    const TileCtx c = begin_tile(stage);
 #pragma unroll
-    for (int i = 0; i < B_DMA; ++i) {
-      const bool kin = MODE == MODE_DENSE ? (int)(kt * BKB_EL + (b_cc[i] >> 1)) < p.K : tile_in;
-      const unsigned off = (kin && b_base[i] != OOB) ? b_base[i] + kb : OOB;
-      dma16(rsB, sB + i * 8192, off);
-    }
+    for (int idx = 0; idx < N_DMA; ++idx) issue_idx(c, idx);
   };
 
   f32x16 acc[2][NJ];
@@ -204,7 +235,8 @@ __global__ __launch_bounds__(512) void nt_big_kernel(const NtParams p) {
       __builtin_memcpy(&fb[j], &v, 16);
     }
   };
-  auto compute = [&](int stage) {
+  static_assert(2 * KSTEPS >= N_DMA, "a tile's pieces are issued two per k-step");
+  auto compute = [&](int stage, const TileCtx& fill) {
     const unsigned char* a_s = smem + stage * STAGE_BYTES;
     const unsigned char* b_s = a_s + BMB * ROW_BYTES;
     Frag<T> fa[2][2], fb[2][NJ];
@@ -213,9 +245,15 @@ __global__ __launch_bounds__(512) void nt_big_kernel(const NtParams p) {
     for (int ks = 0; ks < KSTEPS; ++ks) {
       if (ks + 1 < KSTEPS) read_frags(a_s, b_s, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) mma16(fa[ks & 1][i], fb[ks & 1][j], acc[i][j]);
+        if constexpr (ILV) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_idx(fill, 2 * ks + i);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
   };
 
@@ -238,8 +276,12 @@ __global__ __launch_bounds__(512) void nt_big_kernel(const NtParams p) {
   __builtin_amdgcn_s_barrier();                         // ... and everybody else's
   int st_c = 0, st_i = NSTAGE - 1;                      // stage being consumed / stage being filled
   for (int kt = 0; kt < nkt; ++kt) {
-    issue_tile(st_i);                                   // tile kt + NSTAGE - 1 (zero fill past the end: the count never varies)
-    compute(st_c);
+    const TileCtx fill = begin_tile(st_i);              // tile kt + NSTAGE - 1 (zero fill past the end: the count never varies)
+    if constexpr (!ILV) {
+#pragma unroll
+      for (int idx = 0; idx < N_DMA; ++idx) issue_idx(fill, idx);
+    }
+    compute(st_c, fill);
     // tile kt + 1 landed, younger tiles stay in flight; lgkmcnt(0): this wave's fragment reads of stage st_c have
     // RETURNED before the barrier after which another wave may request a tile into that stage
     wait_landed(std::true_type{});
@@ -350,18 +392,29 @@ __global__ __launch_bounds__(512) void nt_big_kernel(const NtParams p) {
   }
 }
 
+template <int MODE, int BNB, int NSTAGE, bool ILV>
+int launch_big_ilv(const NtParams& q, hipStream_t stream) {
+  static LdsLimitOnce lds_once;                     // one per instantiation
+  const size_t lds = (size_t)NSTAGE * (BMB + BNB) * ROW_BYTES;
+  if (int rc = fod_lds_limit_once(lds_once, reinterpret_cast<const void*>(&nt_big_kernel<MODE, BNB, NSTAGE, ILV>), lds, "gemm_nt_big")) return rc;
+  const dim3 grid(q.gx * ((q.gy + 7) / 8 * 8));
+  hipLaunchKernelGGL((nt_big_kernel<MODE, BNB, NSTAGE, ILV>), grid, dim3(512), lds, stream, q);
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
+}
+
 template <int MODE, int BNB, int NSTAGE>
 int launch_big(const NtParams& p, hipStream_t stream) {
   NtParams q = p;
   q.gy = ceil_div(p.M, BMB);
   q.gx = ceil_div(p.N, BNB);
-  static LdsLimitOnce lds_once;                     // one per instantiation
-  const size_t lds = (size_t)NSTAGE * (BMB + BNB) * ROW_BYTES;
-  if (int rc = fod_lds_limit_once(lds_once, reinterpret_cast<const void*>(&nt_big_kernel<MODE, BNB, NSTAGE>), lds, "gemm_nt_big")) return rc;
-  const dim3 grid(q.gx * ((q.gy + 7) / 8 * 8));
-  hipLaunchKernelGGL((nt_big_kernel<MODE, BNB, NSTAGE>), grid, dim3(512), lds, stream, q);
-  FOD_LAUNCH_CHECK();
-  return FOD_OK;
+  // Interleaved requests pay with the three-stage ring (256 x 128: layer4's 3x3 convolutions 871 -> 910 TFLOP/s) and COST
+  // with the two-stage one (256 x 256: 967 -> 881 -- the tile requested during this one's MFMAs must have landed by their
+  // end, so it is requested as early as possible).  FOD_NT_BIG_ILV=0/1 forces either (profiles/r03r_nt_interleave.txt)
+  const char* env = getenv("FOD_NT_BIG_ILV");
+  const bool ilv = env ? env[0] != '0' : NSTAGE == 3;
+  if (!ilv) return launch_big_ilv<MODE, BNB, NSTAGE, false>(q, stream);
+  return launch_big_ilv<MODE, BNB, NSTAGE, true>(q, stream);
 }
 
 // The 256 x 256 tile where it fills the chip (N a multiple of 256, >= 200 square tiles): layer3's 3x3 convolutions at the

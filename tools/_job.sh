@@ -1,12 +1,13 @@
 set -e
-tag=r03r
-o=gpurun_out/$tag
-bash tools/profile_round.sh $tag > gpurun_out/${tag}_profile.log 2>&1 || { tail -30 gpurun_out/${tag}_profile.log; exit 1; }
-tail -3 gpurun_out/${tag}_profile.log
-bash tools/trace_graph.sh ${tag}_trace > /dev/null 2>&1
-python tools/trace_summary_graph.py gpurun_out/${tag}_trace/kernel_trace.csv > gpurun_out/${tag}_trace/summary.txt 2>&1
-rm -f gpurun_out/${tag}_trace/kernel_trace.csv
-head -2 gpurun_out/${tag}_trace/summary.txt
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_gpu_tests.txt 2>&1 || { tail -40 gpurun_out/${tag}_gpu_tests.txt; exit 1; }
-tail -2 gpurun_out/${tag}_gpu_tests.txt
-python __graft_entry__.py smoke 2>&1 | tail -1
+o=gpurun_out/r03ilv
+mkdir -p $o
+timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "big_" > $o/test.log 2>&1 || { tail -40 $o/test.log; exit 1; }
+tail -2 $o/test.log
+FOD_NT_BIG_ILV=0 timeout -k 10 300 python tools/bench_ops.py conv > $o/c_ilv0.txt 2>&1
+FOD_NT_BIG_ILV=1 timeout -k 10 300 python tools/bench_ops.py conv > $o/c_ilv1.txt 2>&1
+paste <(grep -E "^layer[34]" $o/c_ilv0.txt | awk '{print $1, $2, $9, $10}') <(grep -E "^layer[34]" $o/c_ilv1.txt | awk '{print $9, $10}')
+for v in 0 1 0 1; do
+  FOD_NT_BIG_ILV=$v python bench.py --no-cpu-baseline --no-extras --no-roofline --steps 30 --warmup 5 2> $o/ab.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FOD_NT_BIG_ILV=$v', round(d['value'],2), round(d['ms_per_step'],3))" | tee -a $o/ab.txt
+done
