@@ -457,7 +457,9 @@ bool big_applies(int mode, const NtParams& p) {
   if (env && env[0] == '2') return true;                      // always (tests)
   const char* env_k = getenv("FOD_NT_BIG256_MINK");           // experiment knob: contraction depth from which the square tile is taken
   const int mink256 = env_k ? atoi(env_k) : 128;
-  if (p.K >= mink256 && p.K < 1536 && big256_applies(p)) return true;
+  // (convolution modes only: the encoder's 14 500 x 2048 x 256 GEMMs took 37.6 us on the square tile against 30.3 on the
+  // 128-row kernel -- four k-tiles per block do not pay for the two-pass epilogue)
+  if (mode != MODE_DENSE && p.K >= mink256 && p.K < 1536 && big256_applies(p)) return true;
   const char* env_rk = getenv("FOD_NT_BIG_MINK");             // experiment knobs for the 256 x 128 tile's domain
   const char* env_rn = getenv("FOD_NT_BIG_MINN");
   return p.K >= (env_rk ? atoi(env_rk) : 1536) && p.N >= (env_rn ? atoi(env_rn) : 256) && tiles >= 200;
