@@ -333,30 +333,63 @@ FOD_DEVINL void multi_permute_body(const fod_permute_job& j, long chunk, float* 
       // layouts): lanes walk (column, f) pairs with f fastest, so every lane reads and consecutive lanes read consecutive
       // addresses wherever the source allows (OIHW -> [Cout][tap][Cin]: the whole [Cin][9] block is contiguous); with one
       // lane per f index 23 of 32 lanes idled and a wave-load covered 72 bytes
-      for (unsigned e = tid; e < 256 * df; e += 256) {
+      // (all loads of the thread requested before the first LDS write: with four in flight a block went through its
+      // tile in eight dependent rounds of memory latency, and LDS lets only ~4 blocks run per CU)
+      TS v[16];
+#pragma unroll
+      for (unsigned k = 0; k < 16; ++k) {
+        const unsigned e = tid + 256 * k;
         const unsigned cc = e / df, ifx = e - cc * df;
         const unsigned i2 = c0 + cc;
-        float v = 0.f;
         const unsigned i1 = fast == 1 ? ifx : ig;
-        if (i2 < d2 && i1 < (unsigned)j.valid1 && i2 < (unsigned)j.valid2)
-          v = to_f32(src[(long)ig * sg + ifx + (long)i2 * j.s2]);
-        tile[ifx * 257 + cc] = v;
+        const bool ok = k < df && i2 < d2 && i1 < (unsigned)j.valid1 && i2 < (unsigned)j.valid2;
+        v[k] = src[ok ? (long)ig * sg + ifx + (long)i2 * j.s2 : 0];
+        if (!ok) v[k] = from_f32<TS>(0.f);
+      }
+#pragma unroll
+      for (unsigned k = 0; k < 16; ++k) {
+        const unsigned e = tid + 256 * k;
+        const unsigned cc = e / df, ifx = e - cc * df;
+        if (k < df) tile[ifx * 257 + cc] = to_f32(v[k]);
       }
     } else {
-    // read: lane = index along f (contiguous in the source), 8 columns per pass
+    // read: lane = index along f (contiguous in the source), 8 columns per pass; all 32 loads requested up front
     const unsigned lf = tid & 31, lc = tid >> 5;
-#pragma unroll 4
-    for (unsigned cc = lc; cc < 256; cc += 8) {
+    TS v[32];
+#pragma unroll
+    for (unsigned k = 0; k < 32; ++k) {
+      const unsigned cc = lc + 8 * k;
       const unsigned i2 = c0 + cc, ifx = f0 + lf;
-      float v = 0.f;
       const unsigned i1 = fast == 1 ? ifx : ig;
-      if (ifx < df && i2 < d2 && i1 < (unsigned)j.valid1 && i2 < (unsigned)j.valid2)
-        v = to_f32(src[(long)ig * sg + ifx + (long)i2 * j.s2]);
-      tile[lf * 257 + cc] = v;
+      const bool ok = ifx < df && i2 < d2 && i1 < (unsigned)j.valid1 && i2 < (unsigned)j.valid2;
+      v[k] = src[ok ? (long)ig * sg + ifx + (long)i2 * j.s2 : 0];
+      if (!ok) v[k] = from_f32<TS>(0.f);
     }
+#pragma unroll
+    for (unsigned k = 0; k < 32; ++k) tile[lf * 257 + lc + 8 * k] = to_f32(v[k]);
     }
     __syncthreads();
-    // write: lane = column (contiguous in the destination)
+    // write: lane = column (contiguous in the destination).  bf16 destinations whose rows start 16-byte aligned: 8
+    // consecutive columns per lane, one 16-byte store each (32 lanes per row, 8 rows per pass, 4 passes) instead of 32
+    // two-byte stores per lane -- the launch was bound by its store instructions, not by bytes
+    if (sizeof(TD) == 2 && c0 + 256 <= d2 && ((j.t0 | j.t1) & 7) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+      const unsigned l8 = (tid & 31) * 8, rr = tid >> 5;
+      for (unsigned r = rr; r < 32; r += 8) {
+        const unsigned ifx = f0 + r;
+        if (ifx >= df) continue;
+        const unsigned i0 = fast == 1 ? ig : ifx, i1 = fast == 1 ? ifx : ig;
+        const unsigned i2 = c0 + l8;
+        TD o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = tile[r * 257 + l8 + e];
+          if (j.scale) v *= j.scale[j.scale_axis == 0 ? i0 : (j.scale_axis == 1 ? i1 : i2 + e)];
+          o[e] = from_f32<TD>(v);
+        }
+        __builtin_memcpy(__builtin_assume_aligned(dst + (long)i0 * j.t0 + (long)i1 * j.t1 + i2, 16), o, 16);
+      }
+      return;
+    }
     for (unsigned r = 0; r < 32; ++r) {
       const unsigned ifx = f0 + r, i2 = c0 + tid;
       if (ifx >= df || i2 >= d2) continue;
@@ -373,13 +406,27 @@ FOD_DEVINL void multi_permute_body(const fod_permute_job& j, long chunk, float* 
   if (fast == 2 && (d2 & 3) == 0 && (j.valid2 & 3) == 0 && sizeof(TS) == 4 &&
       ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)(j.s0 * 4) | (uintptr_t)(j.s1 * 4)) & 15) == 0 &&
       ((j.t0 | j.t1) & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
-    // ---- rows: four consecutive elements of one source row per thread
-    for (unsigned i = first + 4 * tid; i < last; i += 1024) {
+    // ---- rows: four consecutive elements of one source row per thread; the chunk's MP_CHUNK / 1024 loads of a thread are
+    // requested before the first store (a round of memory latency per chunk instead of one per load)
+    constexpr int NIT = MP_CHUNK / 1024;
+    float4 pre[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const unsigned i = first + 4 * tid + 1024 * k;
+      const unsigned i2 = i % d2, t = i / d2;
+      const unsigned i1 = t % d1, i0 = t / d1;
+      const bool ok = i < last && i1 < (unsigned)j.valid1 && i2 < (unsigned)j.valid2;
+      pre[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (ok ? (long)i0 * j.s0 + (long)i1 * j.s1 + i2 : 0));
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const unsigned i = first + 4 * tid + 1024 * k;
+      if (i >= last) break;
       const unsigned i2 = i % d2, t = i / d2;
       const unsigned i1 = t % d1, i0 = t / d1;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i1 < (unsigned)j.valid1 && i2 < (unsigned)j.valid2) {
-        v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + (long)i0 * j.s0 + (long)i1 * j.s1 + i2);
+        v = pre[k];
         if (j.scale) {
           if (j.scale_axis == 2) {
             const float4 sc = *reinterpret_cast<const float4*>(j.scale + i2);
