@@ -29,9 +29,18 @@ __global__ __launch_bounds__(256) void multi_sqnorm_kernel(const long* __restric
   float s = 0.f;
   if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {          // 16 bytes per lane (CHUNK is a multiple of 4)
     const long end4 = base + ((end - base) & ~3L);
-    for (long i = base + 4 * threadIdx.x; i < end4; i += 1024) {
-      const float4 q = *reinterpret_cast<const float4*>(g + i);
-      s += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    // all of the thread's loads of the chunk in flight at once; summed in the same order as a rolled loop would
+    constexpr int NIT = CHUNK / 1024;
+    float4 q[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const long i = base + 4 * threadIdx.x + 1024L * k;
+      q[k] = i < end4 ? *reinterpret_cast<const float4*>(g + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const long i = base + 4 * threadIdx.x + 1024L * k;
+      if (i < end4) s += q[k].x * q[k].x + q[k].y * q[k].y + q[k].z * q[k].z + q[k].w * q[k].w;
     }
     for (long i = end4 + threadIdx.x; i < end; i += 256) s += g[i] * g[i];
   } else {
@@ -60,9 +69,18 @@ __global__ __launch_bounds__(256) void multi_sqnorm_det_kernel(const long* __res
   float s = 0.f;
   if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
     const long end4 = base + ((end - base) & ~3L);
-    for (long i = base + 4 * threadIdx.x; i < end4; i += 1024) {
-      const float4 q = *reinterpret_cast<const float4*>(g + i);
-      s += q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+    // all of the thread's loads of the chunk in flight at once; summed in the same order as a rolled loop would
+    constexpr int NIT = CHUNK / 1024;
+    float4 q[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const long i = base + 4 * threadIdx.x + 1024L * k;
+      q[k] = i < end4 ? *reinterpret_cast<const float4*>(g + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const long i = base + 4 * threadIdx.x + 1024L * k;
+      if (i < end4) s += q[k].x * q[k].x + q[k].y * q[k].y + q[k].z * q[k].z + q[k].w * q[k].w;
     }
     for (long i = end4 + threadIdx.x; i < end; i += 256) s += g[i] * g[i];
   } else {
