@@ -1,8 +1,9 @@
 set -e
-o=gpurun_out/r03t
+o=gpurun_out/r03lan
 mkdir -p $o
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $o/gpu_tests.txt 2>&1 || { tail -40 $o/gpu_tests.txt; exit 1; }
-tail -1 $o/gpu_tests.txt
-python __graft_entry__.py smoke 2>&1 | tail -1
-python bench.py > $o/bench_line.json 2> $o/bench.err
-python -c "import json; d=json.loads(open('$o/bench_line.json').read().strip().splitlines()[-1]); print(round(d['value'],2), round(d['ms_per_step'],3), d['roofline']['frac'], d['kernels_per_replayed_step'], d['fast_paths'])"
+timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "linear_add_norm" > $o/test.log 2>&1 || { tail -30 $o/test.log; exit 1; }
+tail -1 $o/test.log
+bash tools/trace_graph.sh r03lan_trace > /dev/null 2>&1
+python tools/trace_summary_graph.py gpurun_out/r03lan_trace/kernel_trace.csv > $o/summary.txt 2>&1
+rm -f gpurun_out/r03lan_trace/kernel_trace.csv
+grep -E "linear_add_norm|kernels, span" $o/summary.txt | cut -c1-90
