@@ -1,9 +1,6 @@
 set -e
-o=gpurun_out/r03lan
+o=gpurun_out/r03tnq
 mkdir -p $o
-timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "linear_add_norm" > $o/test.log 2>&1 || { tail -30 $o/test.log; exit 1; }
-tail -1 $o/test.log
-bash tools/trace_graph.sh r03lan_trace > /dev/null 2>&1
-python tools/trace_summary_graph.py gpurun_out/r03lan_trace/kernel_trace.csv > $o/summary.txt 2>&1
-rm -f gpurun_out/r03lan_trace/kernel_trace.csv
-grep -E "linear_add_norm|kernels, span" $o/summary.txt | cut -c1-90
+FOD_TN_BIG_SPLITS=14 FOD_TN_BIG256=0 timeout -k 10 300 python tools/bench_ops.py conv > $o/rect14.txt 2>&1
+FOD_TN_BIG_SPLITS=14 FOD_TN_BIG256=1 timeout -k 10 300 python tools/bench_ops.py conv > $o/sq14.txt 2>&1
+paste <(grep -E "^layer3.1.conv2|^layer4.1.conv2|^layer3.0.conv2" $o/rect14.txt | awk '{print $1, $11, $12}') <(grep -E "^layer3.1.conv2|^layer4.1.conv2|^layer3.0.conv2" $o/sq14.txt | awk '{print $11, $12}')
