@@ -42,6 +42,11 @@ struct NtParams {
   // blockIdx.y = batch * m-tiles + m-tile; operand b of batch z starts *_batch elements after that of batch z - 1
   int batches;
   long a_batch, b_batch, c_batch, shift_batch, res_batch, mask_batch;
+  // grouped form: the residual of C's column segment s < res_nseg is block s of a [res_nseg][*, c_seg_cols] operand whose
+  // blocks lie res_seg_stride elements apart (row(m) as usual); segments >= res_nseg get none.  res_nseg = 0: one
+  // [*, N] residual for all columns
+  int res_nseg;
+  long res_seg_stride;
   // gather geometry
   int Hs, Ws, Cs;   // source image dims / channels
   int Hd, Wd;       // m-domain dims

@@ -569,7 +569,14 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const NtParams p) {
   for (int ps = 0; ps < 4; ++ps) {
     const int m = min(m0 + rq + 16 * ps, M1);
     const long rm = p.res_row_mod > 0 ? (m % p.res_row_mod) : m;
-    const auto a = __builtin_amdgcn_raw_buffer_load_b64(rsRes, n_ok ? (int)((rm * p.ldr + n) * 2) : (int)OOB, 0, 0);
+    long roff = rm * p.ldr + n;
+    bool r_ok = n_ok;
+    if (p.res_nseg > 0) {                      // per-segment residual blocks (block-uniform: c_seg_cols % 64 == 0)
+      const int cseg = n0 / p.c_seg_cols;
+      roff = (long)cseg * p.res_seg_stride + rm * p.ldr + (n - cseg * p.c_seg_cols);
+      r_ok = n_ok && cseg < p.res_nseg;
+    }
+    const auto a = __builtin_amdgcn_raw_buffer_load_b64(rsRes, r_ok ? (int)(roff * 2) : (int)OOB, 0, 0);
     const auto b = __builtin_amdgcn_raw_buffer_load_b64(rsMask, n_ok ? (int)(((long)m * p.ldmask + n) * 2) : (int)OOB, 0, 0);
     __builtin_memcpy(&rres[ps], &a, 8);
     __builtin_memcpy(&rmsk[ps], &b, 8);
@@ -870,7 +877,8 @@ extern "C" int fod_gemm_nt(int dtype, const void* A, long lda, int a_row_mod, co
 
 extern "C" int fod_gemm_nt_grouped(int dtype, const void* A, long lda, int a_seg_len, long a_seg_stride,
                                    const void* B, long ldb, void* C, long ldc, int c_seg_cols, long c_seg_stride,
-                                   int M, int N, int K, const fod_epilogue* epi, hipStream_t stream) {
+                                   int M, int N, int K, const fod_epilogue* epi, int res_nseg, long res_seg_stride,
+                                   hipStream_t stream) {
   FOD_REQUIRE(dtype == FOD_BF16, "gemm_nt_grouped: bf16 only (dtype %d)", dtype);
   FOD_REQUIRE(A && B && C, "gemm_nt_grouped: null operand");
   FOD_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_nt_grouped: empty problem %d %d %d", M, N, K);
@@ -893,7 +901,13 @@ extern "C" int fod_gemm_nt_grouped(int dtype, const void* A, long lda, int a_seg
   fill_epilogue(p, epi);
   decide_vec_epilogue(p);
   FOD_REQUIRE(p.vec_epi, "gemm_nt_grouped: N, ldc and the epilogue operands must be 4-element / 16-byte aligned");
-  FOD_REQUIRE(!p.res || ((long)(p.res_row_mod > 0 ? p.res_row_mod : M) * p.ldr + N) * 2 < 0x7FFFFFF0L,
+  FOD_REQUIRE(res_nseg >= 0 && (res_nseg == 0 || (p.res && c_seg_cols > 0 && res_seg_stride % 4 == 0 &&
+                                                  res_nseg <= ceil_div(N, c_seg_cols))),
+              "gemm_nt_grouped: per-segment residual (%d blocks) needs a residual, C segments and a 4-element block stride", res_nseg);
+  p.res_nseg = res_nseg;
+  p.res_seg_stride = res_seg_stride;
+  FOD_REQUIRE(!p.res || ((long)(res_nseg > 1 ? res_nseg - 1 : 0) * res_seg_stride +
+                         (long)(p.res_row_mod > 0 ? p.res_row_mod : M) * p.ldr + N) * 2 < 0x7FFFFFF0L,
               "gemm_nt_grouped: residual larger than 2 GiB");
   FOD_REQUIRE(!p.mask || ((long)M * p.ldmask + N) * 2 < 0x7FFFFFF0L, "gemm_nt_grouped: mask larger than 2 GiB");
   const long nseg = a_seg_len > 0 ? K / a_seg_len : 1;

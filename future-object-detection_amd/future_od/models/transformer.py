@@ -129,9 +129,8 @@ class SlotToSlotAttention(Attention):
         _no_masks(attn_mask, key_padding_mask)
         M = qpos.shape[0]
         qp, kp = pos_proj if pos_proj is not None else (_lin(qpos, self.query_pos), _lin(qpos, self.key_pos))
-        qc, kc, v = Fn.group_linear(x, [self.query_content, self.key_content, self.value])
-        q = Fn.add(qc, qp, b_row_mod=M)
-        k = Fn.add(kc, kp, b_row_mod=M)
+        # q = q_content + q_pos, k = k_content + k_pos (positions: [M, D] tables shared by the batch) from the projections' launch
+        q, k, v = Fn.group_linear(x, [self.query_content, self.key_content, self.value], residual=[qp, kp], res_row_mod=M)
         a = Fn.attention(q, k, v, 1.0 / math.sqrt(self.D // self.Nhead), drop_p=self.droprate, training=self.training)
         return _Proj(a, self.fun.out_proj)
 

@@ -1615,14 +1615,22 @@ class GroupLinearFn(Function):
     the per-layer projections of the learned query positions (reference transformer.py:66-70,139-141)."""
 
     @staticmethod
-    def forward(ctx, x, *params):
+    def forward(ctx, x, nres, res_mod, *tensors):
+        """`nres` > 0: the first nres of `tensors` are [R, D] tables (consecutive blocks of ONE buffer, as an earlier
+        GroupLinearFn returns them) added to the first nres outputs in the launch's epilogue, row m + table[m % res_mod]
+        -- the self-attention's q = q_content + q_pos, k = k_content + k_pos without their two element-wise launches."""
+        res, params = tensors[:nres], tensors[nres:]
         P = len(params) // 2
         weights, biases = params[:P], params[P:]
         wcat, bcat, _ = CAT.get(weights, biases, x.dtype)
         D = weights[0].shape[0]
-        y = ops.group_linear_fwd(x.view(-1, x.shape[-1]), wcat, bcat, P)
+        rblock = None
+        if nres:
+            rblock = _as_segments(res, res[0].numel() // D, D)
+            assert rblock is not None, "group_linear(residual=...): the tables must be consecutive blocks (the caller checks)"
+        y = ops.group_linear_fwd(x.view(-1, x.shape[-1]), wcat, bcat, P, residual=rblock, res_row_mod=res_mod)
         ctx.save_for_backward(x)
-        ctx.params = params
+        ctx.params, ctx.nres, ctx.res_mod, ctx.res_shape = params, nres, res_mod, (res[0].shape if nres else None)
         return tuple(y[p].view(*x.shape[:-1], D) for p in range(P))
 
     @staticmethod
@@ -1652,7 +1660,13 @@ class GroupLinearFn(Function):
         dw = zeros_f32((P * D, K), x.device)
         db = zeros_f32((P * D,), x.device)
         WGRADS.grouped(WGRADS.site(ctx.params), g, x.view(rows, K), dw, db)
-        return (dx,) + tuple(dw[i * D:(i + 1) * D] for i in range(P)) + tuple(db[i * D:(i + 1) * D] for i in range(P))
+        dres = ()
+        if ctx.nres:
+            # the tables' gradients: the first nres output gradients summed over the rows that shared a table row
+            dres = tuple((_sum_periodic(g[i], ctx.res_mod).view(ctx.res_shape) if ctx.res_mod and rows > ctx.res_mod
+                          else g[i].view(ctx.res_shape)) if ctx.needs_input_grad[3 + i] else None for i in range(ctx.nres))
+        return ((dx, None, None) + dres + tuple(dw[i * D:(i + 1) * D] for i in range(P))
+                + tuple(db[i * D:(i + 1) * D] for i in range(P)))
 
 
 def _as_segments(gs, rows, D):
@@ -1670,14 +1684,30 @@ def _as_segments(gs, rows, D):
     return torch.as_strided(g0, (len(gs), rows, D), (step, D, 1))
 
 
-def group_linear(x, linears):
+# "0": the self-attention's position adds as their own element-wise launches (not in the grouped projection's epilogue)
+GROUP_RESIDUAL = os.environ.get("FOD_GROUP_RESIDUAL", "1") != "0"
+
+
+def group_linear(x, linears, residual=None, res_row_mod=0):
     """[m(x) for m in linears] for nn.Linear-like holders of equal shape; grouped launches in bf16, plain
-    per-layer launches otherwise (fp32 parity mode, odd widths)."""
+    per-layer launches otherwise (fp32 parity mode, odd widths).  `residual`: a list of [R, D] tables added to the first
+    len(residual) results, row m + table[m % res_row_mod] -- inside the launch when the tables are consecutive blocks of
+    one buffer (what an earlier group_linear returns), as separate additions otherwise."""
     D, K = linears[0].weight.shape
     same = all(tuple(m.weight.shape) == (D, K) and m.bias is not None for m in linears)
+    res = list(residual) if residual is not None else []
     if x.dtype != torch.bfloat16 or not same or D % 64 or K % 32 or len(linears) < 2:
-        return [linear(x, m.weight, m.bias) for m in linears]
-    return list(GroupLinearFn.apply(x.contiguous(), *[m.weight for m in linears], *[m.bias for m in linears]))
+        out = [linear(x, m.weight, m.bias) for m in linears]
+        fused = False
+    else:
+        fused = bool(res) and GROUP_RESIDUAL and all(r.dim() == 2 and r.shape[1] == D and r.dtype == x.dtype for r in res) \
+            and _as_segments(res, res[0].shape[0], D) is not None and 0 < res_row_mod <= res[0].shape[0]
+        out = list(GroupLinearFn.apply(x.contiguous(), len(res) if fused else 0, res_row_mod if fused else 0,
+                                       *(res if fused else []), *[m.weight for m in linears], *[m.bias for m in linears]))
+    if res and not fused:
+        for i, r in enumerate(res):
+            out[i] = add(out[i], r, b_row_mod=res_row_mod)
+    return out
 
 
 class _StackCache:

@@ -69,7 +69,7 @@ _EP, _CG, _AS = _p, _p, _p
 SIGNATURES = {
     "fod_gemm_nt": [_i, _p, _l, _i, _p, _l, _p, _l, _i, _i, _i, _EP, _p],
     "fod_gemm_tn_acc": [_i, _p, _l, _p, _l, _p, _l, _i, _i, _i, _p, _p, _i, _p, C.c_size_t, _p],
-    "fod_gemm_nt_grouped": [_i, _p, _l, _i, _l, _p, _l, _p, _l, _i, _l, _i, _i, _i, _EP, _p],
+    "fod_gemm_nt_grouped": [_i, _p, _l, _i, _l, _p, _l, _p, _l, _i, _l, _i, _i, _i, _EP, _i, _l, _p],
     "fod_gemm_nt_batched": [_i, _i, _p, _l, _l, _p, _l, _l, _p, _l, _l, _i, _i, _i, _EP, _l, _l, _l, _p],
     "fod_gemm_tn_grouped": [_i, _p, _l, _i, _l, _p, _l, _p, _l, _i, _i, _i, _p, _i, _p],
     "fod_gemm_tn_multi": [_p, _p, _p, _i, _p],

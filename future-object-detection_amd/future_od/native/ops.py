@@ -191,9 +191,10 @@ def gemm_tn_acc(g, x, dw, row_scale=None, colsum=None, zeroed=False):
     return dw
 
 
-def group_linear_fwd(x, wcat, bcat, P, relu=False):
+def group_linear_fwd(x, wcat, bcat, P, relu=False, residual=None, res_row_mod=0):
     """P Linear layers sharing the input x [rows, K]: wcat [P*D, K], bcat f32 [P*D] -> y [P, rows, D] (each
-    [rows, D] block contiguous) in one launch."""
+    [rows, D] block contiguous) in one launch.  residual [S, R, D] (S <= P contiguous blocks): added to the first S
+    outputs, row m of block s = residual[s, m % res_row_mod] (res_row_mod = 0: row m)."""
     _chk(x, "x", torch.bfloat16); _chk(wcat, "wcat", torch.bfloat16)
     K = x.shape[-1]
     rows = x.numel() // K
@@ -203,9 +204,16 @@ def group_linear_fwd(x, wcat, bcat, P, relu=False):
     if bcat is not None:
         _chk(bcat, "bcat", torch.float32); assert bcat.numel() == N
     y = torch.empty((P, rows, D), dtype=x.dtype, device=x.device)
+    nseg, seg_stride = 0, 0
+    if residual is not None:
+        _chk(residual, "residual", x.dtype)
+        nseg, R = residual.shape[0], residual.shape[1]
+        assert residual.dim() == 3 and residual.shape[2] == D and nseg <= P
+        assert (res_row_mod and res_row_mod <= R) or (not res_row_mod and R >= rows)
+        seg_stride = R * D
     call("fod_gemm_nt_grouped", dt(x), ptr(x), K, 0, 0, ptr(wcat), K, ptr(y), D, D, rows * D, rows, N, K,
-         _epi(None, bcat, None, N, 0, None, N, relu, False), stream(), work=2.0 * rows * N * K,
-         tag="fod_gemm_nt")
+         _epi(None, bcat, residual, D, res_row_mod, None, N, relu, False), nseg, seg_stride, stream(),
+         work=2.0 * rows * N * K, tag="fod_gemm_nt")
     return y
 
 
@@ -217,7 +225,7 @@ def group_linear_dgrad(g, wcat_t, P):
     assert g.shape[0] == P and wcat_t.shape[1] == P * D and D % 32 == 0
     dx = torch.empty((rows, K), dtype=g.dtype, device=g.device)
     call("fod_gemm_nt_grouped", dt(g), ptr(g), D, D, rows * D, ptr(wcat_t), P * D, ptr(dx), K, 0, 0, rows, K, P * D,
-         None, stream(), work=2.0 * rows * K * P * D, tag="fod_gemm_nt")
+         None, 0, 0, stream(), work=2.0 * rows * K * P * D, tag="fod_gemm_nt")
     return dx
 
 

@@ -98,7 +98,12 @@ int fod_gemm_tn_acc(int dtype, const void* G, long ldg, const void* X, long ldx,
  * A segment size of 0 means "not segmented".  bf16 only; always the short-launch kernels (64 x 64 tiles). */
 int fod_gemm_nt_grouped(int dtype, const void* A, long lda, int a_seg_len, long a_seg_stride, const void* B,
                         long ldb, void* C, long ldc, int c_seg_cols, long c_seg_stride, int M, int N, int K,
-                        const fod_epilogue* epi, fod_stream_t stream);
+                        const fod_epilogue* epi,
+                        /* res_nseg > 0: the epilogue's residual is res_nseg blocks [*, c_seg_cols] lying res_seg_stride
+                         * elements apart, block s for C's column segment s; further segments get no residual (the
+                         * self-attention's q = q_content + q_pos, k = k_content + k_pos, v = value from ONE launch:
+                         * reference transformer.py:66-78).  0: one [*, N] residual */
+                        int res_nseg, long res_seg_stride, fod_stream_t stream);
 /* `batches` independent problems of ONE shape in one launch of the short-launch kernel (bf16): operand X of batch z
  * starts x_batch elements after that of batch z - 1 (A [M, K], B [N, K], C [M, N]; the epilogue's shift [N], residual and
  * relu_mask [M, N] likewise, strides in elements; scale and residual_row_mod are not batched).  The same sub-layer of

@@ -1521,3 +1521,48 @@ def test_fused_mlp2_mul_forward_backward(B, Mq):
     for g1, g2 in zip(*grads):
         err = float((g1.double() - g2.double()).norm() / g2.double().norm().clamp_min(1e-9))
         assert err <= 1e-2, err
+
+
+@pytest.mark.parametrize("B,M,P,S", [(2, 128, 3, 2), (1, 128, 3, 2), (3, 100, 4, 4), (2, 7, 2, 1)])
+def test_group_linear_with_per_segment_residual_tables(B, M, P, S):
+    """fod_gemm_nt_grouped(res_nseg): the first S of P grouped projections get a [M, D] table added in the epilogue (row m +
+    table[m % M]; the self-attention's q / k position terms) -- bit-equal to the grouped launch followed by the
+    element-wise additions; through autograd (Fn.group_linear(residual=...)) every gradient equals the unfused graph's."""
+    from future_od.native import functional as Fn
+    dtype = torch.bfloat16
+    D, K = 256, 256
+    rows = B * M
+    x = rnd((rows, K), dtype, 131).to(DEV)
+    wcat = rnd((P * D, K), dtype, 132, scale=1.0 / 16).to(DEV)
+    bcat = (torch.randn(P * D) * 0.3).to(DEV)
+    tables = rnd((S, M, D), dtype, 133).to(DEV)
+    y = ops.group_linear_fwd(x, wcat, bcat, P, residual=tables, res_row_mod=M)
+    y0 = ops.group_linear_fwd(x, wcat, bcat, P)
+    for p_ in range(P):
+        want = ops.eltwise(L.EW_ADD, y0[p_].contiguous(), tables[p_], b_row_mod=M) if p_ < S else y0[p_]
+        # (the fused epilogue adds bias and table in f32 before ONE rounding; the two launches round twice)
+        assert float((y[p_].float() - want.float()).abs().max()) <= 2.0 ** -7 * float(want.float().abs().max()), p_
+    lins = torch.nn.ModuleList(torch.nn.Linear(K, D) for _ in range(P)).to(DEV)
+    pos_lins = torch.nn.ModuleList(torch.nn.Linear(K, D) for _ in range(S)).to(DEV)
+    gouts = [rnd((rows, D), dtype, 140 + i).to(DEV) for i in range(P)]
+    qpos = rnd((M, K), dtype, 150).to(DEV)
+    res = []
+    for fused in (True, False):
+        for prm in list(lins.parameters()) + list(pos_lins.parameters()):
+            prm.grad = None
+        Fn.PREP.clear()
+        xx, qq = x.clone().requires_grad_(True), qpos.clone().requires_grad_(True)
+        if S >= 2:
+            tabs = Fn.group_linear(qq, list(pos_lins))           # consecutive blocks of one buffer
+        else:
+            tabs = [Fn.linear(qq, pos_lins[0].weight, pos_lins[0].bias)]
+        if fused:
+            outs = Fn.group_linear(xx, list(lins), residual=tabs, res_row_mod=M)
+        else:
+            outs = Fn.group_linear(xx, list(lins))
+            outs = [Fn.add(o, tabs[i], b_row_mod=M) if i < S else o for i, o in enumerate(outs)]
+        sum((o.float() * g.float()).sum() for o, g in zip(outs, gouts)).backward()
+        res.append([xx.grad, qq.grad] + [prm.grad.clone() for prm in list(lins.parameters()) + list(pos_lins.parameters())])
+    for g1, g2 in zip(*res):
+        err = float((g1.double() - g2.double()).norm() / g2.double().norm().clamp_min(1e-9))
+        assert err <= 1e-2, err

@@ -1,6 +1,8 @@
 set -e
-o=gpurun_out/r03tnq
+o=gpurun_out/r03gr
 mkdir -p $o
-FOD_TN_BIG_SPLITS=14 FOD_TN_BIG256=0 timeout -k 10 300 python tools/bench_ops.py conv > $o/rect14.txt 2>&1
-FOD_TN_BIG_SPLITS=14 FOD_TN_BIG256=1 timeout -k 10 300 python tools/bench_ops.py conv > $o/sq14.txt 2>&1
-paste <(grep -E "^layer3.1.conv2|^layer4.1.conv2|^layer3.0.conv2" $o/rect14.txt | awk '{print $1, $11, $12}') <(grep -E "^layer3.1.conv2|^layer4.1.conv2|^layer3.0.conv2" $o/sq14.txt | awk '{print $11, $12}')
+for v in 0 1 0 1 0 1; do
+  FOD_GROUP_RESIDUAL=$v python bench.py --no-cpu-baseline --no-extras --no-roofline --steps 30 --warmup 5 2> $o/ab.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FOD_GROUP_RESIDUAL=$v', round(d['value'],2), round(d['ms_per_step'],3))" | tee -a $o/ab.txt
+done
