@@ -1,12 +1,6 @@
 set -e
-o=gpurun_out/r03u
+o=gpurun_out/r03l4
 mkdir -p $o
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $o/gpu_tests.txt 2>&1 || { tail -40 $o/gpu_tests.txt; exit 1; }
-tail -1 $o/gpu_tests.txt
-python __graft_entry__.py smoke 2>&1 | tail -1
-python bench.py > $o/bench_line.json 2> $o/bench.err
-python -c "import json; d=json.loads(open('$o/bench_line.json').read().strip().splitlines()[-1]); print(round(d['value'],2), round(d['ms_per_step'],3), d['roofline']['frac'], d['kernels_per_replayed_step'], d['roofline']['check'])"
-bash tools/trace_graph.sh r03u_trace > /dev/null 2>&1
-python tools/trace_summary_graph.py gpurun_out/r03u_trace/kernel_trace.csv > $o/summary.txt 2>&1
-rm -f gpurun_out/r03u_trace/kernel_trace.csv
-head -1 $o/summary.txt
+timeout -k 10 300 python tools/bench_ops.py conv > $o/def.txt 2>&1
+FOD_NT_BIG256=2 timeout -k 10 300 python tools/bench_ops.py conv > $o/sq_all.txt 2>&1
+paste <(grep -E "^layer4" $o/def.txt | awk '{print $1, $2, $9, $10}') <(grep -E "^layer4" $o/sq_all.txt | awk '{print $9, $10}')
