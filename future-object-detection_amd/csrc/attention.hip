@@ -1294,15 +1294,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p_in
 //     (accumulator rows 8g + 4h .. +3 are consecutive queries).
 // Rows past Tq are clamped duplicates; their P and dS are zeroed, so they add nothing.
 template <int PARTS, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_pf_kernel(const AttnParams p_in) {
+FOD_DEVINL void attn_bwd_dkv_pf_body(const AttnParams& p_in, const int bx, const int h, const int b) {
   AttnParams p = p_in;
   if constexpr (DROP) resolve_drop_seed(p);
   typedef __bf16 T;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 31, fh = lane >> 5;
-  const int k0 = (blockIdx.x * 4 + wave) * 32;
+  const int k0 = (bx * 4 + wave) * 32;
   if (k0 >= p.S) return;
-  const int h = blockIdx.y, b = blockIdx.z;
   const int key = min(k0 + fr, p.S - 1);
   const T* Qb[2] = {reinterpret_cast<const T*>(p.q1) + (long)b * p.q_bs + h * 32 + 8 * fh,
                     p.q2 ? reinterpret_cast<const T*>(p.q2) + (long)b * p.q_bs + h * 32 + 8 * fh : nullptr};
@@ -1461,6 +1460,34 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_pf_kernel(const AttnParams p
   }
 }
 
+template <int PARTS, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_pf_kernel(const AttnParams p) {
+  attn_bwd_dkv_pf_body<PARTS, DROP>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// The dk / dv passes of SEVERAL calls of one shape in one launch (fod_attn_bwd_dkv_multi): the decoder's cross-attention
+// blocks write their key / value gradients into their own (layer, image) slots of the memory-side buffers, which nothing
+// reads before the hoisted projections' backward -- 30 launches of ~8 us per step wait for each other for no reason.
+// blockIdx.z = job * B + batch element; a job = the operand pointers that differ between the calls.
+struct DkvJob {
+  const void *q1, *q2, *k1, *k2, *v, *dout;
+  float *lse2, *delta;
+  void *dk1, *dk2, *dv;
+};
+constexpr int DKV_MAX_JOBS = 32;
+struct DkvJobs {
+  DkvJob j[DKV_MAX_JOBS];
+};
+template <int PARTS>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_pf_multi_kernel(const AttnParams base, const DkvJobs jobs) {
+  const int job = blockIdx.z / base.B, b = blockIdx.z - job * base.B;
+  AttnParams p = base;
+  const DkvJob& j = jobs.j[job];
+  p.q1 = j.q1; p.q2 = j.q2; p.k1 = j.k1; p.k2 = j.k2; p.v = j.v; p.dout = j.dout;
+  p.lse2 = j.lse2; p.delta = j.delta; p.dk1 = j.dk1; p.dk2 = j.dk2; p.dv = j.dv;
+  attn_bwd_dkv_pf_body<PARTS, false>(p, blockIdx.x, blockIdx.y, b);
+}
+
 template <typename T, int PARTS, bool DROP>
 int launch_all(int which, const AttnParams& p, hipStream_t stream) {
   const dim3 block(256);
@@ -1574,6 +1601,49 @@ extern "C" int fod_attn_fwd(int dtype, const void* q1, const void* k1, const voi
   FOD_REQUIRE((q2 == nullptr) == (k2 == nullptr), "attn_fwd: q2/k2 must come together");
   p.q1 = q1; p.k1 = k1; p.q2 = q2; p.k2 = k2; p.v = v; p.o = o; p.lse2 = lse2;
   return dispatch(dtype, q2 ? 2 : 1, 0, p, stream);
+}
+
+extern "C" int fod_attn_bwd_dq(int dtype, const void* q1, const void* k1, const void* q2, const void* k2, const void* v,
+                               const void* o, const void* dout, const float* lse2, float* delta, void* dq1, void* dq2,
+                               const fod_attn_shape* shape, hipStream_t stream) {
+  AttnParams p{};
+  int rc = fill(p, shape);
+  if (rc) return rc;
+  FOD_REQUIRE(q1 && k1 && v && o && dout && lse2 && delta && dq1, "attn_bwd_dq: null operand");
+  FOD_REQUIRE((q2 == nullptr) == (k2 == nullptr) && (q2 == nullptr) == (dq2 == nullptr), "attn_bwd_dq: part-2 pointers must come together");
+  p.q1 = q1; p.k1 = k1; p.q2 = q2; p.k2 = k2; p.v = v; p.out = o; p.dout = dout;
+  p.lse2 = const_cast<float*>(lse2); p.delta = delta;
+  p.dq1 = dq1; p.dq2 = dq2;
+  return dispatch(dtype, q2 ? 2 : 1, 1, p, stream);
+}
+
+extern "C" int fod_attn_bwd_dkv_multi(int dtype, int njobs, const void* const* ptrs, const fod_attn_shape* shape,
+                                      hipStream_t stream) {
+  FOD_REQUIRE(dtype == FOD_BF16, "attn_bwd_dkv_multi: bf16 only (dtype %d)", dtype);
+  FOD_REQUIRE(ptrs && njobs > 0 && njobs <= DKV_MAX_JOBS, "attn_bwd_dkv_multi: 1 .. %d jobs (%d)", DKV_MAX_JOBS, njobs);
+  AttnParams p{};
+  int rc = fill(p, shape);
+  if (rc) return rc;
+  FOD_REQUIRE(p.drop_threshold == 0, "attn_bwd_dkv_multi: no dropout variant");
+  FOD_REQUIRE((long)njobs * p.B <= 65535, "attn_bwd_dkv_multi: grid too large");
+  DkvJobs jobs{};
+  bool parts2 = false;
+  for (int i = 0; i < njobs; ++i) {
+    const void* const* q = ptrs + 11 * i;
+    DkvJob& j = jobs.j[i];
+    j.q1 = q[0]; j.q2 = q[1]; j.k1 = q[2]; j.k2 = q[3]; j.v = q[4]; j.dout = q[5];
+    j.lse2 = (float*)q[6]; j.delta = (float*)q[7]; j.dk1 = (void*)q[8]; j.dk2 = (void*)q[9]; j.dv = (void*)q[10];
+    FOD_REQUIRE(j.q1 && j.k1 && j.v && j.dout && j.lse2 && j.delta && j.dk1 && j.dv, "attn_bwd_dkv_multi: null operand in job %d", i);
+    const bool two = j.q2 != nullptr;
+    FOD_REQUIRE(two == (j.k2 != nullptr) && two == (j.dk2 != nullptr), "attn_bwd_dkv_multi: part-2 pointers of job %d must come together", i);
+    FOD_REQUIRE(i == 0 || two == parts2, "attn_bwd_dkv_multi: jobs with and without a second part in one launch");
+    parts2 = two;
+  }
+  const dim3 grid(ceil_div(p.S, 128), p.H, p.B * njobs);
+  if (parts2) hipLaunchKernelGGL((attn_bwd_dkv_pf_multi_kernel<2>), grid, dim3(256), 0, stream, p, jobs);
+  else hipLaunchKernelGGL((attn_bwd_dkv_pf_multi_kernel<1>), grid, dim3(256), 0, stream, p, jobs);
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
 }
 
 extern "C" int fod_attn_bwd(int dtype, const void* q1, const void* k1, const void* q2, const void* k2,

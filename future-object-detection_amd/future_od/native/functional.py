@@ -1906,6 +1906,31 @@ class MemorySide:
         return kc, ks, v
 
 
+# "0": every cross-attention block launches its own dk / dv pass (fod_attn_bwd) instead of queueing it
+DKV_QUEUE = os.environ.get("FOD_DKV_QUEUE", "1") != "0"
+
+
+class _DkvQueue:
+    """The dk / dv passes of the decoder's cross-attention blocks (one per layer and image: 30 per step) wait here during the
+    backward sweep and run as ONE launch (fod_attn_bwd_dkv_multi; 32 jobs at most per launch) when the first consumer of
+    their results is reached: each writes its own (layer, image) slot of MemorySide.dbig / .dks, which nothing reads
+    before the call that hands the buffers to autograd (layer 0)."""
+
+    def __init__(self):
+        self.jobs, self.key, self.shp = [], None, None
+
+    def push(self, key, shp, job):
+        if self.jobs and (key != self.key or len(self.jobs) == 32):
+            self.flush()
+        self.key, self.shp = key, shp
+        self.jobs.append(job)
+
+    def flush(self):
+        if self.jobs:
+            jobs, self.jobs = self.jobs, []
+            ops.attn_bwd_dkv_multi(jobs, self.shp)
+
+
 class HoistedCrossAttnFn(Function):
     """softmax((q1.kc + q2.ks) * scale) v with kc / v / ks taken as column slots of the hoisted buffers.
     Gradients of the slots are written in place into MemorySide.dbig / .dks; the buffers are handed to
@@ -1942,9 +1967,27 @@ class HoistedCrossAttnFn(Function):
         key = (layer, tuple(q2.shape))
         if key not in side.dq2:
             side.dq2[key] = torch.empty((side.K,) + tuple(q2.shape), dtype=q2.dtype, device=q2.device)
-        dq1, _, dq2, _, _ = ops.attn_bwd(q1, kc, v, o, do.contiguous(), lse2, ctx.scale, q2, ks,
-                                         dk1_out=dkc, dv_out=dv, dk2_out=dks, dq2_out=side.dq2[key][image],
-                                         drop_p=ctx.drop[0], drop_seed=ctx.drop[1])
+        B_, Tq_, S_ = q1.shape[0], q1.shape[1], kc.shape[1]
+        if (DKV_QUEUE and q1.dtype == torch.bfloat16 and ctx.drop[0] == 0.0 and Tq_ <= 512 and S_ >= 256
+                and dks.dim() == 3):
+            # (the few-query shapes: what fod_attn_bwd would run as dq + attn_bwd_dkv_pf_kernel; the same kernel body runs
+            # the queued jobs, so the results are bit-equal)
+            do_c = do.contiguous()
+            dq1, dq2, delta, shp = ops.attn_bwd_dq(q1, kc, v, o, do_c, lse2, ctx.scale, q2, ks, dk2_like=dks,
+                                                   dq2_out=side.dq2[key][image])
+            if getattr(side, "dkv_queue", None) is None:
+                side.dkv_queue = _DkvQueue()
+            qkey = (tuple(q1.shape), q1.stride(), kc.stride(), v.stride(), ks.stride(), dks.stride(), tuple(kc.shape),
+                    float(ctx.scale))
+            side.dkv_queue.push(qkey, shp, (q1, q2, kc, ks, v, do_c, lse2, delta, dkc, dks, dv))
+            if layer == 0:
+                side.dkv_queue.flush()                  # this call hands dbig[image] (and, at image 0, dks) on
+        else:
+            if getattr(side, "dkv_queue", None) is not None:
+                side.dkv_queue.flush()
+            dq1, _, dq2, _, _ = ops.attn_bwd(q1, kc, v, o, do.contiguous(), lse2, ctx.scale, q2, ks,
+                                             dk1_out=dkc, dv_out=dv, dk2_out=dks, dq2_out=side.dq2[key][image],
+                                             drop_p=ctx.drop[0], drop_seed=ctx.drop[1])
         g_big = side.dbig[image] if layer == 0 else None
         # a batch-shared ks_all gets the sum of the per-batch slots
         g_ks = None

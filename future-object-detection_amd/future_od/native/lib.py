@@ -95,6 +95,8 @@ SIGNATURES = {
     "fod_permute3_cast": [_i, _i, _p, _p, _i, _i, _i, _l, _l, _l, _i, _p, _i, _p],
     "fod_attn_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _AS, _p],
     "fod_attn_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _AS, _p],
+    "fod_attn_bwd_dq": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _AS, _p],
+    "fod_attn_bwd_dkv_multi": [_i, _i, _p, _AS, _p],
     "fod_attn_fp8_pack_bytes": [_AS, _i, _p, _p],
     "fod_attn_quant_fp8": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _AS, _p],
     "fod_attn_fwd_fp8": [_p, _p, _i, _p, _p, _AS, _p],

@@ -602,6 +602,44 @@ def attn_bwd(q1, k1, v, o, dout, lse2, scale, q2=None, k2=None, dk1_out=None, dv
     return dq1, dk1, dq2, dk2, dv
 
 
+def attn_bwd_dq(q1, k1, v, o, dout, lse2, scale, q2=None, k2=None, dk2_like=None, dq2_out=None):
+    """The query-side half of attn_bwd (no dropout): (dq1, dq2, delta, shape) -- delta and the shape descriptor are what
+    attn_bwd_dkv_multi needs for the key / value half.  dk2_like: the tensor the part-2 key gradient will be written to
+    (its strides go into the shape)."""
+    _chk(lse2, "lse2", torch.float32)
+    _chk(o, "o", q1.dtype); _chk(dout, "dout", q1.dtype)
+    assert dout.shape == q1.shape
+    dq1 = torch.empty_strided(q1.shape, q1.stride(), dtype=q1.dtype, device=q1.device)
+    dq2 = None
+    if q2 is not None:
+        _same_bt(q1, q2, "q2")
+        dq2 = dq2_out if dq2_out is not None else torch.empty_strided(q1.shape, q1.stride(), dtype=q1.dtype,
+                                                                      device=q1.device)
+        _same_bt(dq2, q1, "dq2")
+    shp, H = _attn_shape(q1, k1, v, o, scale, k2, dk2_like)
+    assert lse2.shape == (q1.shape[0], H, q1.shape[1])
+    delta = torch.empty_like(lse2)
+    call("fod_attn_bwd_dq", dt(q1), ptr(q1), ptr(k1), ptr(q2), ptr(k2), ptr(v), ptr(o), ptr(dout), ptr(lse2), ptr(delta),
+         ptr(dq1), ptr(dq2), _Addr(shp), stream(),
+         work=2.0 * shp.B * H * shp.Tq * shp.S * 32 * (2 * (2 if q2 is not None else 1) + 1), tag="fod_attn_bwd")
+    return dq1, dq2, delta, shp
+
+
+def attn_bwd_dkv_multi(jobs, shp):
+    """The dk / dv passes of len(jobs) <= 32 calls of ONE shape in one launch.  A job = (q1, q2, k1, k2, v, dout, lse2,
+    delta, dk1, dk2, dv) tensors (q2 / k2 / dk2 None for all or none); `shp` from attn_bwd_dq of any of them."""
+    n = len(jobs)
+    assert 0 < n <= 32
+    arr = (C.c_void_p * (11 * n))()
+    for i, job in enumerate(jobs):
+        assert len(job) == 11
+        for k, t in enumerate(job):
+            arr[11 * i + k] = None if t is None else t.data_ptr()
+    two = jobs[0][1] is not None
+    call("fod_attn_bwd_dkv_multi", BF16, n, C.addressof(arr), _Addr(shp), stream(),
+         work=2.0 * n * shp.B * shp.H * shp.Tq * shp.S * 32 * ((2 if two else 1) + 2), tag="fod_attn_bwd")
+
+
 # ------------------------------------------------------------------------------------------------ norm / eltwise
 def layernorm_fwd(x, gamma, beta, residual=None, res_row_div=0, res_row_mod=0, want_sum=None, eps=1e-5, group_rows=0):
     """group_rows > 0: gamma / beta are [rows / group_rows, D] tables, one entry per group of consecutive rows."""

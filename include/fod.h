@@ -290,6 +290,16 @@ int fod_attn_bwd(int dtype, const void* q1, const void* k1, const void* q2, cons
                  const void* o, const void* dout, const float* lse2, float* delta /* scratch [B,H,Tq] */,
                  void* dq1, void* dk1, void* dq2, void* dk2, void* dv, const fod_attn_shape* shape,
                  fod_stream_t stream);
+/* fod_attn_bwd in two pieces, for callers whose key / value gradients nobody reads yet: fod_attn_bwd_dq computes delta
+ * and the query gradients of ONE call; fod_attn_bwd_dkv_multi then runs the dk / dv passes of up to 32 such calls of one
+ * shape in ONE launch (bf16, no dropout; the decoder's cross-attention blocks: each writes its own (layer, image) slot
+ * of the memory-side gradient buffers).  ptrs: host array of njobs x 11 addresses in the order q1, q2, k1, k2, v, dout,
+ * lse2, delta, dk1, dk2, dv (q2 / k2 / dk2 NULL for all jobs or for none). */
+int fod_attn_bwd_dq(int dtype, const void* q1, const void* k1, const void* q2, const void* k2, const void* v,
+                    const void* o, const void* dout, const float* lse2, float* delta, void* dq1, void* dq2,
+                    const fod_attn_shape* shape, fod_stream_t stream);
+int fod_attn_bwd_dkv_multi(int dtype, int njobs, const void* const* ptrs, const fod_attn_shape* shape,
+                           fod_stream_t stream);
 
 /* fp8 attention forward (BASELINE.json configs[4]; csrc/attention_fp8.hip): OCP e4m3 operands with one E8M0 scale per
  * 32-element block (a token's head slice for q / k, 32 keys of a channel for v), v_mfma_scale_f32_32x32x64_f8f6f4.

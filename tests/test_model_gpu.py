@@ -458,3 +458,30 @@ def test_imu_blocks_of_all_layers_at_once(use_mlp, monkeypatch):
     assert ys[0][1].keys() == ys[1][1].keys()
     for n in ys[0][1]:
         assert rel(ys[0][1][n], ys[1][1][n]) <= 3e-2, (n, rel(ys[0][1][n], ys[1][1][n]))
+
+
+def test_queued_cross_attention_key_value_gradients(monkeypatch):
+    """Fn._DkvQueue: the dk / dv passes of the decoder's cross-attention blocks wait during the backward sweep and run as one
+    fod_attn_bwd_dkv_multi launch when layer 0 hands the memory-side gradient buffers on.  The queued jobs run the SAME
+    kernel body as fod_attn_bwd's own dk / dv pass, so every gradient of the model agrees with the unqueued run to the
+    run-to-run noise of the other kernels' f32 atomics (memory long enough for the few-query key split: 20 x 25 tokens)."""
+    cfg = Config(backbone="resnet18", enc_layers=1, dec_layers=3, num_images=3)
+    data = make_batch(2, 4, 320, 400, seed=11, device=DEV, max_boxes=6)
+    grads = []
+    for queued in (True, False):
+        monkeypatch.setattr(Fn, "DKV_QUEUE", queued)
+        model, _ = build_product(cfg, torch.bfloat16, 3)
+        model.eval()
+        out, _, loss, stats, od = model(data=data, distributed=False)
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append((float(loss), {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None}))
+    (l1, g1), (l2, g2) = grads
+    assert l1 == l2
+    assert g1.keys() == g2.keys()
+    worst = 0.0
+    for n in g1:
+        den = float(g2[n].norm())
+        if den > 0:
+            worst = max(worst, float((g1[n] - g2[n]).norm()) / den)
+    assert worst <= 2e-3, worst

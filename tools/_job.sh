@@ -1,6 +1,12 @@
 set -e
-o=gpurun_out/r03l4
+o=gpurun_out/r03dkv
 mkdir -p $o
-timeout -k 10 300 python tools/bench_ops.py conv > $o/def.txt 2>&1
-FOD_NT_BIG256=2 timeout -k 10 300 python tools/bench_ops.py conv > $o/sq_all.txt 2>&1
-paste <(grep -E "^layer4" $o/def.txt | awk '{print $1, $2, $9, $10}') <(grep -E "^layer4" $o/sq_all.txt | awk '{print $9, $10}')
+timeout -k 10 600 python -m pytest tests/test_model_gpu.py tests/test_kernels_gpu.py -m gpu -x -q -k "queued_cross or attention or parity" > $o/test.log 2>&1 || { tail -40 $o/test.log; exit 1; }
+tail -1 $o/test.log
+timeout -k 10 900 python -m pytest tests/test_model_gpu.py tests/test_graph_gpu.py tests/test_fullsize_oracle_gpu.py tests/test_configs_gpu.py tests/test_parallel_gpu.py -m gpu -x -q > $o/test2.log 2>&1 || { tail -40 $o/test2.log; exit 1; }
+tail -1 $o/test2.log
+for v in 0 1 0 1; do
+  FOD_DKV_QUEUE=$v python bench.py --no-cpu-baseline --no-extras --no-roofline --steps 30 --warmup 5 2> $o/ab.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FOD_DKV_QUEUE=$v', round(d['value'],2), round(d['ms_per_step'],3))" | tee -a $o/ab.txt
+done
