@@ -892,6 +892,71 @@ extern "C" int fod_layernorm_bwd(int dtype, const void* dy, const void* xsum, co
   return FOD_OK;
 }
 
+// ---- out_j[g, n] = sum over the rows of group g of G_j[m, n], for several (G_j, out_j) pairs of one shape in ONE launch,
+// bf16 in and out (f32 accumulation, fixed order): the gradients of the per-frame IMU rows that every encoder layer's
+// norm_eda adds to its tokens (reference transformer.py:444,485: x = norm(x + eda[frame])) -- one [frames, D] sum over the
+// frame's tokens per layer, all first read by the batched IMU blocks' backward.  The pairs travel in the kernel arguments.
+struct ColsumJob {
+  const void* g;
+  void* out;
+};
+constexpr int COLSUM_MAX_JOBS = 16;
+struct ColsumJobs {
+  ColsumJob j[COLSUM_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void colsum_groups_multi_kernel(const ColsumJobs jobs, int group_rows, int N) {
+  __shared__ __attribute__((aligned(16))) float red[4][256];
+  const int tx = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int grp = blockIdx.x;
+  const __bf16* G = reinterpret_cast<const __bf16*>(jobs.j[blockIdx.y].g) + (long)grp * group_rows * N;
+  const bool in = 4 * tx < N;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (in) {
+    int m = rl;
+    for (; m + 28 < group_rows; m += 32) {                // eight loads in flight per thread
+      bf16x4_t v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const bf16x4_t*>(G + (long)(m + 4 * k) * N + 4 * tx);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        a0 += (float)v[k][0]; a1 += (float)v[k][1]; a2 += (float)v[k][2]; a3 += (float)v[k][3];
+      }
+    }
+    for (; m < group_rows; m += 4) {
+      const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(G + (long)m * N + 4 * tx);
+      a0 += (float)v[0]; a1 += (float)v[1]; a2 += (float)v[2]; a3 += (float)v[3];
+    }
+  }
+  *reinterpret_cast<f32x4*>(&red[rl][4 * tx]) = f32x4{a0, a1, a2, a3};
+  __syncthreads();
+  if (rl == 0 && in) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(&red[0][4 * tx]);
+    t += *reinterpret_cast<const f32x4*>(&red[1][4 * tx]);
+    t += *reinterpret_cast<const f32x4*>(&red[2][4 * tx]);
+    t += *reinterpret_cast<const f32x4*>(&red[3][4 * tx]);
+    __bf16* o = reinterpret_cast<__bf16*>(jobs.j[blockIdx.y].out) + (long)grp * N + 4 * tx;
+    *reinterpret_cast<bf16x4_t*>(o) = bf16x4_t{(__bf16)t[0], (__bf16)t[1], (__bf16)t[2], (__bf16)t[3]};
+  }
+}
+
+extern "C" int fod_colsum_groups_multi(int dtype, int njobs, const void* const* ptrs, int groups, int group_rows, int N,
+                                       hipStream_t stream) {
+  FOD_REQUIRE(dtype == FOD_BF16, "colsum_groups_multi: bf16 only (dtype %d)", dtype);
+  FOD_REQUIRE(ptrs && njobs > 0 && njobs <= COLSUM_MAX_JOBS, "colsum_groups_multi: 1 .. %d jobs (%d)", COLSUM_MAX_JOBS, njobs);
+  FOD_REQUIRE(groups > 0 && groups <= 65535 && group_rows > 0 && N > 0 && N <= 256 && N % 4 == 0,
+              "colsum_groups_multi: %d groups of %d rows, N = %d (N <= 256, a multiple of 4)", groups, group_rows, N);
+  ColsumJobs jobs{};
+  for (int i = 0; i < njobs; ++i) {
+    jobs.j[i].g = ptrs[2 * i];
+    jobs.j[i].out = const_cast<void*>(ptrs[2 * i + 1]);
+    FOD_REQUIRE(jobs.j[i].g && jobs.j[i].out && ((uintptr_t)jobs.j[i].g % 8) == 0 && ((uintptr_t)jobs.j[i].out % 8) == 0,
+                "colsum_groups_multi: job %d: null or misaligned operand", i);
+  }
+  hipLaunchKernelGGL(colsum_groups_multi_kernel, dim3(groups, njobs), dim3(256), 0, stream, jobs, group_rows, N);
+  FOD_LAUNCH_CHECK();
+  return FOD_OK;
+}
+
 extern "C" int fod_eltwise(int op, int dtype, void* out, const void* a, const void* b, const void* c, long rows,
                            int cols, int b_row_div, int b_row_mod, float alpha, hipStream_t stream) {
   FOD_REQUIRE(out && a && rows > 0 && cols > 0 && rows < (1L << 31), "eltwise: bad args");

@@ -472,7 +472,7 @@ class TransformerEncoderLayer(nn.Module):
             self.egodeep_attend = None
 
     def forward(self, x, pos, egodeep: Optional[Tensor] = None, prevout: Optional[Tensor] = None, memory=None,
-                imu_pre: Optional[Tensor] = None):
+                imu_pre: Optional[Tensor] = None, imu_queue=None):
         """x [F,N,D]; pos table [N,D] or [F,N,D]; egodeep [F,D] (one IMU token per frame), [F,S,D] (S tokens) or
         None; prevout [F,N,D] or None; memory: list of [F,N,D] (most recent first) or None.  `imu_pre` [F,D]: this
         layer's one-key IMU block as TransformerEncoder computed it for all layers at once."""
@@ -492,7 +492,12 @@ class TransformerEncoderLayer(nn.Module):
             N = x.shape[1]
             e = imu_pre if imu_pre is not None else self.egodeep_attend.forward_single_key(egodeep)
             e = Fn.dropout(e, self.egodeep_attend.droprate, self.training)          # dropout_eda (reference :444,485)
-            x = Fn.layer_norm(x, self.norm_eda.weight, self.norm_eda.bias, residual=e, res_row_div=N)
+            if imu_queue is not None and e is imu_pre:
+                # (queue, slot): the gradient of this layer's IMU rows is summed with the other layers' in one launch
+                x = Fn.layer_norm(x, self.norm_eda.weight, self.norm_eda.bias, residual=e, res_row_div=N,
+                                  res_queue=imu_queue[0], res_slot=imu_queue[1])
+            else:
+                x = Fn.layer_norm(x, self.norm_eda.weight, self.norm_eda.bias, residual=e, res_row_div=N)
             if torch.is_grad_enabled():
                 x = Fn.ZeroGradAnchor.apply(x, *self.egodeep_attend.dead_parameters())
         return x
@@ -511,10 +516,12 @@ class TransformerEncoder(nn.Module):
         blocks = [getattr(layer, "egodeep_attend", None) for layer in self.layers]
         if (egodeep is not None and egodeep.dim() == 2 and all(b is not None for b in blocks)
                 and not any(b.training and b.droprate > 0.0 for b in blocks) and Fn.imu_branch_fits(egodeep, blocks)):
-            pre = Fn.imu_branch(egodeep, blocks)
+            queue = Fn.ResGradQueue(len(blocks)) if (Fn.RES_GRAD_QUEUE and torch.is_grad_enabled()) else None
+            pre = Fn.imu_branch(egodeep, blocks, queue=queue)
         for i, layer in enumerate(self.layers):
             if pre is not None:
-                x = layer(x, pos, egodeep, prevout, memory, imu_pre=pre[i])
+                x = layer(x, pos, egodeep, prevout, memory, imu_pre=pre[i],
+                          imu_queue=None if queue is None else (queue, i))
             else:
                 x = layer(x, pos, egodeep, prevout, memory)
         return x

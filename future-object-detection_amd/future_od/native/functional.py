@@ -928,15 +928,45 @@ def expand_rows(x, reps):
     return ExpandRowsFn.apply(x.contiguous(), reps)
 
 
+# "0": every encoder layer sums the gradient of its per-frame IMU rows itself (fod_colsum_acc + a cast per layer)
+RES_GRAD_QUEUE = os.environ.get("FOD_RES_GRAD_QUEUE", "1") != "0"
+
+
+class ResGradQueue:
+    """The gradients of P broadcast residual rows ([groups, D] each: the per-frame IMU rows that P encoder layers add to
+    their tokens) as slots of ONE [P, groups, D] buffer, filled by ONE launch (fod_colsum_groups_multi) when their reader
+    -- ImuBranchFn.backward -- is reached: a LayerNormFn whose residual is such a row hands its gradient's tokens over
+    and returns the (still unfilled) slot."""
+
+    def __init__(self, P):
+        self.P, self.buf, self.jobs, self.geom = P, None, [], None
+
+    def push(self, slot, g, groups, group_rows, D):
+        if self.buf is None:
+            self.buf = torch.empty((self.P, groups, D), dtype=g.dtype, device=g.device)
+        geom = (groups, group_rows, D)
+        assert self.geom in (None, geom) and tuple(self.buf.shape[1:]) == (groups, D)
+        self.geom = geom
+        self.jobs.append((g, self.buf[slot]))
+        return self.buf[slot]
+
+    def flush(self):
+        if self.jobs:
+            jobs, self.jobs = self.jobs, []
+            for i in range(0, len(jobs), 16):
+                ops.colsum_groups_multi(jobs[i:i + 16], *self.geom)
+
+
 class LayerNormFn(Function):
     """LayerNorm(x + residual[row(m)]) over the last dim."""
 
     @staticmethod
-    def forward(ctx, x, residual, gamma, beta, res_row_div):
+    def forward(ctx, x, residual, gamma, beta, res_row_div, res_queue=None, res_slot=0):
         y, s, mean, rstd = ops.layernorm_fwd(x, gamma, beta, residual=residual, res_row_div=res_row_div)
         ctx.save_for_backward(s, mean, rstd, gamma)
         ctx.res_row_div = res_row_div
         ctx.res_shape = None if residual is None else residual.shape
+        ctx.res_queue, ctx.res_slot = res_queue, res_slot
         return y
 
     @staticmethod
@@ -948,19 +978,25 @@ class LayerNormFn(Function):
         dx = ops.layernorm_bwd(dy.contiguous(), s, mean, rstd, gamma, dg, db)
         dres = None
         if ctx.res_shape is not None and ctx.needs_input_grad[1]:
-            if ctx.res_row_div:
-                rows = dx.numel() // D
+            rows = dx.numel() // D
+            if (ctx.res_row_div and ctx.res_queue is not None and dx.dtype == torch.bfloat16 and D <= 256 and D % 4 == 0
+                    and rows % ctx.res_row_div == 0):
+                # the sum over each frame's tokens waits for the other layers' (ResGradQueue): the slot is filled later
+                dres = ctx.res_queue.push(ctx.res_slot, dx.view(rows, D), rows // ctx.res_row_div, ctx.res_row_div,
+                                          D).view(ctx.res_shape)
+            elif ctx.res_row_div:
                 out = zeros_f32((rows // ctx.res_row_div, D), dy.device)
                 ops.colsum_acc(dx.view(rows, D), out, group_rows=ctx.res_row_div)
                 dres = cast(out, dx.dtype).view(ctx.res_shape)
             else:
                 dres = dx.view(ctx.res_shape)
-        return dx, dres, dg, db, None
+        return dx, dres, dg, db, None, None, None
 
 
-def layer_norm(x, gamma, beta, residual=None, res_row_div=0):
+def layer_norm(x, gamma, beta, residual=None, res_row_div=0, res_queue=None, res_slot=0):
+    """res_queue / res_slot (with res_row_div): the residual's gradient is summed later, with the other slots of the queue."""
     return LayerNormFn.apply(x.contiguous(), None if residual is None else residual.contiguous(), gamma, beta,
-                             res_row_div)
+                             res_row_div, res_queue, res_slot)
 
 
 # "0": the output projection and the post-norm of the decoder's attention blocks as two launches (fod_gemm_nt +
@@ -1747,7 +1783,9 @@ class ImuBranchFn(Function):
     -> P tensors [frames, D] (blocks of one buffer)."""
 
     @staticmethod
-    def forward(ctx, ego, P, use_mlp, *params):
+    def forward(ctx, ego, P, use_mlp, queue, *params):
+        """`queue` (ResGradQueue or None): where the consumers of the P results leave their gradients' sums pending."""
+        ctx.queue = queue
         groups = [params[i * P:(i + 1) * P] for i in range(len(params) // P)]
         wv, bv, wo, bo = groups[:4]
         M, D = ego.shape
@@ -1783,6 +1821,8 @@ class ImuBranchFn(Function):
         ego, t = saved[:2]
         M, D = ego.shape
         dtype, dev = ego.dtype, ego.device
+        if ctx.queue is not None:
+            ctx.queue.flush()                                # the slots handed out as gradients become real
         de = _as_segments(gs, M, D)
         if de is None or de.dtype != dtype:
             de = torch.empty((P, M, D), dtype=dtype, device=dev)
@@ -1833,7 +1873,7 @@ class ImuBranchFn(Function):
         dwv, dbv = zeros_f32((P * D, D), dev), zeros_f32((P * D,), dev)
         WGRADS.grouped(WGRADS.site(tuple(wv) + tuple(bv)), dt_, ego, dwv, dbv)
         sl = lambda v: [v[p_ * D:(p_ + 1) * D] for p_ in range(P)]
-        return (dego, None, None) + tuple(sl(dwv) + sl(dbv) + dwo + dbo + extra)
+        return (dego, None, None, None) + tuple(sl(dwv) + sl(dbv) + dwo + dbo + extra)
 
 
 def imu_branch_fits(ego, blocks):
@@ -1857,7 +1897,7 @@ def imu_branch_fits(ego, blocks):
     return D % 64 == 0 and (not b0.use_mlp or b0.mlp[0].weight.shape[0] % 64 == 0)
 
 
-def imu_branch(ego, blocks):
+def imu_branch(ego, blocks, queue=None):
     """[block.forward_single_key(ego) without dropout for block in blocks] in a handful of launches (ImuBranchFn)."""
     P = len(blocks)
     use_mlp = blocks[0].use_mlp
@@ -1868,7 +1908,7 @@ def imu_branch(ego, blocks):
                    + [b.mlp[0].weight for b in blocks] + [b.mlp[0].bias for b in blocks]
                    + [b.mlp[3].weight for b in blocks] + [b.mlp[3].bias for b in blocks]
                    + [b.norm2.weight for b in blocks] + [b.norm2.bias for b in blocks])
-    return list(ImuBranchFn.apply(ego.contiguous(), P, use_mlp, *params))
+    return list(ImuBranchFn.apply(ego.contiguous(), P, use_mlp, queue, *params))
 
 
 def _sum_leading(t, n):

@@ -100,6 +100,7 @@ SIGNATURES = {
     "fod_attn_fp8_pack_bytes": [_AS, _i, _p, _p],
     "fod_attn_quant_fp8": [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _AS, _p],
     "fod_attn_fwd_fp8": [_p, _p, _i, _p, _p, _AS, _p],
+    "fod_colsum_groups_multi": [_i, _i, _p, _i, _i, _i, _p],
     "fod_mlp2_mul_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _p],
     "fod_mlp2_mul_bwd": [_i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p],
     "fod_layernorm_fwd": [_i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _i, _f, _i, _p],

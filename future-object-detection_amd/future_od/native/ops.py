@@ -721,6 +721,18 @@ def linear_add_norm_bwd(dy, xsum, mean, rstd, gamma, w_t, dgamma, dbeta, want_da
     return dsum, da
 
 
+def colsum_groups_multi(jobs, groups, group_rows, N):
+    """out[g] = sum of the group_rows rows of group g of G, for up to 16 (G, out) pairs of one shape in one launch (bf16)."""
+    n = len(jobs)
+    assert 0 < n <= 16
+    arr = (C.c_void_p * (2 * n))()
+    for i, (g, out) in enumerate(jobs):
+        _chk(g, "g", torch.bfloat16); _chk(out, "out", torch.bfloat16)
+        assert g.numel() == groups * group_rows * N and out.numel() == groups * N
+        arr[2 * i], arr[2 * i + 1] = g.data_ptr(), out.data_ptr()
+    call("fod_colsum_groups_multi", BF16, n, C.addressof(arr), groups, group_rows, N, stream())
+
+
 def mlp2_mul_fwd(x, w1, b1, w2, b2, table=None):
     """((relu(x w1^T + b1)) w2^T + b2) * table[m % table_rows] in one launch (bf16, 256 -> 256 -> 256): (out, h, q) with h the
     hidden activations and q the MLP's output before the product (None without a table)."""

@@ -362,6 +362,13 @@ int fod_layernorm_bwd(int dtype, const void* dy, const void* xsum, const float* 
                       const float* gamma, void* dx, float* dgamma, float* dbeta, int rows, int D,
                       int group_rows, fod_stream_t stream);
 
+/* out_j[g, n] = sum over rows m of group g (group_rows consecutive rows) of G_j[m, n] for njobs <= 16 (G_j, out_j) pairs of
+ * ONE shape in one launch; bf16 in and out, f32 accumulation in a fixed order.  ptrs: host array of njobs x 2 addresses
+ * (G_j [groups * group_rows, N], out_j [groups, N]); N <= 256.  The gradients of the per-frame IMU rows the encoder layers'
+ * norm_eda adds to its tokens (transformer.py:444,485), one per layer, first read together. */
+int fod_colsum_groups_multi(int dtype, int njobs, const void* const* ptrs, int groups, int group_rows, int N,
+                            fod_stream_t stream);
+
 enum {
   FOD_EW_ADD = 0,       /* out = a + b[row(m)]            */
   FOD_EW_MUL = 1,       /* out = a * b[row(m)]            */
