@@ -1,12 +1,12 @@
 set -e
-o=gpurun_out/r03rq
+o=gpurun_out/r03w
 mkdir -p $o
-timeout -k 10 600 python -m pytest tests/test_model_gpu.py -m gpu -x -q > $o/test.log 2>&1 || { tail -40 $o/test.log; exit 1; }
-tail -1 $o/test.log
-timeout -k 10 900 python -m pytest tests/test_graph_gpu.py tests/test_fullsize_oracle_gpu.py tests/test_configs_gpu.py tests/test_parallel_gpu.py tests/test_train_gpu.py -m gpu -x -q > $o/test2.log 2>&1 || { tail -40 $o/test2.log; exit 1; }
-tail -1 $o/test2.log
-for v in 0 1 0 1; do
-  FOD_RES_GRAD_QUEUE=$v python bench.py --no-cpu-baseline --no-extras --no-roofline --steps 30 --warmup 5 2> $o/ab.err | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('FOD_RES_GRAD_QUEUE=$v', round(d['value'],2), round(d['ms_per_step'],3))" | tee -a $o/ab.txt
-done
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > $o/gpu_tests.txt 2>&1 || { tail -40 $o/gpu_tests.txt; exit 1; }
+tail -1 $o/gpu_tests.txt
+python __graft_entry__.py smoke 2>&1 | tail -1
+python bench.py > $o/bench_line.json 2> $o/bench.err
+python -c "import json; d=json.loads(open('$o/bench_line.json').read().strip().splitlines()[-1]); print(round(d['value'],2), round(d['ms_per_step'],3), d['roofline']['frac'], d['kernels_per_replayed_step'], d['roofline']['check'], {k:round(v['value'],1) for k,v in d['also'].items()})"
+bash tools/trace_graph.sh r03w_trace > /dev/null 2>&1
+python tools/trace_summary_graph.py gpurun_out/r03w_trace/kernel_trace.csv > $o/summary.txt 2>&1
+rm -f gpurun_out/r03w_trace/kernel_trace.csv
+head -1 $o/summary.txt
