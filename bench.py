@@ -39,6 +39,9 @@ WORKLOADS = {
 LIVE_FLOPS = WORKLOADS["headline"][5]
 
 
+MATCHER_EVENTS = []        # measure(): device-matcher failures of a timed run (the loss went non-finite), see there
+
+
 def live_flops_per_sequence(num_images):
     """Algorithmic FLOPs of one frame-sequence, forward + backward, live work only."""
     return LIVE_FLOPS
@@ -310,6 +313,15 @@ def main():
         if distributed:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # the device-side matcher reports a non-finite cost matrix one step late through a per-device status word: look at
+        # it HERE, so that a run of this model that went non-finite (the random-init model at lr 1e-4 does in some runs,
+        # DESIGN.md 5) is reported on ITS line instead of raising inside the next model built in this process
+        try:
+            from future_od.models.set_criterion import _lap_status
+            _lap_status(torch.device(device)).check(wait=True)
+        except Exception as e:                               # noqa: BLE001
+            MATCHER_EVENTS.append(f"{dtype}{'/' + a.attn_dtype if getattr(a, 'attn_dtype', 'bf16') != 'bf16' else ''}, "
+                                  f"num_images={num_images}: {e}")
         summ, nprof, replay = None, 2, None
         if profile and use_graph:
             # the profiling leg launches eagerly but must time the kernels the replayed step is made of: the weight
@@ -439,6 +451,8 @@ def main():
     # in GraphedStep -- bench.py has no eager fallback), and whether the weight-gradient queues were available (they need a
     # private torch symbol; without it ~170 extra launches run one by one)
     from future_od.native import functional as _Fn
+    if MATCHER_EVENTS:
+        result["matcher_events"] = list(MATCHER_EVENTS)
     result["fast_paths"] = {"captured_graph": bool(use_graph), "wgrad_queue": bool(_Fn.WGRADS.enabled),
                             "wgrad_queue_long": bool(_Fn.WGRADS.enabled and _Fn.WGRADS.long_enabled)}
     if use_graph and not _Fn.WGRADS.enabled and rank == 0:
